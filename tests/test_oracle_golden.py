@@ -1,0 +1,236 @@
+"""The oracle (oracle/aqe_oracle.c) against what the reference's own C++ returned here
+(tests/golden/ref_golden.json, made by oracle/make_golden.py).  Index sets: bit-exact.
+Sums: <= 1e-12 relative.  Estimates / intervals (CLI expressions): <= 1e-9."""
+import base64
+import math
+
+import numpy as np
+import pytest
+
+from helpers import digest, oracle_indices, rel
+from oracle.pyoracle import AVG, COUNT, SUM
+
+
+def _check_call(o, rows, call, cache_rows):
+    if call.get("threw"):
+        pytest.fail(f"reference threw on {call}")
+    idx = oracle_indices(o, rows, call, cache_rows)
+    assert idx is not None, call
+    if call.get("sorted"):
+        idx = np.sort(idx)
+    assert digest(idx) == call["idx"], (call["method"], call["pct"], call["args"])
+    amt = rows["amount"][idx.astype(np.int64)]
+    # same rows => the exactly rounded sums are identical, bit for bit
+    assert math.fsum(amt) == call["fsum"]
+    m = o.moments_idx(rows, idx)
+    assert m.n == call["idx"]["n"]
+    if m.n:
+        assert rel(m.sum, call["fsum"]) <= 1e-12
+        assert rel(m.sumsq, call["fsumsq"]) <= 1e-12
+    N = len(rows)
+    if "cli" in call:
+        c = call["cli"]
+        assert rel(o.lib.aqo_estimate_cli(SUM, N, m.n, m.sum), c["SUM"]) <= 1e-9
+        assert rel(o.lib.aqo_estimate_cli(AVG, N, m.n, m.sum), c["AVG"]) <= 1e-9
+        assert o.lib.aqo_estimate_cli(COUNT, N, m.n, m.sum) == c["COUNT"]
+        if "moe" in c:
+            moe, lo, hi = o.ci_cli(AVG, N, m.n, m.m2, m.sum / m.n)
+            assert rel(moe, c["moe"]) <= 1e-9
+            assert rel(lo, c["AVG_ci"][0]) <= 1e-9 and rel(hi, c["AVG_ci"][1]) <= 1e-9
+            est = o.lib.aqo_estimate_cli(SUM, N, m.n, m.sum)
+            _, lo, hi = o.ci_cli(SUM, N, m.n, m.m2, est)
+            assert rel(lo, c["SUM_ci"][0]) <= 1e-9 and rel(hi, c["SUM_ci"][1]) <= 1e-9
+            # the moment form (executor.cpp:180-199) agrees with the two-pass form
+            assert rel(o.lib.aqo_margin_moments(m.n, m.sum, m.sumsq), c["moe"]) <= 1e-7
+    if "where" in call:
+        w = call["where"]
+        mw = o.moments_idx(rows, idx, where=tuple(w["range"]))
+        assert mw.n == w["n"] and rel(mw.sum, w["fsum"]) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [10_000, 100_000, 100_007, 1_000_000])
+def test_deterministic_samplers_match_reference(oracle, golden, table, n):
+    T = golden["tables"][str(n)]
+    rows = table(n)
+    assert float(rows["amount"][0]) == T["amount0"]
+    assert T["cache_rows"] == (n // 1000) * 1000  # DB.cpp:188-191
+    for call in T["calls"]:
+        _check_call(oracle, rows, call, T["cache_rows"])
+
+
+@pytest.mark.parametrize("n", [10_000, 1_000_000])
+def test_seeded_random_sampler_seeds(oracle, golden, table, n):
+    rows = table(n)
+    for call in golden["tables"][str(n)]["random_seeds"]:
+        _check_call(oracle, rows, call, None)
+
+
+def test_mt19937_stream(oracle, golden):
+    for seed, vals in golden["mt19937_numpy_legacy"].items():
+        assert [int(x) for x in oracle.mt19937(int(seed), 8)] == vals
+
+
+@pytest.mark.parametrize("n", [10_000, 100_000, 100_007, 1_000_000])
+def test_exact_sums(oracle, golden, table, n):
+    T, rows = golden["tables"][str(n)], table(n)
+    m = oracle.moments_range(rows, 0, n)
+    assert m.n == n
+    assert m.sum == T["exact"]["sum_amount"]  # same sequential order as DB.cpp:246-249
+    assert rel(m.sum, T["exact"]["fsum"]) <= 1e-12
+    for w in T["exact"]["where"]:
+        mw = oracle.moments_range(rows, 0, n, where=tuple(w["range"]))
+        assert mw.sum == w["sum"] and rel(mw.sum, w["fsum"]) <= 1e-12 if w["fsum"] else mw.sum == 0.0
+
+
+@pytest.mark.slow
+def test_ten_million_rows_scalars(oracle, golden, table):
+    T = golden["tables"]["10000000"]
+    rows = table(10_000_000)
+    assert oracle.moments_range(rows, 0, len(rows)).sum == T["exact_sum"]
+    for call in T["calls"]:
+        _check_call(oracle, rows, call, 10_000_000)
+
+
+def test_clt_fast_worker_stop_points(oracle, golden, table):
+    """DB.cpp:936-961 decision function, pinned by where the reference's single fast worker stopped."""
+    rows = table(1_000_000)
+    x = rows["amount"]
+    for g in golden["tables"]["1000000"]["clt_fast_stop"]:
+        ci, e, step = g["check_interval"], g["e"], g["fast_step"]
+        vals = x[0::step]
+        z = oracle.lib.aqo_clt_zscore(0.95)
+        n, stop = 0, None
+        while n + ci <= len(vals):
+            n += ci
+            v = vals[:n]
+            mean = float(np.sum(v) / n)
+            var = float(np.sum((v - mean) ** 2) / (n - 1))
+            if oracle.lib.aqo_clt_fast_rule(n, mean, var, z, e):
+                stop = n
+                break
+        assert stop == g["n_fast_at_stop"], g
+
+
+def test_clt_round_synchronous_reference_cadence_single_fast(oracle, golden, table):
+    """With T=1... the pooled rule equals the single worker's rule: T=2 slow+fast pooled differs, so use
+    the decision scan above for the reference and here check the oracle's own driver is consistent with
+    its decision function at R0 = check_interval."""
+    rows = table(100_000)
+    rc, res, idx = oracle.clt_run(rows, 20.0, 0.95, 10, 4, 2.0, want_idx=True)
+    assert rc == 0 and res.converged == 1
+    z = oracle.lib.aqo_clt_zscore(0.95)
+    # replay: after every round of 10 samples per worker, the pooled rule must first fire at res.rounds
+    rc2, plan = oracle.clt_plan(len(rows), 20.0, 0.95, 10, 4)
+    vals = []
+    fired = None
+    for r in range(res.rounds):
+        for w in range(plan.n_workers):
+            wk = plan.w[w]
+            for k in range(r * 10, min((r + 1) * 10, wk.count)):
+                vals.append(rows["amount"][wk.first + k * wk.step])
+        v = np.array(vals)
+        mean = float(v.sum() / len(v))
+        var = float(((v - mean) ** 2).sum() / (len(v) - 1))
+        if oracle.lib.aqo_clt_fast_rule(len(v), mean, var, z, 2.0):
+            fired = r + 1
+            break
+    assert fired == res.rounds
+    assert res.all.n == len(vals)
+    # top-up of DB.cpp:1032-1040: collected < base/4 -> +base/4 systematic rows
+    base = plan.base
+    assert res.all.n < base // 4 and res.topup == base // 4 and res.final.n == res.all.n + res.topup
+    assert len(idx) == res.final.n
+
+
+def test_clt_distribution_of_reference_runs(oracle, golden, table):
+    """Statistical parity for the racy converging regime: the reference's own 30 runs (N=1M, pct 20,
+    e=1 %, T=4) bracket the deterministic round-synchronous result."""
+    rows = table(1_000_000)
+    runs = golden["tables"]["1000000"]["distributions"]["clt_e1_pct20_T4"]
+    rc, res, _ = oracle.clt_run(rows, 20.0, 0.95, 10, 4, 1.0)
+    assert rc == 0 and res.converged
+    avg = res.final.sum / res.final.n
+    ref_avgs = np.array([r["avg"] for r in runs])
+    true_mean = float(rows["amount"].mean())
+    # both within 1 % (the requested e) of the truth, and ours inside the reference's spread +- 3 sigma
+    assert abs(avg - true_mean) / true_mean <= 0.01
+    assert np.all(np.abs(ref_avgs - true_mean) / true_mean <= 0.01)
+    assert abs(avg - ref_avgs.mean()) <= 3 * max(ref_avgs.std(), 0.5)
+    # sample counts: reference returns collected + base/4 top-up (DB.cpp:1032-1040) => >= base/4
+    assert min(r["n"] for r in runs) >= 50_000 and res.final.n >= 50_000
+
+
+def test_random_device_reducers_are_statistically_consistent(oracle, golden, table):
+    rows = table(1_000_000)
+    d = golden["tables"]["1000000"]["distributions"]
+    exact = golden["tables"]["1000000"]["exact"]["sum_amount"]
+    # parallel_sum_sample: SUM * 100/pct over a 1 % simple random sample (DB.cpp:276-304)
+    idx = oracle.idx_random_pointer(len(rows), 1.0, 42)
+    m = oracle.moments_idx(rows, idx)
+    ours = oracle.lib.aqo_estimate_cpp(SUM, len(rows), 1.0, m.n, m.sum)
+    ref = np.array(d["parallel_sum_pct1_T4"])
+    sigma = 288.4 * 100 * math.sqrt(m.n)  # sd of the scaled sum
+    assert abs(ours - exact) <= 4 * sigma and np.all(np.abs(ref - exact) <= 4 * sigma)
+    assert all(c == 1_000_000 for c in d["parallel_count_pct1_T4"])
+    assert oracle.lib.aqo_estimate_cpp(COUNT, len(rows), 1.0, m.n, m.sum) == 1_000_000
+    # fast_aggregated_memory_stride_sum: raw sum at overall rate pct/T
+    idx = oracle.idx_region_stride(len(rows), 1.0, 4, seed=7, reference_partition=True)
+    assert len(idx) == 2500
+    ours = oracle.moments_idx(rows, idx).sum
+    ref = np.array(d["fast_aggregated_pct1_T4"])
+    assert abs(ours - ref.mean()) <= 4 * max(ref.std(), 288.4 * math.sqrt(2500))
+
+
+def test_small_n_quirks_of_the_real_tree(oracle, golden):
+    """memory_stride_sample's fallback reads root->subtree_record_count, which only a leaf root
+    maintains (DB.cpp:1569-1571): 255 <= N < 1000 returns nothing.  The oracle takes the visible row
+    count M explicitly, so the quirk is M = 0 there."""
+    for q in golden["small_n_quirks"]:
+        N = q["N"]
+        M = N if N < 255 else (N // 1000) * 1000
+        idx = oracle.idx_memory_stride(M, 10.0, 0)
+        assert len(idx) == q["memory_stride_n"]
+        assert [int(i) for i in idx[:4]] == q["first"]
+        assert len(oracle.idx_block(N, 10.0, 10)) == q["block_n"]
+    g = golden["insert_vs_direct_3000"]
+    assert g["identical"] and g["cache_rows"] == 3000
+
+
+def test_file_format_written_by_reference(oracle, golden, tmp_path):
+    raw = base64.b64decode(golden["file_5_rows_b64"])
+    assert len(raw) == 24 + 5 * 32  # DB.cpp:669-680
+    p = tmp_path / "five.db"
+    p.write_bytes(raw)
+    rows = oracle.file_read(p)
+    want = oracle.synth(5, 42)
+    assert rows.tobytes() == want.tobytes()
+    q = tmp_path / "mine.db"
+    assert oracle.file_write(q, want, height=1) == 0
+    assert q.read_bytes() == raw
+
+
+def test_confidence_heuristic(oracle, golden):
+    for c in golden["confidence"]:
+        assert oracle.lib.aqo_confidence_heuristic(c["pct"], c["N"]) == c["value"]
+
+
+def test_error_to_percent_map(oracle):
+    # enhanced_aqe_cli.py:243-250
+    assert [oracle.lib.aqo_error_to_percent(e) for e in (0.01, 1.0, 1.5, 2.0, 3.0, 5.0, 7.0)] == \
+        [20, 20, 15, 15, 10, 10, 5]
+
+
+def test_invalid_parameters_where_reference_divides_by_zero(oracle):
+    assert oracle.clt_plan(1000, 0.1, 0.95, 10, 4)[0] == -1   # base=1, base/F == 0 (DB.cpp:927)
+    assert oracle.clt_plan(100_000, 10.0, 0.95, 1, 4)[0] == -1  # check_interval/2 == 0 (DB.cpp:993)
+    assert oracle.idx_dual_pointer(100, 2.0) is None          # fast_target == 0 (DB.cpp:799)
+    assert len(oracle.idx_memory_stride(0, 10.0)) == 0
+    assert len(oracle.idx_block(10, 1.0, 1000)) == 0          # target 0 -> empty
+
+
+def test_synthetic_generator_properties(oracle):
+    a = oracle.synth(1000, 42, first=0)
+    b = oracle.synth(500, 42, first=500)
+    assert a[500:].tobytes() == b.tobytes()        # shard-independent
+    assert a["id"][0] == 1 and a["region"][5] == 1 and a["product_id"][123] == 23 and a["timestamp"][7] == 7
+    assert 1.0 <= a["amount"].min() and a["amount"].max() < 1000.0
