@@ -1,0 +1,788 @@
+// capi.hip — the C ABI of include/aqe_hip.h: context, staging into HBM, plan objects, enqueue/fetch.
+// Host code only (compiled by hipcc for the HIP runtime API); the kernels live in kernels.hip.
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "planner.hpp"
+
+using namespace aqe;
+
+static_assert(sizeof(aqe_record) == 32, "row layout of DB.hpp:17-27");
+static_assert(sizeof(QueryState) % 8 == 0, "state is memset as a block");
+
+namespace {
+thread_local std::string g_create_error;
+
+struct LaunchDesc {
+    size_t fam_offset = 0;
+    uint32_t nfam = 0;
+    uint64_t ntiles = 0;
+    uint64_t samples = 0;  // ordinals in this launch's windows (upper bound for the top-up)
+};
+
+constexpr size_t kStageChunkRows = 1u << 21;  // 2 Mi rows: 64 MiB of AoS per pinned buffer
+}  // namespace
+
+struct aqe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // table (one shard)
+    double* amount = nullptr;
+    aqe_record* aos = nullptr;
+    bool owns_table = true;
+    bool staged = false;
+    uint64_t n_global = 0, shard_lo = 0, n_local = 0;
+    double shift = 0.0;
+    uint64_t hbm_bytes = 0;
+    uint64_t table_epoch = 0;
+    // scratch shared by every launch of this context (one query in flight per context)
+    double* partials = nullptr;
+    unsigned* counter = nullptr;
+    // prepared plans of aqe_reduce / aqe_gather, keyed by the query bytes
+    std::vector<std::pair<aqe_query, aqe_plan*>> cache;
+};
+
+struct aqe_plan {
+    aqe_ctx* ctx = nullptr;
+    aqe_query q{};
+    HostPlan host;
+    uint64_t table_epoch = 0;
+    DevFamily* d_fams = nullptr;
+    std::vector<DevFamily> h_fams;
+    std::vector<LaunchDesc> rounds;
+    LaunchDesc topup;
+    uint64_t* d_idx = nullptr;
+    QueryState* d_state = nullptr;
+    aqe_result* d_result = nullptr;
+    aqe_result* h_result = nullptr;  // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+int fail(aqe_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(ctx, AQE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+void free_table(aqe_ctx* c) {
+    if (c->owns_table) {
+        if (c->amount) (void)hipFree(c->amount);
+        if (c->aos) (void)hipFree(c->aos);
+    }
+    c->amount = nullptr;
+    c->aos = nullptr;
+    c->owns_table = true;
+    c->staged = false;
+    c->n_global = c->shard_lo = c->n_local = 0;
+    c->hbm_bytes = 0;
+    c->table_epoch++;
+}
+
+void destroy_plan(aqe_plan* p) {
+    if (!p) return;
+    if (p->d_fams) (void)hipFree(p->d_fams);
+    if (p->d_idx) (void)hipFree(p->d_idx);
+    if (p->d_state) (void)hipFree(p->d_state);
+    if (p->d_result) (void)hipFree(p->d_result);
+    if (p->h_result) (void)hipHostFree(p->h_result);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+}
+
+void drop_cache(aqe_ctx* c) {
+    for (auto& kv : c->cache) destroy_plan(kv.second);
+    c->cache.clear();
+}
+
+int alloc_table(aqe_ctx* c, uint64_t n_local, bool keep_aos) {
+    free_table(c);
+    drop_cache(c);
+    if (n_local == 0) return AQE_OK;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->amount), n_local * sizeof(double)));
+    c->hbm_bytes = n_local * sizeof(double);
+    if (keep_aos) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->aos), n_local * sizeof(aqe_record)));
+        c->hbm_bytes += n_local * sizeof(aqe_record);
+    }
+    return AQE_OK;
+}
+
+// Tile decomposition of one family window (kernels.hpp: one wave folds kTileOrdinals per tile).
+void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f, uint64_t& out_pos) {
+    if (f.ord_hi <= f.ord_lo) return;
+    DevFamily d{};
+    d.row0 = f.row0; d.pitch = f.pitch; d.seg_len = f.seg_len; d.step = f.step;
+    d.ord_lo = f.ord_lo; d.ord_hi = f.ord_hi; d.group = f.group; d.flags = f.flags;
+    const uint64_t s_lo = f.ord_lo / f.seg_len, s_hi = (f.ord_hi - 1) / f.seg_len;
+    uint64_t ntiles;
+    d.seg_lo = s_lo;
+    if (s_lo == s_hi) {
+        d.tiles_per_seg = 0;
+        d.j_lo = (f.ord_lo % f.seg_len) / kTileOrdinals;
+        ntiles = ((f.ord_hi - 1) % f.seg_len) / kTileOrdinals + 1 - d.j_lo;
+    } else {
+        d.tiles_per_seg = (f.seg_len + kTileOrdinals - 1) / kTileOrdinals;
+        d.j_lo = 0;
+        ntiles = (s_hi - s_lo + 1) * d.tiles_per_seg;
+    }
+    d.tile_begin = L.ntiles;
+    d.out_begin = out_pos;
+    out_pos += f.ord_hi - f.ord_lo;
+    L.ntiles += ntiles;
+    L.nfam += 1;
+    L.samples += f.ord_hi - f.ord_lo;
+    out.push_back(d);
+}
+
+FoldParams fold_params(const aqe_plan* p, bool topup) {
+    FoldParams f{};
+    f.shift = p->ctx->shift;
+    f.z = p->host.clt.z;
+    f.e = p->host.clt.e;
+    f.base = p->host.clt.base;
+    f.is_clt = p->host.is_clt ? 1 : 0;
+    f.is_topup = topup ? 1 : 0;
+    return f;
+}
+
+RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, bool topup, bool fused, double* out_vec) {
+    const aqe_ctx* c = p->ctx;
+    RoundLaunch a{};
+    a.amount = c->amount;
+    a.shard_lo = c->shard_lo;
+    a.fams = p->d_fams ? p->d_fams + L.fam_offset : nullptr;
+    a.nfam = L.nfam;
+    a.ntiles = L.ntiles;
+    a.has_where = p->q.has_where ? 1 : 0;
+    a.wmin = p->q.where_min;
+    a.wmax = p->q.where_max;
+    a.partials = c->partials;
+    a.counter = c->counter;
+    a.out_vec = out_vec;
+    a.state = p->d_state;
+    a.fused = fused ? 1 : 0;
+    a.check_stop = p->host.is_clt ? 1 : 0;
+    a.fold = fold_params(p, topup);
+    return a;
+}
+
+int plan_is_current(aqe_plan* p) {
+    if (!p || !p->ctx) return AQE_ERR_INVALID;
+    if (p->table_epoch != p->ctx->table_epoch)
+        return fail(p->ctx, AQE_ERR_INVALID, "plan was created for a table that has since been replaced");
+    return AQE_OK;
+}
+
+hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStream_t>(stream) : p->ctx->stream; }
+
+int enqueue_launch(aqe_plan* p, const LaunchDesc& L, bool topup, bool fused, double* out_vec, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    RoundLaunch a = round_launch(p, L, topup, fused, out_vec);
+    if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s));
+    else HIPCHK(c, launch_round(a, s));
+    return AQE_OK;
+}
+
+FinalizeParams finalize_params(const aqe_plan* p) {
+    FinalizeParams f{};
+    f.n_global = p->ctx->n_global;
+    f.pct = p->q.sample_percent;
+    f.agg = p->q.agg;
+    f.convention = p->q.convention;
+    f.is_exact = p->q.method == AQE_M_EXACT;
+    f.is_clt = p->host.is_clt;
+    return f;
+}
+
+int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    std::unique_ptr<aqe_plan, void (*)(aqe_plan*)> p(new aqe_plan(), destroy_plan);
+    p->ctx = c;
+    p->q = *q;
+    p->table_epoch = c->table_epoch;
+    std::string err;
+    int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err);
+    if (rc != AQE_OK) return fail(c, rc, err);
+    uint64_t out_pos = 0;
+    for (const auto& rf : p->host.round_fams) {
+        LaunchDesc L;
+        L.fam_offset = p->h_fams.size();
+        for (const auto& f : rf) add_family(p->h_fams, L, f, out_pos);
+        p->rounds.push_back(L);
+    }
+    if (p->host.is_random) {
+        LaunchDesc L;
+        L.samples = p->host.random_idx.size();
+        p->rounds.assign(1, L);
+    }
+    if (p->host.has_topup) {
+        p->topup.fam_offset = p->h_fams.size();
+        for (const auto& f : p->host.topup_fams) add_family(p->h_fams, p->topup, f, out_pos);
+    }
+    if (!p->h_fams.empty()) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams), p->h_fams.size() * sizeof(DevFamily)));
+        HIPCHK(c, hipMemcpy(p->d_fams, p->h_fams.data(), p->h_fams.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
+    }
+    if (!p->host.random_idx.empty()) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_idx), p->host.random_idx.size() * sizeof(uint64_t)));
+        HIPCHK(c, hipMemcpy(p->d_idx, p->host.random_idx.data(), p->host.random_idx.size() * sizeof(uint64_t),
+                            hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
+    HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_result), sizeof(aqe_result)));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), sizeof(aqe_result), hipHostMallocDefault));
+    HIPCHK(c, hipEventCreate(&p->ev0));
+    HIPCHK(c, hipEventCreate(&p->ev1));
+    *out = p.release();
+    return AQE_OK;
+}
+
+int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
+    for (auto& kv : c->cache)
+        if (std::memcmp(&kv.first, q, sizeof(aqe_query)) == 0) { *out = kv.second; return AQE_OK; }
+    aqe_plan* p = nullptr;
+    int rc = create_plan(c, q, &p);
+    if (rc != AQE_OK) return rc;
+    if (c->cache.size() >= 64) { destroy_plan(c->cache.front().second); c->cache.erase(c->cache.begin()); }
+    c->cache.emplace_back(*q, p);
+    *out = p;
+    return AQE_OK;
+}
+
+int enqueue_all(aqe_plan* p, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
+    HIPCHK(c, hipEventRecord(p->ev0, s));
+    for (const auto& L : p->rounds) {
+        int rc = enqueue_launch(p, L, false, true, nullptr, s);
+        if (rc != AQE_OK) return rc;
+    }
+    if (p->host.has_topup) {
+        int rc = enqueue_launch(p, p->topup, true, true, nullptr, s);
+        if (rc != AQE_OK) return rc;
+    }
+    HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
+    HIPCHK(c, hipEventRecord(p->ev1, s));
+    p->timed = true;
+    return AQE_OK;
+}
+
+int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    HIPCHK(c, hipMemcpyAsync(p->h_result, p->d_result, sizeof(aqe_result), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *out = *p->h_result;
+    if (p->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) out->kernel_ms = ms;
+    }
+    return AQE_OK;
+}
+
+int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64_t shard_lo, uint64_t n_global,
+                    uint32_t flags) {
+    if (shard_lo + n_local > n_global) return fail(c, AQE_ERR_INVALID, "shard exceeds the table");
+    if (n_local && !rows) return fail(c, AQE_ERR_INVALID, "null rows");
+    const bool keep = flags & AQE_STAGE_KEEP_AOS;
+    int rc = alloc_table(c, n_local, keep);
+    if (rc != AQE_OK) return rc;
+    c->n_global = n_global;
+    c->shard_lo = shard_lo;
+    c->n_local = n_local;
+    c->staged = true;
+    c->shift = n_local ? rows[0].amount : 0.0;  // callers sharding a table overwrite this (aqe_set_shift)
+    if (n_local == 0) return AQE_OK;
+    // Double-buffered pinned bounce: the CPU fills buffer b while the DMA engine drains buffer b^1.
+    // Without KEEP_AOS only the amount column crosses PCIe (8 of every 32 bytes).
+    const size_t row_bytes = keep ? sizeof(aqe_record) : sizeof(double);
+    void* pinned[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(c, hipHostMalloc(&pinned[b], kStageChunkRows * row_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+    }
+    int status = AQE_OK;
+    for (uint64_t off = 0, k = 0; off < n_local && status == AQE_OK; off += kStageChunkRows, ++k) {
+        const int b = static_cast<int>(k & 1);
+        const uint64_t m = std::min<uint64_t>(kStageChunkRows, n_local - off);
+        if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) { status = fail(c, AQE_ERR_HIP, "event sync"); break; }
+        hipError_t e;
+        if (keep) {
+            std::memcpy(pinned[b], rows + off, m * sizeof(aqe_record));
+            e = hipMemcpyAsync(c->aos + off, pinned[b], m * sizeof(aqe_record), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_split_amount(c->aos + off, c->amount + off, m, c->stream);
+        } else {
+            double* dst = static_cast<double*>(pinned[b]);
+            for (uint64_t i = 0; i < m; ++i) dst[i] = rows[off + i].amount;
+            e = hipMemcpyAsync(c->amount + off, pinned[b], m * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(done[b], c->stream);
+        if (e != hipSuccess) status = fail(c, AQE_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess && status == AQE_OK) status = fail(c, AQE_ERR_HIP, std::string("staging sync: ") + hipGetErrorString(e));
+    for (int b = 0; b < 2; ++b) {
+        if (pinned[b]) (void)hipHostFree(pinned[b]);
+        if (done[b]) (void)hipEventDestroy(done[b]);
+    }
+    if (status != AQE_OK) free_table(c);
+    return status;
+}
+
+struct MappedFile {
+    void* base = MAP_FAILED;
+    size_t bytes = 0;
+    int fd = -1;
+    ~MappedFile() {
+        if (base != MAP_FAILED) munmap(base, bytes);
+        if (fd >= 0) close(fd);
+    }
+};
+
+int open_db_file(aqe_ctx* c, const char* path, MappedFile& mf, uint64_t& count) {
+    mf.fd = open(path, O_RDONLY);
+    if (mf.fd < 0) return fail(c, AQE_ERR_IO, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(mf.fd, &st) != 0 || st.st_size < 24) return fail(c, AQE_ERR_IO, std::string("not an aqe database file: ") + path);
+    mf.bytes = static_cast<size_t>(st.st_size);
+    mf.base = mmap(nullptr, mf.bytes, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+    if (mf.base == MAP_FAILED) return fail(c, AQE_ERR_IO, std::string("mmap failed: ") + path);
+    uint64_t hdr[3];  // size_t total | size_t height | size_t count, DB.cpp:669-676
+    std::memcpy(hdr, mf.base, sizeof hdr);
+    count = hdr[2];
+    if (24 + count * sizeof(aqe_record) > mf.bytes) return fail(c, AQE_ERR_IO, std::string("truncated database file: ") + path);
+    return AQE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aqe_abi_version(void) { return AQE_ABI_VERSION; }
+
+const char* aqe_status_string(int s) {
+    switch (s) {
+        case AQE_OK: return "ok";
+        case AQE_ERR_INVALID: return "invalid argument";
+        case AQE_ERR_HIP: return "HIP error";
+        case AQE_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case AQE_ERR_NO_TABLE: return "no table staged";
+        case AQE_ERR_IO: return "I/O error";
+        case AQE_ERR_CAPACITY: return "output buffer too small";
+        case AQE_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+const char* aqe_last_error(const aqe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int aqe_create(int device_id, aqe_ctx** out) {
+    if (!out) return fail(nullptr, AQE_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, AQE_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, AQE_ERR_INVALID, "device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, AQE_ERR_NO_DEVICE, "cannot query device");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, AQE_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    std::unique_ptr<aqe_ctx> c(new aqe_ctx());
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "stream creation failed");
+    if (hipMalloc(reinterpret_cast<void**>(&c->partials), sizeof(double) * kVec * kMaxBlocks) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->counter), 64) != hipSuccess ||
+        hipMemset(c->counter, 0, 64) != hipSuccess || hipMemset(c->partials, 0, sizeof(double) * kVec * kMaxBlocks) != hipSuccess)
+        return fail(nullptr, AQE_ERR_HIP, "scratch allocation failed");
+    *out = c.release();
+    return AQE_OK;
+}
+
+void aqe_destroy(aqe_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_cache(c);
+    free_table(c);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->counter) (void)hipFree(c->counter);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int aqe_stage_records(aqe_ctx* c, const void* aos32, uint64_t n_local, uint64_t shard_lo, uint64_t n_global, uint32_t flags) {
+    if (!c) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return stage_from_host(c, static_cast<const aqe_record*>(aos32), n_local, shard_lo, n_global, flags);
+}
+
+int aqe_file_rows(const char* path, uint64_t* n_rows) {
+    if (!path || !n_rows) return AQE_ERR_INVALID;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(nullptr, AQE_ERR_IO, std::string("cannot open ") + path);
+    uint64_t hdr[3];
+    size_t got = std::fread(hdr, sizeof hdr, 1, f);
+    std::fclose(f);
+    if (got != 1) return fail(nullptr, AQE_ERR_IO, std::string("not an aqe database file: ") + path);
+    *n_rows = hdr[2];
+    return AQE_OK;
+}
+
+int aqe_stage_file(aqe_ctx* c, const char* path, uint64_t shard_lo, uint64_t n_local, uint32_t flags) {
+    if (!c || !path) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    MappedFile mf;
+    uint64_t count = 0;
+    int rc = open_db_file(c, path, mf, count);
+    if (rc != AQE_OK) return rc;
+    if (shard_lo > count) return fail(c, AQE_ERR_INVALID, "shard_lo beyond the end of the file");
+    if (n_local == 0) n_local = count - shard_lo;
+    if (shard_lo + n_local > count) return fail(c, AQE_ERR_INVALID, "shard exceeds the file");
+    (void)madvise(mf.base, mf.bytes, MADV_SEQUENTIAL);
+    const aqe_record* rows = reinterpret_cast<const aqe_record*>(static_cast<const char*>(mf.base) + 24);
+    rc = stage_from_host(c, rows + shard_lo, n_local, shard_lo, count, flags);
+    if (rc == AQE_OK && count) c->shift = rows[0].amount;  // global row 0: identical on every shard
+    return rc;
+}
+
+int aqe_save_file(aqe_ctx* c, const char* path) {
+    if (!c || !path) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_local && !c->aos) return fail(c, AQE_ERR_UNSUPPORTED, "save needs the rows resident (AQE_STAGE_KEEP_AOS)");
+    if (c->shard_lo != 0 || c->n_local != c->n_global) return fail(c, AQE_ERR_UNSUPPORTED, "save needs the whole table in this context");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(c, AQE_ERR_IO, std::string("cannot create ") + path);
+    uint64_t height = 1;  // informational: the reference rebuilds its tree on load (DB.cpp:703-710)
+    for (uint64_t cap = 254; c->n_global > cap; cap *= 128) ++height;
+    uint64_t hdr[3] = {c->n_global, height, c->n_global};
+    bool ok = std::fwrite(hdr, sizeof hdr, 1, f) == 1;
+    std::vector<aqe_record> buf(std::min<uint64_t>(kStageChunkRows, std::max<uint64_t>(c->n_local, 1)));
+    for (uint64_t off = 0; ok && off < c->n_local; off += buf.size()) {
+        uint64_t m = std::min<uint64_t>(buf.size(), c->n_local - off);
+        if (hipMemcpy(buf.data(), c->aos + off, m * sizeof(aqe_record), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = std::fwrite(buf.data(), sizeof(aqe_record), m, f) == m;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? AQE_OK : fail(c, AQE_ERR_IO, std::string("write failed: ") + path);
+}
+
+int aqe_generate_synthetic(aqe_ctx* c, uint64_t n_local, uint64_t shard_lo, uint64_t n_global, uint64_t seed, uint32_t flags) {
+    if (!c) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (shard_lo + n_local > n_global) return fail(c, AQE_ERR_INVALID, "shard exceeds the table");
+    int rc = alloc_table(c, n_local, flags & AQE_STAGE_KEEP_AOS);
+    if (rc != AQE_OK) return rc;
+    c->n_global = n_global;
+    c->shard_lo = shard_lo;
+    c->n_local = n_local;
+    c->staged = true;
+    {   // amount of global row 0, the same expression the kernel evaluates
+        uint64_t z = seed + 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        c->shift = 1.0 + 999.0 * (static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0));
+    }
+    HIPCHK(c, launch_synth(c->aos, c->amount, n_local, shard_lo, seed, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AQE_OK;
+}
+
+int aqe_attach_device(aqe_ctx* c, const double* dev_amount, const void* dev_aos32, uint64_t n_local, uint64_t shard_lo,
+                      uint64_t n_global, double shift) {
+    if (!c) return AQE_ERR_INVALID;
+    if (n_local && !dev_amount) return fail(c, AQE_ERR_INVALID, "null amount column");
+    if (shard_lo + n_local > n_global) return fail(c, AQE_ERR_INVALID, "shard exceeds the table");
+    free_table(c);
+    drop_cache(c);
+    c->owns_table = false;
+    c->staged = true;
+    c->amount = const_cast<double*>(dev_amount);
+    c->aos = static_cast<aqe_record*>(const_cast<void*>(dev_aos32));
+    c->n_local = n_local;
+    c->shard_lo = shard_lo;
+    c->n_global = n_global;
+    c->shift = shift;
+    return AQE_OK;
+}
+
+int aqe_set_shift(aqe_ctx* c, double shift) {
+    if (!c) return AQE_ERR_INVALID;
+    c->shift = shift;
+    drop_cache(c);
+    return AQE_OK;
+}
+
+int aqe_table_info_get(const aqe_ctx* c, aqe_table_info* out) {
+    if (!c || !out) return AQE_ERR_INVALID;
+    out->global_rows = c->n_global;
+    out->shard_lo = c->shard_lo;
+    out->local_rows = c->n_local;
+    out->shift = c->shift;
+    out->has_aos = c->aos != nullptr;
+    out->device_id = c->device;
+    out->hbm_bytes = c->hbm_bytes;
+    return AQE_OK;
+}
+
+int aqe_release_table(aqe_ctx* c) {
+    if (!c) return AQE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drop_cache(c);
+    free_table(c);
+    return AQE_OK;
+}
+
+// ---- host planning ------------------------------------------------------------------------------
+void aqe_query_defaults(aqe_query* q) {
+    if (!q) return;
+    std::memset(q, 0, sizeof *q);
+    q->method = AQE_M_MEMORY_STRIDE;
+    q->agg = AQE_SUM;
+    q->convention = AQE_EST_CLI;
+    q->num_threads = 4;        // BIND:62-101 defaults
+    q->sample_percent = 10.0;
+    q->block_size = 1000;
+    q->seed = 42;
+    q->step_size = 2;
+    q->check_interval = 10;
+    q->confidence_level = 0.95;
+    q->max_error_percent = 2.0;
+    q->clt_growth = 1;
+}
+
+int aqe_plan_families(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, uint64_t shard_hi, uint32_t round,
+                      aqe_family* fams, uint32_t cap, uint32_t* n_out, uint32_t* rounds_out, uint64_t* samples_out) {
+    if (!q) return AQE_ERR_INVALID;
+    HostPlan P;
+    std::string err;
+    int rc = build_plan(*q, n_global, ClipWindow{shard_lo, shard_hi}, P, err);
+    if (rc != AQE_OK) return fail(nullptr, rc, err);
+    if (rounds_out) *rounds_out = P.rounds;
+    if (samples_out) *samples_out = P.global_samples;
+    const std::vector<aqe_family>* src = nullptr;
+    static const std::vector<aqe_family> none;
+    if (P.is_random) src = &none;
+    else if (round < P.round_fams.size()) src = &P.round_fams[round];
+    else if (round == P.rounds && P.has_topup) src = &P.topup_fams;
+    else src = &none;
+    if (n_out) *n_out = static_cast<uint32_t>(src->size());
+    if (fams) {
+        if (cap < src->size()) return fail(nullptr, AQE_ERR_CAPACITY, "family buffer too small");
+        std::copy(src->begin(), src->end(), fams);
+    }
+    return AQE_OK;
+}
+
+int aqe_plan_random_indices(uint64_t n_global, double pct, uint32_t seed, uint64_t shard_lo, uint64_t shard_hi,
+                            uint64_t* out, uint64_t cap, uint64_t* n_out) {
+    std::vector<uint64_t> idx;
+    std::string err;
+    int rc = random_pointer_indices(n_global, pct, seed, ClipWindow{shard_lo, shard_hi}, idx, err);
+    if (rc != AQE_OK) return fail(nullptr, rc, err);
+    if (n_out) *n_out = idx.size();
+    if (out) {
+        if (cap < idx.size()) return fail(nullptr, AQE_ERR_CAPACITY, "index buffer too small");
+        std::copy(idx.begin(), idx.end(), out);
+    }
+    return AQE_OK;
+}
+
+int aqe_parse_where(const char* query, double* lo, double* hi) {
+    double a, b;
+    bool found = parse_where(query, &a, &b);
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+    return found ? 1 : 0;
+}
+
+double aqe_confidence_heuristic(double pct, uint64_t total) { return confidence_heuristic(pct, total); }
+double aqe_error_to_sample_percent(double e) { return error_to_sample_percent(e); }
+
+// ---- plans --------------------------------------------------------------------------------------
+int aqe_plan_create(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
+    if (!c || !q || !out) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return create_plan(c, q, out);
+}
+
+void aqe_plan_destroy(aqe_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    destroy_plan(p);
+}
+
+int aqe_plan_rounds(const aqe_plan* p, uint32_t* rounds, int32_t* has_topup) {
+    if (!p) return AQE_ERR_INVALID;
+    if (rounds) *rounds = static_cast<uint32_t>(p->rounds.size());
+    if (has_topup) *has_topup = p->host.has_topup ? 1 : 0;
+    return AQE_OK;
+}
+
+int aqe_plan_reset(aqe_plan* p, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    hipStream_t s = pick(p, stream);
+    HIPCHK(p->ctx, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
+    p->timed = false;
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_round(aqe_plan* p, uint32_t round, double* dev_vec, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!dev_vec) return fail(p->ctx, AQE_ERR_INVALID, "dev_vec is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    const bool topup = round == p->rounds.size() && p->host.has_topup;
+    if (!topup && round >= p->rounds.size()) return fail(p->ctx, AQE_ERR_INVALID, "round out of range");
+    return enqueue_launch(p, topup ? p->topup : p->rounds[round], topup, false, dev_vec, pick(p, stream));
+}
+
+int aqe_plan_enqueue_update(aqe_plan* p, uint32_t round, const double* dev_vec, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!dev_vec) return fail(p->ctx, AQE_ERR_INVALID, "dev_vec is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    const bool topup = round == p->rounds.size() && p->host.has_topup;
+    if (!topup && round >= p->rounds.size()) return fail(p->ctx, AQE_ERR_INVALID, "round out of range");
+    HIPCHK(p->ctx, launch_update(p->d_state, dev_vec, fold_params(p, topup), pick(p, stream)));
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_finalize(aqe_plan* p, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    HIPCHK(p->ctx, launch_finalize(p->d_state, finalize_params(p), p->d_result, pick(p, stream)));
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_all(aqe_plan* p, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    return enqueue_all(p, pick(p, stream));
+}
+
+int aqe_plan_fetch(aqe_plan* p, aqe_result* out, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!out) return AQE_ERR_INVALID;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    return fetch(p, out, pick(p, stream));
+}
+
+int aqe_plan_last_kernel_ms(aqe_plan* p, float* ms) {
+    if (!p || !ms) return AQE_ERR_INVALID;
+    if (!p->timed) return fail(p->ctx, AQE_ERR_INVALID, "no timed execution yet");
+    HIPCHK(p->ctx, hipEventSynchronize(p->ev1));
+    HIPCHK(p->ctx, hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return AQE_OK;
+}
+
+// ---- one-call forms -----------------------------------------------------------------------------
+int aqe_reduce(aqe_ctx* c, const aqe_query* q, aqe_result* out) {
+    if (!c || !q || !out) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->shard_lo != 0 || c->n_local != c->n_global)
+        return fail(c, AQE_ERR_UNSUPPORTED, "aqe_reduce needs the whole table in this context; use the stepwise plan API for shards");
+    aqe_plan* p = nullptr;
+    int rc = cached_plan(c, q, &p);
+    if (rc != AQE_OK) return rc;
+    rc = enqueue_all(p, c->stream);
+    if (rc != AQE_OK) return rc;
+    return fetch(p, out, c->stream);
+}
+
+int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, uint64_t* n_out) {
+    if (!c || !q || !n_out) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_local && !c->aos) return fail(c, AQE_ERR_UNSUPPORTED, "record-returning samplers need AQE_STAGE_KEEP_AOS");
+    if (c->shard_lo != 0 || c->n_local != c->n_global) return fail(c, AQE_ERR_UNSUPPORTED, "aqe_gather needs the whole table in this context");
+    if (q->method == AQE_M_EXACT) return fail(c, AQE_ERR_UNSUPPORTED, "EXACT has no record-returning form");
+    aqe_plan* p = nullptr;
+    int rc = cached_plan(c, q, &p);
+    if (rc != AQE_OK) return rc;
+    // which launches contributed: all of them, except that the CLT sampler stops at its converged round
+    // and appends `topup` rows (DB.cpp:1031-1040) — both known only after running the reduction.
+    uint32_t rounds_used = static_cast<uint32_t>(p->rounds.size());
+    uint64_t topup_rows = 0;
+    if (p->host.is_clt) {
+        aqe_result r;
+        rc = enqueue_all(p, c->stream);
+        if (rc == AQE_OK) rc = fetch(p, &r, c->stream);
+        if (rc != AQE_OK) return rc;
+        rounds_used = static_cast<uint32_t>(r.rounds);
+        topup_rows = r.topup;
+    }
+    uint64_t total = p->host.is_random ? p->host.random_idx.size() : 0;
+    if (!p->host.is_random)
+        for (uint32_t r = 0; r < rounds_used; ++r) total += p->rounds[r].samples;
+    total += topup_rows;
+    *n_out = total;
+    if (total == 0) return AQE_OK;
+    if (!out_aos32 || cap < total) return fail(c, AQE_ERR_CAPACITY, "output buffer too small");
+    aqe_record* d_out = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), total * sizeof(aqe_record)));
+    hipError_t e = hipSuccess;
+    if (p->host.is_random) {
+        e = launch_gather_indexed(c->aos, c->shard_lo, p->d_idx, p->host.random_idx.size(), d_out, c->stream);
+    } else {
+        for (uint32_t r = 0; r < rounds_used && e == hipSuccess; ++r) {
+            const LaunchDesc& L = p->rounds[r];
+            if (L.nfam) e = launch_gather(c->aos, c->shard_lo, p->d_fams + L.fam_offset, L.nfam, L.ntiles, d_out, c->stream);
+        }
+        if (e == hipSuccess && topup_rows) {
+            // the top-up is one strided family from row 0; keep its first `topup_rows` ordinals and place
+            // them after the rows of the rounds that ran
+            std::vector<DevFamily> tf(p->h_fams.begin() + static_cast<long>(p->topup.fam_offset),
+                                      p->h_fams.begin() + static_cast<long>(p->topup.fam_offset + p->topup.nfam));
+            uint64_t pos = total - topup_rows;
+            for (auto& f : tf) {
+                f.ord_hi = std::min<uint64_t>(f.ord_hi, topup_rows);
+                f.out_begin = pos;
+                f.flags = 0;
+            }
+            DevFamily* d_tf = nullptr;
+            e = hipMalloc(reinterpret_cast<void**>(&d_tf), tf.size() * sizeof(DevFamily));
+            if (e == hipSuccess) e = hipMemcpy(d_tf, tf.data(), tf.size() * sizeof(DevFamily), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = launch_gather(c->aos, c->shard_lo, d_tf, static_cast<uint32_t>(tf.size()), p->topup.ntiles, d_out, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (d_tf) (void)hipFree(d_tf);
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_aos32, d_out, total * sizeof(aqe_record), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("gather: ") + hipGetErrorString(e));
+    return AQE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,462 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the sampled-reduce path.
+//
+// The path is a bandwidth/latency-bound f64 reduction (3 flops per 8 bytes): no MFMA.  What matters is
+// coalesced loads of the SoA `amount` column, many loads in flight per lane, a wave64 shuffle tree, an
+// LDS cross-wave step, and ONE hand-off per workgroup to the last-arriving workgroup, which folds the
+// launch into the query's running Welford state and evaluates the CLT rules on the device.
+//
+// Reference lines restated here (DB.cpp = /root/reference/src/aqe_backend/core/custom_bplus_db.cpp):
+//   reducer loops       DB.cpp:285-294, 324-335, 2024-2036  -> k_round / k_indexed
+//   CLT error rule      DB.cpp:936-961                      -> fold(), rule A on the pooled triple
+//   CLT cross-check     DB.cpp:993-1016                     -> fold(), rule B
+//   should_stop polling DB.cpp:930, 987                     -> QueryState::stop tested on kernel entry
+//   top-up              DB.cpp:1031-1040                    -> k_round with FoldParams::is_topup
+//   estimators + CI     enhanced_aqe_cli.py:189-200, 277-291; DB.cpp:303-315 -> k_finalize
+#include "kernels.hpp"
+
+namespace aqe {
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 uniform64(u64 x) {
+    unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(x));
+    unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(x >> 32));
+    return (static_cast<u64>(hi) << 32) | lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0; fixed tree => bitwise reproducible
+}
+
+struct Acc {
+    double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
+    unsigned na = 0, nb = 0, nv = 0;
+};
+
+// Chan/Welford merge of a batch given as shifted sums (n, sum(x-c), sum (x-c)^2) into (n, mean, m2).
+__device__ __forceinline__ void welford_merge(double& n, double& mean, double& m2, double nb, double sd,
+                                              double qd, double c) {
+    if (!(nb > 0.0)) return;
+    double mb = c + sd / nb;
+    double m2b = qd - sd * sd / nb;
+    if (m2b < 0.0) m2b = 0.0;
+    if (!(n > 0.0)) {
+        n = nb; mean = mb; m2 = m2b;
+        return;
+    }
+    double tot = n + nb, delta = mb - mean;
+    mean += delta * (nb / tot);
+    m2 += m2b + delta * delta * (n * nb / tot);
+    n = tot;
+}
+
+// Fold one launch's reduced vector into the query state and take the CLT decision.
+__device__ void fold(QueryState* s, const double* vec, const FoldParams& p) {
+    if (p.is_topup) {  // DB.cpp:1031-1040: systematic rows appended to the sample
+        welford_merge(s->n_p, s->mean_p, s->m2_p, vec[0], vec[1], vec[2], p.shift);
+        s->topup += vec[0];
+        s->visited += vec[6];
+        return;
+    }
+    welford_merge(s->n_a, s->mean_a, s->m2_a, vec[0], vec[1], vec[2], p.shift);
+    welford_merge(s->n_b, s->mean_b, s->m2_b, vec[3], vec[4], vec[5], p.shift);
+    welford_merge(s->n_p, s->mean_p, s->m2_p, vec[0], vec[1], vec[2], p.shift);
+    welford_merge(s->n_p, s->mean_p, s->m2_p, vec[3], vec[4], vec[5], p.shift);
+    s->visited += vec[6];
+    s->rounds += 1;
+    if (!p.is_clt) return;
+    // rule A, DB.cpp:936-961, on the pooled (all-reduced) moments
+    const double n = s->n_p;
+    if (n >= 30.0) {
+        double var = s->m2_p / (n - 1.0);
+        double se = sqrt(var / n);
+        double err = (p.z * se / s->mean_p) * 100.0;
+        if (err <= p.e && n >= 50.0) {
+            s->converged = 1;
+            s->stop = 1;
+            return;
+        }
+    }
+    // rule B, DB.cpp:993-1016: slow pointers cross-validate the fast pointers' mean
+    if (s->n_b >= 20.0 && s->n_a >= 30.0 && s->mean_a > 0.0) {
+        double diff = fabs(s->mean_b - s->mean_a) / s->mean_a;
+        if (diff <= p.e / 100.0 && s->n_a >= static_cast<double>(p.base / 2)) {
+            s->converged = 2;
+            s->stop = 1;
+        }
+    }
+}
+
+// Workgroup epilogue shared by k_round and k_indexed: wave64 shuffle tree -> LDS -> one 64-byte partial
+// per workgroup, published with write-through (sc1) stores by ONE lane, then an agent-scope ticket.
+// The workgroup that draws the last ticket re-reads every partial with sc1 loads in a fixed order
+// (deterministic sum), resets the ticket and folds.  (cdna_hip_programming.md G16, counter form.)
+__device__ void finish_block(const Acc& acc, const RoundLaunch& a) {
+    __shared__ double red[kWavesPerBlock][kVec];
+    __shared__ double tree[kBlockThreads];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    double r[7];
+    r[0] = wave_sum(static_cast<double>(acc.na));
+    r[1] = wave_sum(acc.sa);
+    r[2] = wave_sum(acc.qa);
+    r[3] = wave_sum(static_cast<double>(acc.nb));
+    r[4] = wave_sum(acc.sb);
+    r[5] = wave_sum(acc.qb);
+    r[6] = wave_sum(static_cast<double>(acc.nv));
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) red[wave][k] = r[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* mine = a.partials + static_cast<size_t>(blockIdx.x) * kVec;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            double v = red[0][k];
+            for (int w = 1; w < kWavesPerBlock; ++w) v += red[w][k];
+            __hip_atomic_store(mine + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial is out before the ticket is drawn
+        unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    double tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double v = 0.0;
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += kBlockThreads)
+            v += __hip_atomic_load(a.partials + static_cast<size_t>(b) * kVec + k, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        tree[threadIdx.x] = v;
+        __syncthreads();
+        for (int h = kBlockThreads / 2; h > 0; h >>= 1) {
+            if (static_cast<int>(threadIdx.x) < h) tree[threadIdx.x] += tree[threadIdx.x + h];
+            __syncthreads();
+        }
+        tot[k] = tree[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double vec[kVec];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) vec[k] = tot[k];
+        vec[7] = 0.0;
+        if (a.out_vec) {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) a.out_vec[k] = vec[k];
+        }
+        if (a.fused) fold(a.state, vec, a.fold);
+    }
+}
+
+__device__ __forceinline__ void accumulate(Acc& acc, double x, bool ok, bool group_b, const RoundLaunch& a) {
+    if (!ok) return;
+    acc.nv += 1;
+    if (a.has_where && !(x >= a.wmin && x <= a.wmax)) return;  // inclusive both ends, DB.cpp:329
+    double d = x - a.fold.shift;
+    if (group_b) {
+        acc.nb += 1; acc.sb += d; acc.qb += d * d;
+    } else {
+        acc.na += 1; acc.sa += d; acc.qa += d * d;
+    }
+}
+
+// Early-outs every launch of a query shares: should_stop (DB.cpp:930/987) and the top-up gate.
+// Returns false when the whole grid must leave without touching anything.
+__device__ __forceinline__ bool launch_is_live(const RoundLaunch& a, u64& ord_limit) {
+    ord_limit = ~0ull;
+    if (a.fold.is_topup) {
+        double collected = a.state->n_p;
+        if (!(collected < static_cast<double>(a.fold.base / 4))) return false;  // DB.cpp:1032
+        ord_limit = static_cast<u64>(static_cast<double>(a.fold.base) - collected);  // size() < base, DB.cpp:1037
+        return true;
+    }
+    return !(a.check_stop && a.state->stop);
+}
+
+// One wave folds one tile (64 * kTileUnroll ordinals of one segment of one family) per iteration.
+__global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
+    u64 ord_limit;
+    if (!launch_is_live(a, ord_limit)) return;
+    const int lane = threadIdx.x & 63;
+    const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
+    const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
+    Acc acc;
+    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) {
+        // wave-uniform tile decode
+        unsigned lo = 0, hi = a.nfam;
+        while (hi - lo > 1) {
+            unsigned mid = (lo + hi) >> 1;
+            if (a.fams[mid].tile_begin <= t) lo = mid; else hi = mid;
+        }
+        const DevFamily& F = a.fams[lo];
+        const u64 lt = t - F.tile_begin;
+        u64 seg, j;
+        if (F.tiles_per_seg == 0) { seg = F.seg_lo; j = F.j_lo + lt; }
+        else { seg = F.seg_lo + lt / F.tiles_per_seg; j = lt % F.tiles_per_seg; }
+        const u64 seg_len = F.seg_len, step = F.step;
+        const u64 seg_ord0 = seg * seg_len;
+        const u64 ord_lo = F.ord_lo;
+        const u64 ord_hi = (F.flags & AQE_F_TOPUP) ? (F.ord_hi < ord_limit ? F.ord_hi : ord_limit) : F.ord_hi;
+        const double* base = a.amount + (F.row0 + seg * F.pitch - a.shard_lo);
+        const u64 oi0 = j * kTileOrdinals + lane;
+        const bool group_b = F.group != 0;
+
+        double v[kTileUnroll];
+        bool ok[kTileUnroll];
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) {  // issue every load of the tile before the first use
+            const u64 oi = oi0 + static_cast<u64>(k) * 64;
+            const u64 o = seg_ord0 + oi;
+            ok[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
+            v[k] = ok[k] ? base[oi * step] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) accumulate(acc, v[k], ok[k], group_b, a);
+    }
+    finish_block(acc, a);
+}
+
+// random_pointer_sample (DB.cpp:856-882): explicit ascending row list built on the host.
+__global__ __launch_bounds__(kBlockThreads) void k_indexed(RoundLaunch a, const uint64_t* __restrict__ idx, u64 n_idx) {
+    u64 ord_limit;
+    if (!launch_is_live(a, ord_limit)) return;
+    Acc acc;
+    constexpr u64 kChunk = static_cast<u64>(kBlockThreads) * kTileUnroll;
+    for (u64 c0 = static_cast<u64>(blockIdx.x) * kChunk; c0 < n_idx; c0 += static_cast<u64>(gridDim.x) * kChunk) {
+        double v[kTileUnroll];
+        bool ok[kTileUnroll];
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) {
+            const u64 i = c0 + threadIdx.x + static_cast<u64>(k) * kBlockThreads;
+            ok[k] = i < n_idx;
+            v[k] = ok[k] ? a.amount[idx[i] - a.shard_lo] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) accumulate(acc, v[k], ok[k], false, a);
+    }
+    finish_block(acc, a);
+}
+
+__global__ void k_update(QueryState* s, const double* vec, FoldParams p) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (p.is_topup) {
+        if (!(s->n_p < static_cast<double>(p.base / 4))) return;  // same gate as the top-up launch
+    } else if (s->stop) {
+        return;  // a round enqueued after the stop never ran: nothing to fold
+    }
+    double v[kVec];
+    for (int k = 0; k < kVec; ++k) v[k] = vec[k];
+    fold(s, v, p);
+}
+
+__global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    aqe_result r;
+    const double n = s->n_p, mean = n > 0.0 ? s->mean_p : 0.0, m2 = s->m2_p, visited = s->visited;
+    const double N = static_cast<double>(p.n_global);
+    const double S = n * mean;
+    r.sum = S;
+    r.sumsq = m2 + n * mean * mean;
+    r.mean = mean;
+    r.m2 = m2;
+    r.n = static_cast<uint64_t>(n);
+    r.visited = static_cast<uint64_t>(visited);
+    r.topup = static_cast<uint64_t>(s->topup);
+    r.converged = s->converged;
+    r.rounds = s->rounds;
+    r.kernel_ms = 0.0;
+    r.bytes_algorithmic = r.visited * 8ull;
+
+    double moe = 0.0;  // CLI:279-282: two-pass variance, fixed 1.96
+    if (n > 1.0) moe = 1.96 * sqrt(m2 / (n - 1.0)) / sqrt(n);
+    double value = 0.0, margin = 0.0;
+    if (n > 0.0 || p.is_exact) {
+        if (p.is_exact) {  // DB.cpp:242-274
+            value = p.agg == AQE_SUM ? S : p.agg == AQE_AVG ? (N > 0.0 ? S / N : 0.0) : (visited > n ? n : N);
+        } else if (p.convention == AQE_EST_CLI) {  // CLI:189-200; interval CLI:284-291
+            const double scale = visited > 0.0 ? N / visited : 0.0;
+            if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
+            else if (p.agg == AQE_COUNT) { value = visited > n ? n * scale : N; }
+            else { value = n > 0.0 ? S / n : 0.0; margin = moe; }
+        } else if (p.convention == AQE_EST_CPP) {  // DB.cpp:303-315; interval scaled as executor.cpp:192-197
+            const double scale = 100.0 / p.pct;
+            if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
+            else if (p.agg == AQE_AVG) { value = N > 0.0 ? S * scale / N : 0.0; margin = moe; }
+            else { value = static_cast<double>(static_cast<uint64_t>(visited * scale)); }
+        } else {  // raw sample aggregate, DB.cpp:2046
+            if (p.agg == AQE_SUM) { value = S; margin = moe * n; }
+            else if (p.agg == AQE_AVG) { value = mean; margin = moe; }
+            else { value = visited; }
+        }
+    }
+    r.value = value;
+    r.margin = margin;
+    r.ci_lower = value - margin;
+    r.ci_upper = value + margin;
+    *out = r;
+}
+
+// ---- record-returning samplers: gather 32-byte rows ---------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __restrict__ aos, u64 shard_lo,
+                                                          const DevFamily* __restrict__ fams, unsigned nfam,
+                                                          u64 ntiles, aqe_record* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
+    const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
+    const uint4* src = reinterpret_cast<const uint4*>(aos);
+    uint4* dst = reinterpret_cast<uint4*>(out);
+    for (u64 t = wave_id; t < ntiles; t += wave_stride) {
+        unsigned lo = 0, hi = nfam;
+        while (hi - lo > 1) {
+            unsigned mid = (lo + hi) >> 1;
+            if (fams[mid].tile_begin <= t) lo = mid; else hi = mid;
+        }
+        const DevFamily& F = fams[lo];
+        const u64 lt = t - F.tile_begin;
+        u64 seg, j;
+        if (F.tiles_per_seg == 0) { seg = F.seg_lo; j = F.j_lo + lt; }
+        else { seg = F.seg_lo + lt / F.tiles_per_seg; j = lt % F.tiles_per_seg; }
+        const u64 seg_ord0 = seg * F.seg_len;
+        const u64 row_base = F.row0 + seg * F.pitch - shard_lo;
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) {
+            const u64 oi = j * kTileOrdinals + lane + static_cast<u64>(k) * 64;
+            const u64 o = seg_ord0 + oi;
+            if (oi < F.seg_len && o >= F.ord_lo && o < F.ord_hi) {
+                const u64 row = row_base + oi * F.step;
+                const u64 pos = F.out_begin + (o - F.ord_lo);
+                uint4 a = src[2 * row], b = src[2 * row + 1];
+                dst[2 * pos] = a;
+                dst[2 * pos + 1] = b;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void k_gather_indexed(const aqe_record* __restrict__ aos, u64 shard_lo,
+                                                                  const uint64_t* __restrict__ idx, u64 n,
+                                                                  aqe_record* __restrict__ out) {
+    const uint4* src = reinterpret_cast<const uint4*>(aos);
+    uint4* dst = reinterpret_cast<uint4*>(out);
+    for (u64 i = static_cast<u64>(blockIdx.x) * kBlockThreads + threadIdx.x; i < n;
+         i += static_cast<u64>(gridDim.x) * kBlockThreads) {
+        const u64 row = idx[i] - shard_lo;
+        uint4 a = src[2 * row], b = src[2 * row + 1];
+        dst[2 * i] = a;
+        dst[2 * i + 1] = b;
+    }
+}
+
+// ---- staging ------------------------------------------------------------------------------------
+// AoS -> SoA: each lane reads the 16-byte half-row holding (id, amount) and keeps the amount.
+__global__ __launch_bounds__(kBlockThreads) void k_split_amount(const aqe_record* __restrict__ aos,
+                                                                double* __restrict__ amount, u64 n) {
+    const double2* src = reinterpret_cast<const double2*>(aos);
+    for (u64 i = static_cast<u64>(blockIdx.x) * kBlockThreads + threadIdx.x; i < n;
+         i += static_cast<u64>(gridDim.x) * kBlockThreads)
+        amount[i] = src[2 * i].y;
+}
+
+__device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 i) {
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// Synthetic `sales` rows: id=i+1, amount=1+999*u, region=i%4, product_id=i%100, timestamp=i.
+__global__ __launch_bounds__(kBlockThreads) void k_synth(aqe_record* __restrict__ aos, double* __restrict__ amount,
+                                                         u64 n, u64 first_row, u64 seed) {
+    for (u64 k = static_cast<u64>(blockIdx.x) * kBlockThreads + threadIdx.x; k < n;
+         k += static_cast<u64>(gridDim.x) * kBlockThreads) {
+        const u64 i = first_row + k;
+        const double u = static_cast<double>(splitmix64_at(seed, i) >> 11) * (1.0 / 9007199254740992.0);
+        const double x = 1.0 + 999.0 * u;
+        amount[k] = x;
+        if (aos) {
+            aqe_record r;
+            r.id = static_cast<int64_t>(i + 1);
+            r.amount = x;
+            r.region = static_cast<int32_t>(i % 4);
+            r.product_id = static_cast<int32_t>(i % 100);
+            r.timestamp = static_cast<int64_t>(i);
+            aos[k] = r;
+        }
+    }
+}
+
+inline unsigned grid_for(u64 work_items, u64 per_block) {
+    u64 g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > kMaxBlocks) g = kMaxBlocks;
+    return static_cast<unsigned>(g);
+}
+
+}  // namespace
+
+hipError_t launch_round(const RoundLaunch& a, hipStream_t s) {
+    unsigned grid = grid_for(a.ntiles, kWavesPerBlock);
+    hipLaunchKernelGGL(k_round, dim3(grid), dim3(kBlockThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s) {
+    unsigned grid = grid_for(n_idx, static_cast<u64>(kBlockThreads) * kTileUnroll);
+    hipLaunchKernelGGL(k_indexed, dim3(grid), dim3(kBlockThreads), 0, s, a, idx, static_cast<u64>(n_idx));
+    return hipGetLastError();
+}
+
+hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, s, state, vec, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe_result* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, state, p, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFamily* fams, uint32_t nfam,
+                         uint64_t ntiles, aqe_record* out, hipStream_t s) {
+    if (ntiles == 0) return hipSuccess;
+    unsigned grid = grid_for(ntiles, kWavesPerBlock);
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlockThreads), 0, s, aos, static_cast<u64>(shard_lo), fams, nfam,
+                       static_cast<u64>(ntiles), out);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const uint64_t* idx, uint64_t n,
+                                 aqe_record* out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned grid = grid_for(n, kBlockThreads);
+    hipLaunchKernelGGL(k_gather_indexed, dim3(grid), dim3(kBlockThreads), 0, s, aos, static_cast<u64>(shard_lo), idx,
+                       static_cast<u64>(n), out);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_amount(const aqe_record* aos, double* amount, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_split_amount, dim3(grid_for(n, kBlockThreads * 4)), dim3(kBlockThreads), 0, s, aos, amount,
+                       static_cast<u64>(n));
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(aqe_record* aos_or_null, double* amount, uint64_t n, uint64_t first_row, uint64_t seed,
+                        hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth, dim3(grid_for(n, kBlockThreads * 4)), dim3(kBlockThreads), 0, s, aos_or_null, amount,
+                       static_cast<u64>(n), static_cast<u64>(first_row), static_cast<u64>(seed));
+    return hipGetLastError();
+}
+
+}  // namespace aqe

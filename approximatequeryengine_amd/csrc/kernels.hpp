@@ -1,0 +1,91 @@
+// kernels.hpp — launch interface between the C-ABI layer (capi.hip) and the gfx950 kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/aqe_hip.h"
+
+namespace aqe {
+
+constexpr int kBlockThreads = 256;          // 4 wave64 per workgroup
+constexpr int kWavesPerBlock = kBlockThreads / 64;
+constexpr int kTileUnroll = 8;              // loads in flight per lane
+constexpr int kTileOrdinals = 64 * kTileUnroll;  // ordinals one wave folds per tile
+constexpr int kMaxBlocks = 2048;            // 8 workgroups per CU on 256 CUs
+constexpr int kVec = AQE_MOMENT_VEC;
+
+// A family as the device sees it: the ABI family plus its tile decomposition.
+struct DevFamily {
+    uint64_t row0, pitch, seg_len, step;
+    uint64_t ord_lo, ord_hi;
+    uint64_t tile_begin;     // first tile id (within the launch) owned by this family
+    uint64_t seg_lo;         // first segment the window touches
+    uint64_t tiles_per_seg;  // 0: the window lies in one segment and tile j starts at ordinal (j_lo+j)*tile
+    uint64_t j_lo;
+    uint64_t out_begin;      // gather: position of ordinal ord_lo in the output
+    uint32_t group, flags;
+};
+
+// Running state of one query on the device: Welford triples folded round by round, the CLT
+// decision, and the should_stop flag later launches test on entry.
+struct QueryState {
+    double n_a, mean_a, m2_a;  // group a: fast pointers (or every sample of a non-CLT query)
+    double n_b, mean_b, m2_b;  // group b: slow pointers
+    double n_p, mean_p, m2_p;  // pooled a+b, plus the top-up
+    double visited;            // samples drawn (>= n_p when a WHERE filter drops some)
+    double topup;              // rows added by the top-up
+    int32_t stop;              // should_stop: set by the CLT rules, read by every later launch
+    int32_t converged;         // 0 none, 1 error rule, 2 cross-validation rule
+    int32_t rounds;            // rounds folded
+    int32_t pad;
+};
+
+struct FoldParams {
+    double shift;      // c of the shifted sums
+    double z, e;       // CLT
+    int32_t base;      // CLT: int(N*pct/100)
+    int32_t is_clt;
+    int32_t is_topup;  // this launch is the top-up (folds into the pooled triple only)
+    int32_t pad;
+};
+
+struct RoundLaunch {
+    const double* amount;   // this shard's amount column
+    uint64_t shard_lo;
+    const DevFamily* fams;
+    uint32_t nfam;
+    uint64_t ntiles;
+    int32_t has_where;
+    double wmin, wmax;
+    double* partials;       // [kMaxBlocks][kVec]
+    unsigned* counter;      // arrival ticket, zero between launches
+    double* out_vec;        // reduced vector of this launch (may be null)
+    QueryState* state;
+    int32_t fused;          // last arriver folds into state (single-GPU form)
+    int32_t check_stop;     // leave at once when state->stop is set
+    FoldParams fold;
+};
+
+struct FinalizeParams {
+    uint64_t n_global;
+    double pct;
+    int32_t agg, convention, is_exact, is_clt;
+};
+
+hipError_t launch_round(const RoundLaunch& a, hipStream_t s);
+hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s);
+hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, hipStream_t s);
+hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe_result* out, hipStream_t s);
+
+hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFamily* fams, uint32_t nfam,
+                         uint64_t ntiles, aqe_record* out, hipStream_t s);
+hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const uint64_t* idx, uint64_t n,
+                                 aqe_record* out, hipStream_t s);
+
+hipError_t launch_split_amount(const aqe_record* aos, double* amount, uint64_t n, hipStream_t s);
+hipError_t launch_synth(aqe_record* aos_or_null, double* amount, uint64_t n, uint64_t first_row, uint64_t seed,
+                        hipStream_t s);
+
+}  // namespace aqe

@@ -1,0 +1,427 @@
+// planner.cpp — host-side planning of the reference's samplers as arithmetic row families.
+//
+// Each builder re-derives the index arithmetic of one reference sampler (cited per function; DB.cpp =
+// /root/reference/src/aqe_backend/core/custom_bplus_db.cpp) and emits it in closed form:
+//     row(o) = row0 + (o / seg_len) * pitch + (o % seg_len) * step,   o in [ord_lo, ord_hi)
+// so a GPU can enumerate the sample without materialising it.  Truncating casts (int target counts,
+// left-to-right double products) are kept exactly as the reference has them: they decide the sample.
+#include "planner.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <regex>
+
+namespace aqe {
+namespace {
+
+using u64 = uint64_t;
+using u128 = unsigned __int128;
+
+inline int target_of(u64 rows, double pct) { return static_cast<int>(static_cast<double>(rows) * pct / 100.0); }
+inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// number of terms of start, start+step, ... that are < end
+inline u64 prog_count(u64 start, u64 end, u64 step) { return start < end ? ceil_div(end - start, step) : 0; }
+
+aqe_family strided(u64 row0, u64 step, u64 count, uint32_t group = 0) {
+    aqe_family f{};
+    f.row0 = row0;
+    f.step = step;
+    f.seg_len = count ? count : 1;
+    f.pitch = 0;
+    f.ord_lo = 0;
+    f.ord_hi = count;
+    f.group = group;
+    return f;
+}
+
+aqe_family blocks(u64 row0, u64 pitch, u64 seg_len, u64 total) {
+    aqe_family f{};
+    f.row0 = row0;
+    f.pitch = pitch;
+    f.seg_len = seg_len;
+    f.step = 1;
+    f.ord_lo = 0;
+    f.ord_hi = total;
+    return f;
+}
+
+// Rows of a family ascend with the ordinal (segments never overlap), so the ordinals whose rows fall
+// in [lo, hi) form one window; find it by bisection on the closed form.
+u64 first_ordinal_at_or_after(const aqe_family& f, u64 a, u64 b, u64 row) {
+    while (a < b) {
+        u64 mid = a + (b - a) / 2;
+        if (family_row(f, mid) >= row) b = mid; else a = mid + 1;
+    }
+    return a;
+}
+
+void clip_push(std::vector<aqe_family>& out, aqe_family f, ClipWindow w) {
+    if (f.ord_hi <= f.ord_lo) return;
+    u64 a = first_ordinal_at_or_after(f, f.ord_lo, f.ord_hi, w.lo);
+    u64 b = first_ordinal_at_or_after(f, a, f.ord_hi, w.hi);
+    if (b <= a) return;
+    f.ord_lo = a;
+    f.ord_hi = b;
+    out.push_back(f);
+}
+
+// ---- MT19937 + libstdc++-11 uniform_int_distribution (bits/uniform_int_dist.h:246-317) ----------
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx;
+    explicit Mt19937(uint32_t seed) {
+        mt[0] = seed;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + static_cast<uint32_t>(i);
+        idx = 624;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+
+inline uint32_t lemire_bounded(Mt19937& g, uint32_t range) {
+    u64 product = static_cast<u64>(g.next()) * range;
+    uint32_t low = static_cast<uint32_t>(product);
+    if (low < range) {
+        uint32_t threshold = static_cast<uint32_t>(0u - range) % range;
+        while (low < threshold) {
+            product = static_cast<u64>(g.next()) * range;
+            low = static_cast<uint32_t>(product);
+        }
+    }
+    return static_cast<uint32_t>(product >> 32);
+}
+
+inline u64 splitmix64_at(u64 seed, u64 i) {
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+#define AQE_FAIL(msg) do { err = (msg); return AQE_ERR_INVALID; } while (0)
+
+}  // namespace
+
+int random_pointer_indices(u64 N, double pct, uint32_t seed, ClipWindow shard, std::vector<u64>& out,
+                           std::string& err) {
+    out.clear();
+    if (N == 0) return AQE_OK;
+    int target = target_of(N, pct);
+    if (target <= 0) return AQE_OK;
+    if (N > 0xFFFFFFFFull) AQE_FAIL("random_pointer_sample: tables above 2^32-1 rows are not supported");
+    u64 want = std::min<u64>(static_cast<u64>(target), N);
+    std::vector<u64> bits((N + 63) / 64, 0);
+    Mt19937 rng(seed);
+    u64 have = 0;
+    while (have < want) {  // std::set insertion until `target` unique positions, DB.cpp:872-875
+        u64 v = lemire_bounded(rng, static_cast<uint32_t>(N));
+        u64 m = 1ull << (v & 63);
+        if (!(bits[v >> 6] & m)) { bits[v >> 6] |= m; ++have; }
+    }
+    u64 lo = std::min(shard.lo, N), hi = std::min(shard.hi, N);
+    for (u64 w = lo / 64; w < (hi + 63) / 64; ++w) {  // ascending, as the std::set iterates
+        u64 word = bits[w];
+        while (word) {
+            u64 i = w * 64 + static_cast<u64>(__builtin_ctzll(word));
+            word &= word - 1;
+            if (i >= lo && i < hi) out.push_back(i);
+        }
+    }
+    return AQE_OK;
+}
+
+int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err) {
+    P = HostPlan{};
+    P.pct = q.sample_percent;
+    shard.lo = std::min(shard.lo, N);
+    shard.hi = std::min(std::max(shard.hi, shard.lo), N);
+    const double pct = q.sample_percent;
+    if (!(pct == pct)) AQE_FAIL("sample_percent is NaN");
+    const u64 M = (q.visible_rows && q.visible_rows < N) ? q.visible_rows : N;
+    P.visible_rows = M;
+    const int T = q.num_threads;
+    std::vector<aqe_family> fams;  // unclipped families of a single-round sampler
+    auto finish_single = [&]() {
+        P.rounds = 1;
+        P.round_fams.assign(1, {});
+        for (const auto& f : fams) {
+            P.global_samples += family_size(f);
+            clip_push(P.round_fams[0], f, shard);
+        }
+        return AQE_OK;
+    };
+
+    switch (q.method) {
+        case AQE_M_EXACT: {  // DB.cpp:242-274: every row
+            if (N) fams.push_back(blocks(0, N, N, N));
+            return finish_single();
+        }
+        case AQE_M_MEMORY_STRIDE: {  // DB.cpp:1540-1566
+            if (M == 0) return finish_single();
+            int target = target_of(M, pct);
+            if (target <= 0) return finish_single();
+            u64 stride = q.stride_bytes == 0 ? std::max<u64>(1, M / static_cast<u64>(target))
+                                             : std::max<u64>(1, q.stride_bytes / sizeof(aqe_record));
+            fams.push_back(strided(0, stride, std::min<u64>(static_cast<u64>(target), ceil_div(M, stride))));
+            return finish_single();
+        }
+        case AQE_M_ADDRESS_ARITHMETIC: {  // DB.cpp:1667-1703
+            if (M == 0) return finish_single();
+            int target = target_of(M, pct);
+            if (target <= 0) return finish_single();
+            u64 stride = std::max<u64>(1, M / static_cast<u64>(target));
+            fams.push_back(strided(0, stride, std::min<u64>(static_cast<u64>(target), ceil_div(M, stride))));
+            return finish_single();
+        }
+        case AQE_M_FAST_POINTER:    // DB.cpp:737-758
+        case AQE_M_SLOW_POINTER: {  // DB.cpp:760-780
+            if (N == 0) return finish_single();
+            int target = target_of(N, pct);
+            if (target <= 0) return finish_single();
+            int step = std::max(1, static_cast<int>(N / static_cast<u64>(target)));
+            if (q.method == AQE_M_FAST_POINTER) step *= q.step_size;
+            if (step <= 0) AQE_FAIL("fast_pointer_sample: step_size must be positive");
+            fams.push_back(strided(0, static_cast<u64>(step),
+                                   std::min<u64>(static_cast<u64>(target), ceil_div(N, static_cast<u64>(step)))));
+            return finish_single();
+        }
+        case AQE_M_DUAL_POINTER: {  // DB.cpp:782-813
+            if (N == 0) return finish_single();
+            int target = target_of(N, pct);
+            if (target <= 0) return finish_single();
+            int fast_target = target / 3, slow_target = target - fast_target;
+            if (fast_target == 0) AQE_FAIL("dual_pointer_sample: target < 3 (the reference divides by zero)");
+            u64 fast_step = static_cast<u64>(std::max(1, static_cast<int>(N / static_cast<u64>(fast_target))) * 3);
+            u64 n_fast = std::min<u64>(static_cast<u64>(fast_target), ceil_div(N, fast_step));
+            fams.push_back(strided(0, fast_step, n_fast));
+            u64 slow_step = static_cast<u64>(std::max(1, static_cast<int>(N / static_cast<u64>(slow_target))));
+            u64 offset = fast_step / 2;
+            u64 n_slow = std::min<u64>(static_cast<u64>(target) - n_fast, prog_count(offset, N, slow_step));
+            fams.push_back(strided(offset, slow_step, n_slow));
+            // the two pointers interleave in row order: keep them as separate families (each ascending)
+            return finish_single();
+        }
+        case AQE_M_PARALLEL_POINTER: {  // DB.cpp:815-854
+            if (N == 0) return finish_single();
+            int target = target_of(N, pct);
+            if (target <= 0) return finish_single();
+            if (T <= 0) AQE_FAIL("parallel_pointer_sample: num_threads must be positive");
+            u64 per_thread = static_cast<u64>(target / T);
+            u64 step = static_cast<u64>(std::max(1, static_cast<int>(N / static_cast<u64>(target))));
+            for (int t = 0; t < T; ++t) {
+                u64 start = (N / static_cast<u64>(T)) * static_cast<u64>(t);
+                fams.push_back(strided(start, step, std::min(per_thread, prog_count(start, N, step))));
+            }
+            return finish_single();
+        }
+        case AQE_M_BLOCK:   // DB.cpp:1151-1181
+        case AQE_M_PAGE: {  // DB.cpp:1183-1216
+            if (N == 0) return finish_single();
+            int target = target_of(N, pct);
+            if (target <= 0) return finish_single();
+            u64 B = q.block_size;
+            if (q.method == AQE_M_PAGE) { B = q.block_size / sizeof(aqe_record); if (B == 0) B = 1; }
+            if (B == 0) AQE_FAIL("block_sample: block_size must be positive");
+            u64 total_blocks = ceil_div(N, B);
+            u64 to_sample = std::max<u64>(1, static_cast<u64>(static_cast<double>(total_blocks) * pct / 100.0));
+            u64 interval = std::max<u64>(1, total_blocks / to_sample);
+            u64 nseg = ceil_div(total_blocks, interval);          // blk = 0, interval, ... < total_blocks
+            u64 last_row0 = (nseg - 1) * interval * B;
+            u64 last_len = std::min(B, N - last_row0);            // only the table's tail block is short
+            u64 avail = (nseg - 1) * B + last_len;
+            fams.push_back(blocks(0, interval * B, B, std::min<u64>(static_cast<u64>(target), avail)));
+            return finish_single();
+        }
+        case AQE_M_PARALLEL_BLOCK: {  // DB.cpp:1218-1271
+            if (N == 0) return finish_single();
+            int target = target_of(N, pct);
+            if (target <= 0) return finish_single();
+            u64 B = q.block_size;
+            if (B == 0 || T <= 0) AQE_FAIL("parallel_block_sample: block_size and num_threads must be positive");
+            u64 total_blocks = ceil_div(N, B);
+            u64 to_sample = std::max<u64>(1, static_cast<u64>(static_cast<double>(total_blocks) * pct / 100.0));
+            u64 per_thread = std::max<u64>(1, to_sample / static_cast<u64>(T));
+            u64 interval = std::max<u64>(1, total_blocks / to_sample);
+            u64 thread_target = static_cast<u64>(target / T);
+            for (int t = 0; t < T; ++t) {
+                u64 b0 = static_cast<u64>(t) * per_thread, b1 = std::min(b0 + per_thread, to_sample);
+                if (b1 <= b0 || thread_target == 0) continue;
+                u64 nseg = b1 - b0;
+                u64 last_row0 = (b1 - 1) * interval * B;
+                u64 last_len = last_row0 < N ? std::min(B, N - last_row0) : 0;
+                u64 avail = (nseg - 1) * B + last_len;
+                fams.push_back(blocks(b0 * interval * B, interval * B, B, std::min(thread_target, avail)));
+            }
+            return finish_single();
+        }
+        case AQE_M_OPTIMIZED_CLT: {  // DB.cpp:1046-1147 (deterministic: both CLT branches return the same rows)
+            if (N == 0) return finish_single();
+            u64 target = static_cast<u64>(static_cast<double>(N) * pct / 100.0);
+            if (target == 0) return finish_single();
+            int opt = std::min(T, std::max(1, static_cast<int>(target / 100)));
+            if (N < 5000 || target < 200 || opt == 1) {
+                u64 step = std::max<u64>(1, N / target);
+                fams.push_back(strided(0, step, std::min(target, ceil_div(N, step))));
+                return finish_single();
+            }
+            if (opt <= 0) return finish_single();
+            u64 per_thread = target / static_cast<u64>(opt);
+            for (int t = 0; t < opt; ++t) {
+                u64 rpt = N / static_cast<u64>(opt);
+                u64 a = static_cast<u64>(t) * rpt, b = (t == opt - 1) ? N : static_cast<u64>(t + 1) * rpt;
+                u64 local = (t == opt - 1) ? target - static_cast<u64>(opt - 1) * per_thread : per_thread;
+                if (local == 0) continue;
+                u64 stride = std::max<u64>(1, (b - a) / local);
+                fams.push_back(strided(a, stride, std::min(local, prog_count(a, b, stride))));
+            }
+            return finish_single();
+        }
+        case AQE_M_REGION_STRIDE: {  // DB.cpp:1880-2048 with a proper prefix partition and seeded starts
+            if (M == 0) return finish_single();
+            if (T <= 0) AQE_FAIL("region stride: num_threads must be positive");
+            double per_thread_pct = pct / static_cast<double>(T);
+            for (int t = 0; t < T; ++t) {
+                u64 a = static_cast<u64>((static_cast<u128>(M) * static_cast<u64>(t)) / static_cast<u64>(T));
+                u64 b = static_cast<u64>((static_cast<u128>(M) * static_cast<u64>(t + 1)) / static_cast<u64>(T));
+                u64 total = b - a;
+                u64 target = static_cast<u64>(static_cast<double>(total) * per_thread_pct / 100.0);
+                if (target == 0) continue;
+                u64 span = std::min<u64>(total / 10, 100);
+                u64 start = a + splitmix64_at(q.seed, static_cast<u64>(t)) % (span + 1);
+                u64 stride = std::max<u64>(1, total / target);
+                fams.push_back(strided(start, stride, std::min(target, prog_count(start, b, stride))));
+            }
+            return finish_single();
+        }
+        case AQE_M_RANDOM_POINTER: {
+            P.is_random = true;
+            P.rounds = 1;
+            int rc = random_pointer_indices(N, pct, static_cast<uint32_t>(q.seed), shard, P.random_idx, err);
+            if (rc != AQE_OK) return rc;
+            int target = N ? target_of(N, pct) : 0;
+            P.global_samples = target > 0 ? std::min<u64>(static_cast<u64>(target), N) : 0;
+            return AQE_OK;
+        }
+        case AQE_M_CLT_DUAL_POINTER: {  // DB.cpp:885-1043, round-synchronous
+            P.is_clt = true;
+            P.clt.base = N ? target_of(N, pct) : 0;
+            P.clt.z = q.confidence_level >= 0.99 ? 2.576 : q.confidence_level >= 0.95 ? 1.96 : 1.645;
+            P.clt.e = q.max_error_percent;
+            P.rounds = 0;
+            if (q.has_where) AQE_FAIL("the CLT sampler has no WHERE form in the reference");
+            if (N == 0 || P.clt.base <= 0) return AQE_OK;  // empty result, DB.cpp:894-898
+            if (T <= 0 || T > 4096) AQE_FAIL("clt: num_threads out of range");
+            const int F = T / 2, S = T - F;
+            if (q.check_interval / 2 == 0) AQE_FAIL("clt: check_interval < 2 (the reference takes a modulo by zero, DB.cpp:993)");
+            if (F > 0 && P.clt.base / F == 0) AQE_FAIL("clt: base/fast_threads == 0 (the reference divides by zero, DB.cpp:927)");
+            if (S > 0 && P.clt.base / S == 0) AQE_FAIL("clt: base/slow_threads == 0 (the reference divides by zero, DB.cpp:985)");
+            P.clt.n_workers = T;
+            P.clt.n_fast = F;
+            struct W { u64 first, step, count; uint32_t group; };
+            std::vector<W> ws;
+            for (int t = 0; t < F; ++t) {  // DB.cpp:925-927
+                u64 a = (N * static_cast<u64>(t)) / static_cast<u64>(F), b = (N * static_cast<u64>(t + 1)) / static_cast<u64>(F);
+                u64 step = static_cast<u64>(std::max(3, static_cast<int>((b - a) / static_cast<u64>(P.clt.base / F))));
+                ws.push_back({a, step, prog_count(a, b, step), 0});
+            }
+            for (int t = 0; t < S; ++t) {  // DB.cpp:983-990
+                u64 a = (N * static_cast<u64>(t)) / static_cast<u64>(S), b = (N * static_cast<u64>(t + 1)) / static_cast<u64>(S);
+                u64 step = static_cast<u64>(std::max(1, static_cast<int>((b - a) / static_cast<u64>(P.clt.base / S))));
+                u64 first = a + step / 2;
+                ws.push_back({first, step, prog_count(first, b, step), 1});
+            }
+            for (const auto& w : ws) { P.clt.max_count = std::max(P.clt.max_count, w.count); P.global_samples += w.count; }
+            u64 R = q.clt_round0 ? q.clt_round0 : static_cast<u64>(q.check_interval);
+            u64 g = q.clt_growth ? q.clt_growth : 1;
+            u64 b0 = 0;
+            while (b0 < P.clt.max_count) {
+                u64 b1 = (R > P.clt.max_count - b0) ? P.clt.max_count : b0 + R;
+                std::vector<aqe_family> rf;
+                for (const auto& w : ws) {
+                    u64 k1 = std::min(b1, w.count);
+                    if (k1 <= b0) continue;
+                    aqe_family f = strided(w.first, w.step, w.count, w.group);
+                    f.ord_lo = b0;
+                    f.ord_hi = k1;
+                    clip_push(rf, f, shard);
+                }
+                P.round_fams.push_back(std::move(rf));
+                b0 = b1;
+                R = (R > (UINT64_MAX / 4) / g) ? UINT64_MAX / 4 : R * g;
+                if (P.round_fams.size() > (1u << 20)) AQE_FAIL("clt: more than 2^20 rounds; raise clt_round0 or clt_growth");
+            }
+            P.rounds = static_cast<uint32_t>(P.round_fams.size());
+            if (!(q.flags & AQE_Q_NO_TOPUP)) {  // DB.cpp:1031-1040
+                int additional = P.clt.base / 4;
+                if (additional > 0) {
+                    u64 step = static_cast<u64>(std::max(1, static_cast<int>(N / static_cast<u64>(additional))));
+                    aqe_family f = strided(0, step, std::min<u64>(ceil_div(N, step), static_cast<u64>(P.clt.base)));
+                    f.flags = AQE_F_TOPUP;
+                    P.has_topup = true;
+                    // the device limits ord_hi to base - collected, which is a prefix of the ordinals, so
+                    // clipping to the shard stays valid: a shard keeps ordinals [a,b) and the device
+                    // intersects with [0, limit).
+                    clip_push(P.topup_fams, f, shard);
+                }
+            }
+            return AQE_OK;
+        }
+        default:
+            AQE_FAIL("unknown method");
+    }
+}
+
+bool parse_where(const char* query, double* lo, double* hi) {
+    // same three shapes, same precedence and the same case sensitivity as SCH.cpp:277-294
+    static const std::regex between(R"(amount\s+BETWEEN\s+(\d+(?:\.\d+)?)\s+AND\s+(\d+(?:\.\d+)?))");
+    static const std::regex range(R"(amount\s*>=\s*(\d+(?:\.\d+)?)\s+AND\s+amount\s*<=\s*(\d+(?:\.\d+)?))");
+    static const std::regex greater(R"(amount\s*>\s*(\d+(?:\.\d+)?))");
+    std::string s(query ? query : "");
+    std::smatch m;
+    if (std::regex_search(s, m, between) || std::regex_search(s, m, range)) {
+        *lo = std::stod(m[1]);
+        *hi = std::stod(m[2]);
+        return true;
+    }
+    if (std::regex_search(s, m, greater)) {
+        *lo = std::stod(m[1]);
+        *hi = 99999.99;  // SCH.cpp:290 default upper bound; note the bound stays inclusive
+        return true;
+    }
+    *lo = -1;
+    *hi = -1;
+    return false;
+}
+
+double confidence_heuristic(double pct, uint64_t total) {
+    double sample = static_cast<double>(total) * pct / 100.0;
+    if (sample >= 1000) return 0.95;
+    if (sample >= 500) return 0.90;
+    if (sample >= 100) return 0.85;
+    if (sample >= 50) return 0.80;
+    return 0.70;
+}
+
+double error_to_sample_percent(double e) {
+    if (e <= 1.0) return 20.0;
+    if (e <= 2.0) return 15.0;
+    if (e <= 5.0) return 10.0;
+    return 5.0;
+}
+
+}  // namespace aqe

@@ -1,0 +1,60 @@
+// planner.hpp — host-side query planning: turns (method, parameters, table size, shard) into the short
+// list of arithmetic row families the GPU kernels sweep.  Pure C++, no HIP: exported through the C ABI
+// (aqe_plan_families / aqe_plan_random_indices) so it is testable without a GPU.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/aqe_hip.h"
+
+namespace aqe {
+
+struct ClipWindow {
+    uint64_t lo, hi;  // shard rows [lo, hi) in global row numbering
+};
+
+struct CltShape {
+    int base = 0;        // int(N*pct/100), DB.cpp:896
+    int n_workers = 0;   // T
+    int n_fast = 0;      // T/2, DB.cpp:918
+    double z = 1.96;     // DB.cpp:911-912
+    double e = 0.0;      // max_error_percent
+    uint64_t max_count = 0;  // longest worker progression
+};
+
+struct HostPlan {
+    bool is_random = false;   // RANDOM_POINTER: explicit index list instead of families
+    bool is_clt = false;
+    bool has_topup = false;
+    uint32_t rounds = 1;
+    CltShape clt;
+    std::vector<std::vector<aqe_family>> round_fams;  // [round] -> families clipped to the shard
+    std::vector<aqe_family> topup_fams;               // CLT top-up (flag AQE_F_TOPUP)
+    std::vector<uint64_t> random_idx;                 // ascending global rows inside the shard
+    uint64_t global_samples = 0;  // samples the whole query draws over the whole table (all rounds)
+    uint64_t visible_rows = 0;    // M actually used
+    double pct = 0.0;
+};
+
+// Returns AQE_OK or AQE_ERR_INVALID (err gets the reason).  shard = [lo, hi) global rows.
+int build_plan(const aqe_query& q, uint64_t n_global, ClipWindow shard, HostPlan& out, std::string& err);
+
+// random_pointer_sample index set (DB.cpp:856-882), ascending, restricted to the shard.
+int random_pointer_indices(uint64_t n_global, double pct, uint32_t seed, ClipWindow shard,
+                           std::vector<uint64_t>& out, std::string& err);
+
+// total ordinals in a family window
+inline uint64_t family_size(const aqe_family& f) { return f.ord_hi > f.ord_lo ? f.ord_hi - f.ord_lo : 0; }
+
+// row of ordinal o
+inline uint64_t family_row(const aqe_family& f, uint64_t o) {
+    return f.row0 + (o / f.seg_len) * f.pitch + (o % f.seg_len) * f.step;
+}
+
+bool parse_where(const char* query, double* lo, double* hi);   // SCH.cpp:277-294
+double confidence_heuristic(double pct, uint64_t total);        // SCH.cpp:296-305
+double error_to_sample_percent(double e);                       // CLI:243-250
+
+}  // namespace aqe

@@ -1,0 +1,171 @@
+"""engine.py — thin object layer over the C ABI (include/aqe_hip.h): one Engine = one GPU = one shard.
+
+The Engine owns an ``aqe_ctx``; every number it returns was computed by the HIP kernels behind
+``aqe_reduce`` / the plan API.  There is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as nat
+from ._native import AqeError, Query, Result  # noqa: F401
+
+#: numpy view of the reference's 32-byte row (custom_bplus_db.hpp:17-27)
+RECORD_DTYPE = np.dtype(
+    [("id", "<i8"), ("amount", "<f8"), ("region", "<i4"), ("product_id", "<i4"), ("timestamp", "<i8")]
+)
+assert RECORD_DTYPE.itemsize == 32
+
+
+class Plan:
+    """A planned query on one Engine (aqe_plan): rounds can be enqueued one by one (multi-GPU) or at once."""
+
+    def __init__(self, engine: "Engine", query: Query):
+        self.engine = engine
+        self.query = query
+        self._h = C.c_void_p()
+        nat.check(nat.lib().aqe_plan_create(engine._h, C.byref(query), C.byref(self._h)), engine._h)
+        r, t = C.c_uint32(), C.c_int32()
+        nat.check(nat.lib().aqe_plan_rounds(self._h, C.byref(r), C.byref(t)), engine._h)
+        self.rounds, self.has_topup = r.value, bool(t.value)
+
+    def close(self):
+        if self._h:
+            nat.lib().aqe_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        nat.check(rc, self.engine._h)
+
+    def reset(self, stream: int = 0):
+        self._chk(nat.lib().aqe_plan_reset(self._h, C.c_void_p(stream)))
+
+    def enqueue_round(self, r: int, dev_vec_ptr: int, stream: int = 0):
+        self._chk(nat.lib().aqe_plan_enqueue_round(self._h, r, C.c_void_p(dev_vec_ptr), C.c_void_p(stream)))
+
+    def enqueue_update(self, r: int, dev_vec_ptr: int, stream: int = 0):
+        self._chk(nat.lib().aqe_plan_enqueue_update(self._h, r, C.c_void_p(dev_vec_ptr), C.c_void_p(stream)))
+
+    def enqueue_finalize(self, stream: int = 0):
+        self._chk(nat.lib().aqe_plan_enqueue_finalize(self._h, C.c_void_p(stream)))
+
+    def enqueue_all(self, stream: int = 0):
+        self._chk(nat.lib().aqe_plan_enqueue_all(self._h, C.c_void_p(stream)))
+
+    def fetch(self, stream: int = 0) -> Result:
+        res = Result()
+        self._chk(nat.lib().aqe_plan_fetch(self._h, C.byref(res), C.c_void_p(stream)))
+        return res
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._chk(nat.lib().aqe_plan_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+class Engine:
+    """One GPU context holding one shard [shard_lo, shard_lo+local_rows) of a table of global_rows rows."""
+
+    def __init__(self, device_id: int = 0):
+        self._h = C.c_void_p()
+        rc = nat.lib().aqe_create(device_id, C.byref(self._h))
+        if rc != nat.OK:
+            nat.check(rc, None)
+        self._keepalive = None  # tensors adopted through attach_device
+
+    # -- lifecycle --
+    def close(self):
+        if self._h:
+            nat.lib().aqe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        nat.check(rc, self._h)
+
+    # -- staging --
+    def stage_records(self, rows: np.ndarray, shard_lo: int = 0, n_global: Optional[int] = None, keep_aos: bool = True):
+        rows = np.ascontiguousarray(rows, dtype=RECORD_DTYPE)
+        n_global = len(rows) if n_global is None else n_global
+        self._chk(nat.lib().aqe_stage_records(self._h, rows.ctypes.data, len(rows), shard_lo, n_global,
+                                              nat.STAGE_KEEP_AOS if keep_aos else 0))
+
+    def stage_file(self, path, shard_lo: int = 0, n_local: int = 0, keep_aos: bool = True):
+        self._chk(nat.lib().aqe_stage_file(self._h, str(path).encode(), shard_lo, n_local,
+                                           nat.STAGE_KEEP_AOS if keep_aos else 0))
+
+    def save_file(self, path):
+        self._chk(nat.lib().aqe_save_file(self._h, str(path).encode()))
+
+    def generate_synthetic(self, n_local: int, shard_lo: int = 0, n_global: Optional[int] = None, seed: int = 42,
+                           keep_aos: bool = False):
+        n_global = n_local if n_global is None else n_global
+        self._chk(nat.lib().aqe_generate_synthetic(self._h, n_local, shard_lo, n_global, seed,
+                                                   nat.STAGE_KEEP_AOS if keep_aos else 0))
+
+    def attach_device(self, amount_ptr: int, n_local: int, shard_lo: int, n_global: int, shift: float,
+                      aos_ptr: int = 0, keepalive=None):
+        self._chk(nat.lib().aqe_attach_device(self._h, C.c_void_p(amount_ptr), C.c_void_p(aos_ptr), n_local,
+                                              shard_lo, n_global, shift))
+        self._keepalive = keepalive
+
+    def set_shift(self, shift: float):
+        self._chk(nat.lib().aqe_set_shift(self._h, shift))
+
+    def release_table(self):
+        self._chk(nat.lib().aqe_release_table(self._h))
+        self._keepalive = None
+
+    def info(self) -> nat.TableInfo:
+        t = nat.TableInfo()
+        self._chk(nat.lib().aqe_table_info_get(self._h, C.byref(t)))
+        return t
+
+    # -- hot path --
+    def reduce(self, query: Query) -> Result:
+        res = Result()
+        self._chk(nat.lib().aqe_reduce(self._h, C.byref(query), C.byref(res)))
+        return res
+
+    def gather(self, query: Query) -> np.ndarray:
+        """Rows of the record-returning sampler, as a RECORD_DTYPE array."""
+        n = C.c_uint64()
+        rc = nat.lib().aqe_gather(self._h, C.byref(query), None, 0, C.byref(n))
+        if rc not in (nat.OK, nat.ERR_CAPACITY):
+            self._chk(rc)
+        out = np.zeros(max(n.value, 1), dtype=RECORD_DTYPE)
+        if n.value:
+            self._chk(nat.lib().aqe_gather(self._h, C.byref(query), out.ctypes.data, n.value, C.byref(n)))
+        return out[: n.value]
+
+    def plan(self, query: Query) -> Plan:
+        return Plan(self, query)
+
+
+def make_query(method: int, sample_percent: float = 10.0, agg: int = nat.SUM, convention: int = nat.EST_CLI,
+               where: Optional[Tuple[float, float]] = None, **kw) -> Query:
+    """aqe_query with the reference's defaults (bindings.cpp:56-101) plus overrides."""
+    q = nat.default_query(method=method, sample_percent=float(sample_percent), agg=agg, convention=convention, **kw)
+    if where is not None:
+        q.has_where, q.where_min, q.where_max = 1, float(where[0]), float(where[1])
+    return q

@@ -1,0 +1,234 @@
+/* include/aqe_hip.h — C ABI of libaqe_hip.so, the MI355X (gfx950) execution path for the
+ * reference's sampled SUM/AVG/COUNT reducer with CLT confidence interval.
+ *
+ * What it replaces.  The reference has no C ABI: its boundary is the pybind11 module `aqe_backend`
+ * (/root/reference/src/aqe_backend/bindings/bindings.cpp:10-137) whose class CustomBPlusDB *is* the
+ * operator API.  Each entry point below names the reference interface it stands in for; the Python
+ * mirror (approximatequeryengine_amd/aqe_backend.py) and INTEGRATION.md show the binding.
+ *   DB.cpp = src/aqe_backend/core/custom_bplus_db.cpp, DB.hpp = .../custom_bplus_db.hpp,
+ *   SCH.cpp = .../custom_scheduler.cpp, BIND = src/aqe_backend/bindings/bindings.cpp,
+ *   CLI = enhanced_aqe_cli.py, EXE = src/aqe_backend/executor.cpp.
+ *
+ * Conventions.  Plain C, POD structs, caller-allocated outputs, no C++/torch types.  Every function
+ * returns an aqe_status (0 = ok, negative = error; aqe_last_error() has the text).  A context is
+ * bound to one GPU and must be used from one host thread at a time.  There is no CPU fallback: with
+ * no usable HIP device aqe_create fails with AQE_ERR_NO_DEVICE.
+ *
+ * Data model.  A context holds one *shard*: rows [shard_lo, shard_lo + local_rows) of a table of
+ * global_rows rows in flat leaf order (the reference's `cached_records_`, DB.hpp:158-159).  Rows are
+ * staged once into HBM as a structure of arrays: the `amount` column (f64, the only column the
+ * reducers read) plus, optionally, the 32-byte AoS rows for the record-returning samplers.  All
+ * sampler arithmetic is on GLOBAL row indices, so the union over shards of what each shard samples
+ * is bit-identical to the single-device index set.
+ */
+#ifndef AQE_HIP_H
+#define AQE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AQE_API __attribute__((visibility("default")))
+#define AQE_ABI_VERSION 1
+
+typedef struct aqe_ctx aqe_ctx;   /* one GPU, one shard                              */
+typedef struct aqe_plan aqe_plan; /* a planned query: families, rounds, device state */
+
+typedef enum aqe_status {
+    AQE_OK = 0,
+    AQE_ERR_INVALID = -1,   /* bad argument, or parameters on which the reference divides by zero */
+    AQE_ERR_HIP = -2,       /* a HIP call failed                                                  */
+    AQE_ERR_NO_DEVICE = -3, /* no usable gfx950 device / HIP runtime                              */
+    AQE_ERR_NO_TABLE = -4,  /* nothing staged                                                     */
+    AQE_ERR_IO = -5,        /* file missing / malformed                                           */
+    AQE_ERR_CAPACITY = -6,  /* caller buffer too small                                            */
+    AQE_ERR_UNSUPPORTED = -7
+} aqe_status;
+
+/* DB.hpp:17-27 — the reference's 32-byte row, amount at byte 8. */
+typedef struct aqe_record {
+    int64_t id;
+    double amount;
+    int32_t region;
+    int32_t product_id;
+    int64_t timestamp;
+} aqe_record;
+
+/* Sampler selection; the number is the reference method it reproduces. */
+typedef enum aqe_method {
+    AQE_M_EXACT = 0,              /* sum_amount / sum_amount_where          DB.cpp:242-274   */
+    AQE_M_MEMORY_STRIDE = 1,      /* memory_stride_sample                   DB.cpp:1526-1603 */
+    AQE_M_ADDRESS_ARITHMETIC = 2, /* optimized_address_arithmetic_sample    DB.cpp:1667-1703 */
+    AQE_M_RANDOM_POINTER = 3,     /* random_pointer_sample (mt19937+Lemire) DB.cpp:856-882   */
+    AQE_M_BLOCK = 4,              /* block_sample                           DB.cpp:1151-1181 */
+    AQE_M_PAGE = 5,               /* page_sample                            DB.cpp:1183-1216 */
+    AQE_M_PARALLEL_BLOCK = 6,     /* parallel_block_sample                  DB.cpp:1218-1271 */
+    AQE_M_OPTIMIZED_CLT = 7,      /* optimized_clt_sample                   DB.cpp:1046-1147 */
+    AQE_M_CLT_DUAL_POINTER = 8,   /* clt_validated_dual_pointer_sample      DB.cpp:885-1043  */
+    AQE_M_FAST_POINTER = 9,       /* fast_pointer_sample                    DB.cpp:737-758   */
+    AQE_M_SLOW_POINTER = 10,      /* slow_pointer_sample                    DB.cpp:760-780   */
+    AQE_M_DUAL_POINTER = 11,      /* dual_pointer_sample                    DB.cpp:782-813   */
+    AQE_M_PARALLEL_POINTER = 12,  /* parallel_pointer_sample                DB.cpp:815-854   */
+    AQE_M_REGION_STRIDE = 13      /* multithreaded_memory_stride_sample / fast_aggregated_memory_stride_sum,
+                                     DB.cpp:1880-2048, with a seeded counter-based start per region */
+} aqe_method;
+
+typedef enum aqe_agg { AQE_SUM = 0, AQE_AVG = 1, AQE_COUNT = 2 } aqe_agg;
+
+/* How (n, S) become the reported value. */
+typedef enum aqe_convention {
+    AQE_EST_CLI = 0, /* CLI:189-200   SUM = S*(N/n), AVG = S/n, COUNT = N                         */
+    AQE_EST_CPP = 1, /* DB.cpp:303-315 SUM = S*(100/pct), AVG = SUM/N, COUNT = size_t(n*100/pct)   */
+    AQE_EST_RAW = 2  /* DB.cpp:2046   unscaled sample sum (fast_aggregated_memory_stride_sum)     */
+} aqe_convention;
+
+typedef struct aqe_query {
+    int32_t method;           /* aqe_method                                                      */
+    int32_t agg;              /* aqe_agg                                                         */
+    int32_t convention;       /* aqe_convention                                                  */
+    int32_t num_threads;      /* T of the parallel / CLT samplers (reference default 4)          */
+    double sample_percent;    /* pct, in percent                                                 */
+    uint64_t stride_bytes;    /* memory_stride_sample: 0 = auto (DB.cpp:1549-1556)               */
+    uint64_t block_size;      /* block rows (BLOCK/PARALLEL_BLOCK) or page bytes (PAGE)          */
+    uint64_t seed;            /* RANDOM_POINTER (low 32 bits), REGION_STRIDE                     */
+    int32_t step_size;        /* FAST_POINTER multiplier (reference default 2)                   */
+    int32_t check_interval;   /* CLT (reference default 10)                                      */
+    double confidence_level;  /* CLT: picks z = 2.576 / 1.96 / 1.645 (DB.cpp:911-912)            */
+    double max_error_percent; /* CLT: e, in percent (DB.cpp:958)                                 */
+    int32_t has_where;        /* 1: keep min <= amount <= max, both inclusive (DB.cpp:329)        */
+    int32_t reserved0;
+    double where_min, where_max;
+    uint64_t clt_round0;      /* CLT: samples per worker in round 0; 0 = check_interval          */
+    uint32_t clt_growth;      /* CLT: round r takes clt_round0*growth^r per worker; 0/1 = fixed   */
+    uint32_t flags;           /* AQE_Q_*                                                         */
+    uint64_t visible_rows;    /* M of the cached samplers; 0 = global_rows (the
+                                 reference's stale-cache quirk DB.cpp:188-191 is not reproduced)  */
+} aqe_query;
+
+#define AQE_Q_NO_TOPUP 1u /* CLT: skip the systematic top-up of DB.cpp:1031-1040 */
+
+/* Everything a caller of the reference computes from a sample, produced on the device. */
+typedef struct aqe_result {
+    double value;      /* estimate under query.convention                                   */
+    double ci_lower;   /* value -/+ margin; CLI:277-291 (1.96, two-pass variance)            */
+    double ci_upper;
+    double margin;     /* half-width actually applied to `value`                             */
+    double sum;        /* S  = sum of sampled amounts that pass WHERE                        */
+    double sumsq;      /* Q  = sum of squares                                                */
+    double mean;       /* S / n                                                              */
+    double m2;         /* sum (x - mean)^2                                                   */
+    uint64_t n;        /* samples folded into (S, Q) (pass WHERE)                            */
+    uint64_t visited;  /* samples drawn (== n without WHERE)                                 */
+    uint64_t topup;    /* CLT: rows added by the top-up                                      */
+    int32_t converged; /* CLT: 0 no, 1 error rule (DB.cpp:958), 2 cross-validation (DB.cpp:1009) */
+    int32_t rounds;    /* CLT: rounds folded before the stop                                 */
+    double kernel_ms;  /* device time of this query's kernels (events on the query stream)   */
+    uint64_t bytes_algorithmic; /* 8 B per visited sample (SoA amount column)                 */
+} aqe_result;
+
+/* One arithmetic family of sampled rows: row(o) = row0 + (o / seg_len) * pitch + (o % seg_len) * step
+ * for ordinals o in [ord_lo, ord_hi).  Every deterministic sampler is a short list of these. */
+typedef struct aqe_family {
+    uint64_t row0, pitch, seg_len, step;
+    uint64_t ord_lo, ord_hi;
+    uint32_t group; /* 0 = fast pointers / default, 1 = slow pointers */
+    uint32_t flags; /* AQE_F_* */
+} aqe_family;
+#define AQE_F_TOPUP 1u /* ord_hi is further limited on the device to base - collected */
+
+typedef struct aqe_table_info {
+    uint64_t global_rows, shard_lo, local_rows;
+    double shift;        /* c of the shifted moments (amount of global row 0 unless set)     */
+    int32_t has_aos;     /* 32-byte rows resident (record-returning samplers available)      */
+    int32_t device_id;
+    uint64_t hbm_bytes;  /* bytes this context holds in HBM                                  */
+} aqe_table_info;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+AQE_API int aqe_abi_version(void);
+/* replaces: CustomBPlusDB() (BIND:42-43, DB.cpp:123-129).  device_id: HIP ordinal. */
+AQE_API int aqe_create(int device_id, aqe_ctx** out);
+AQE_API void aqe_destroy(aqe_ctx* ctx);
+AQE_API const char* aqe_last_error(const aqe_ctx* ctx); /* ctx may be NULL: last create() error */
+AQE_API const char* aqe_status_string(int status);
+
+/* ---- staging: replaces insert_record/insert_batch + collect_leaf_records ("mmap") ------------ */
+#define AQE_STAGE_KEEP_AOS 1u /* also keep the 32-byte rows in HBM (needed by aqe_gather)     */
+/* Host rows (any pageable/mmap'd memory) -> HBM through pinned double buffers.  rows = this shard's
+ * rows [shard_lo, shard_lo+n_local) of a table of n_global rows.   DB.cpp:164-194, 715-735. */
+AQE_API int aqe_stage_records(aqe_ctx* ctx, const void* aos32, uint64_t n_local, uint64_t shard_lo,
+                              uint64_t n_global, uint32_t flags);
+/* The reference's file format (24-byte header + AoS, DB.cpp:665-711): mmap + stage rows
+ * [shard_lo, shard_lo+n_local) (n_local = 0: to the end).  Replaces open_database/load_from_file. */
+AQE_API int aqe_stage_file(aqe_ctx* ctx, const char* path, uint64_t shard_lo, uint64_t n_local,
+                           uint32_t flags);
+AQE_API int aqe_file_rows(const char* path, uint64_t* n_rows); /* header only */
+/* Writes the staged shard back in the reference's format (save_to_file, DB.cpp:665-683). */
+AQE_API int aqe_save_file(aqe_ctx* ctx, const char* path);
+/* Synthetic `sales` shard generated in HBM: id=i+1, amount=1+999*u(splitmix64(seed,i)). */
+AQE_API int aqe_generate_synthetic(aqe_ctx* ctx, uint64_t n_local, uint64_t shard_lo, uint64_t n_global,
+                                   uint64_t seed, uint32_t flags);
+/* Adopt caller-owned device memory (e.g. a torch tensor): f64 amount column, optional AoS rows. */
+AQE_API int aqe_attach_device(aqe_ctx* ctx, const double* dev_amount, const void* dev_aos32,
+                              uint64_t n_local, uint64_t shard_lo, uint64_t n_global, double shift);
+AQE_API int aqe_set_shift(aqe_ctx* ctx, double shift); /* all shards of one table must agree */
+AQE_API int aqe_table_info_get(const aqe_ctx* ctx, aqe_table_info* out);
+AQE_API int aqe_release_table(aqe_ctx* ctx);
+
+/* ---- host-side planning (no GPU needed) ------------------------------------------------------ */
+AQE_API void aqe_query_defaults(aqe_query* q); /* reference defaults of BIND:56-101 */
+/* Families of `q` over a table of n_global rows, clipped to rows [shard_lo, shard_hi).  For the CLT
+ * sampler `round` selects the round (families of the top-up come last, flagged AQE_F_TOPUP, when
+ * round == rounds).  Returns the number of families in *n_out (fams may be NULL to count).
+ * RANDOM_POINTER has no families: use aqe_plan_random_indices. */
+AQE_API int aqe_plan_families(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, uint64_t shard_hi,
+                              uint32_t round, aqe_family* fams, uint32_t cap, uint32_t* n_out,
+                              uint32_t* rounds_out, uint64_t* samples_out);
+/* Ascending unique indices of random_pointer_sample(pct, seed) that fall in [shard_lo, shard_hi). */
+AQE_API int aqe_plan_random_indices(uint64_t n_global, double pct, uint32_t seed, uint64_t shard_lo,
+                                    uint64_t shard_hi, uint64_t* out, uint64_t cap, uint64_t* n_out);
+/* WHERE-range extraction of the façade (SCH.cpp:277-294): returns 1 and fills lo/hi, 0 if none. */
+AQE_API int aqe_parse_where(const char* query, double* lo, double* hi);
+AQE_API double aqe_confidence_heuristic(double sample_percent, uint64_t total_records); /* SCH.cpp:296-305 */
+AQE_API double aqe_error_to_sample_percent(double error_percent);                       /* CLI:243-250 */
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/* One complete approximate aggregate on this context's GPU (shard must be the whole table):
+ * sample -> (n, S, Q) -> [CLT rounds with device-side should_stop] -> estimate + interval.
+ * Replaces: <sampler>(...) + CLI:189-200/262-291, fast_aggregated_memory_stride_sum (BIND:98-99),
+ * parallel_{sum,avg,count}[_where]_sample (DB.cpp:276-343), sum_amount[_where] (BIND:48-49). */
+AQE_API int aqe_reduce(aqe_ctx* ctx, const aqe_query* q, aqe_result* out);
+
+/* Record-returning form of the same samplers (BIND:50-101): rows in the reference's order
+ * (CLT: round-major order; compare as a multiset).  Needs AQE_STAGE_KEEP_AOS. */
+AQE_API int aqe_gather(aqe_ctx* ctx, const aqe_query* q, void* out_aos32, uint64_t cap, uint64_t* n_out);
+
+/* ---- stepwise / multi-GPU form ----------------------------------------------------------------
+ * One process per GPU; each rank plans the same query over its own shard.  Per round:
+ *     aqe_plan_enqueue_round(plan, r, dev_vec, stream)     this shard's partial moment vector
+ *     <all-reduce SUM of AQE_MOMENT_VEC doubles, e.g. torch.distributed over RCCL>
+ *     aqe_plan_enqueue_update(plan, r, dev_vec, stream)    fold + CLT rules + should_stop (on device)
+ * then aqe_plan_enqueue_finalize and aqe_plan_fetch.  Every rank sees the same reduced vector, takes
+ * the same stop decision, and a round enqueued after the stop is a device-side no-op.
+ * `stream` is a hipStream_t passed as void* (NULL = the context's own stream). */
+#define AQE_MOMENT_VEC 8 /* {n_a, S_a-c n_a, Q_a (shifted), n_b, S_b.., Q_b.., visited, 0} */
+AQE_API int aqe_plan_create(aqe_ctx* ctx, const aqe_query* q, aqe_plan** out);
+AQE_API void aqe_plan_destroy(aqe_plan* plan);
+AQE_API int aqe_plan_rounds(const aqe_plan* plan, uint32_t* rounds, int32_t* has_topup);
+AQE_API int aqe_plan_enqueue_round(aqe_plan* plan, uint32_t round, double* dev_vec, void* stream);
+AQE_API int aqe_plan_enqueue_update(aqe_plan* plan, uint32_t round, const double* dev_vec, void* stream);
+AQE_API int aqe_plan_enqueue_finalize(aqe_plan* plan, void* stream);
+/* fused single-GPU form: round + update in one launch (the last workgroup to arrive folds) */
+AQE_API int aqe_plan_enqueue_all(aqe_plan* plan, void* stream);
+AQE_API int aqe_plan_reset(aqe_plan* plan, void* stream); /* re-arm a plan for another execution */
+AQE_API int aqe_plan_fetch(aqe_plan* plan, aqe_result* out, void* stream); /* synchronises */
+/* device time between the first and last kernel of the most recent execution (HIP events) */
+AQE_API int aqe_plan_last_kernel_ms(aqe_plan* plan, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQE_HIP_H */

@@ -1,0 +1,380 @@
+"""GPU parity: every HIP kernel, called through the C ABI (libaqe_hip.so), against the oracle
+(oracle/aqe_oracle.c) on the same seeded table, and against the golden vectors recorded from the
+reference's own C++.
+
+Bars: sample counts / index sets (via the gather kernels) bit-exact; sums 1e-12 relative (f64, different
+summation order); estimates and interval bounds 1e-9 — far inside the 1e-6 the north star allows.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import digest, oracle_indices, rel
+
+pytestmark = pytest.mark.gpu
+
+SUM_TOL = 1e-12
+EST_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from approximatequeryengine_amd import _native
+    _native.lib()
+    return _native
+
+
+@pytest.fixture(scope="module")
+def engines(nat, table):
+    """engine(N) -> Engine with the seeded synthetic table of N rows staged from host rows (AoS kept)."""
+    from approximatequeryengine_amd.engine import Engine
+    cache = {}
+
+    def get(n):
+        if n not in cache:
+            if len(cache) >= 3:
+                k = next(iter(cache))
+                cache.pop(k).close()
+            e = Engine(0)
+            e.stage_records(table(n), keep_aos=True)
+            cache[n] = e
+        return cache[n]
+
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def _query_for(nat, call):
+    from approximatequeryengine_amd.engine import make_query
+    m, pct, a = call["method"], call["pct"], call["args"]
+    table_ = {
+        "memory_stride_sample": lambda: make_query(nat.M_MEMORY_STRIDE, pct, stride_bytes=int(a[0])),
+        "optimized_address_arithmetic_sample": lambda: make_query(nat.M_ADDRESS_ARITHMETIC, pct),
+        "random_pointer_sample": lambda: make_query(nat.M_RANDOM_POINTER, pct, seed=int(a[0])),
+        "block_sample": lambda: make_query(nat.M_BLOCK, pct, block_size=int(a[0])),
+        "page_sample": lambda: make_query(nat.M_PAGE, pct, block_size=int(a[0])),
+        "parallel_block_sample": lambda: make_query(nat.M_PARALLEL_BLOCK, pct, block_size=int(a[0]), num_threads=int(a[1])),
+        "optimized_clt_sample": lambda: make_query(nat.M_OPTIMIZED_CLT, pct, num_threads=int(a[2])),
+        "fast_pointer_sample": lambda: make_query(nat.M_FAST_POINTER, pct, step_size=int(a[0])),
+        "slow_pointer_sample": lambda: make_query(nat.M_SLOW_POINTER, pct),
+        "dual_pointer_sample": lambda: make_query(nat.M_DUAL_POINTER, pct),
+        "parallel_pointer_sample": lambda: make_query(nat.M_PARALLEL_POINTER, pct, num_threads=int(a[0])),
+        "clt_validated_dual_pointer_sample": lambda: make_query(
+            nat.M_CLT_DUAL_POINTER, pct, confidence_level=a[0], check_interval=int(a[1]), num_threads=int(a[2]),
+            max_error_percent=a[3]),
+    }
+    return table_[m]()
+
+
+def _check_against_oracle(nat, o, eng, rows, q, idx, where=None):
+    """HIP aggregate of query q == oracle moments over the oracle's index list."""
+    N = len(rows)
+    res = eng.reduce(q)
+    m = o.moments_idx(rows, idx, where=where)
+    assert res.visited == len(idx)
+    assert res.n == m.n
+    if m.n:
+        assert rel(res.sum, m.sum) <= SUM_TOL
+        assert rel(res.sumsq, m.sumsq) <= SUM_TOL
+        assert rel(res.m2, m.m2) <= 1e-9
+        if where is None:
+            est = o.lib.aqo_estimate_cli(q.agg, N, m.n, m.sum)
+            assert rel(res.value, est) <= EST_TOL
+            if m.n > 1 and q.agg != nat.COUNT:
+                moe, lo, hi = o.ci_cli(q.agg, N, m.n, m.m2, est)
+                assert rel(res.ci_lower, lo) <= EST_TOL and rel(res.ci_upper, hi) <= EST_TOL
+    return res
+
+
+@pytest.mark.parametrize("n", [10_000, 100_000, 100_007, 1_000_000])
+def test_golden_calls_reduce_and_gather(nat, oracle, golden, table, engines, n):
+    """Every deterministic reference call in the golden file: the HIP reduce reproduces the sums the
+    reference's samples give, and the HIP gather returns exactly the reference's rows."""
+    T = golden["tables"][str(n)]
+    rows, eng = table(n), engines(n)
+    for call in T["calls"]:
+        q = _query_for(nat, call)
+        if call["method"] in ("memory_stride_sample", "optimized_address_arithmetic_sample"):
+            q.visible_rows = T["cache_rows"]  # the reference's stale-cache length (DB.cpp:188-191)
+        res = eng.reduce(q)
+        g = call["idx"]
+        assert res.visited == g["n"], call
+        if g["n"]:
+            assert rel(res.sum, call["fsum"]) <= SUM_TOL, call
+            assert rel(res.sumsq, call["fsumsq"]) <= SUM_TOL, call
+        if "cli" in call and g["n"] > 1:
+            c = call["cli"]
+            assert rel(res.value, c["SUM"]) <= EST_TOL
+            assert rel(res.ci_lower, c["SUM_ci"][0]) <= EST_TOL and rel(res.ci_upper, c["SUM_ci"][1]) <= EST_TOL
+            q.agg = nat.AVG
+            r2 = eng.reduce(q)
+            assert rel(r2.value, c["AVG"]) <= EST_TOL
+            assert rel(r2.ci_lower, c["AVG_ci"][0]) <= EST_TOL and rel(r2.ci_upper, c["AVG_ci"][1]) <= EST_TOL
+            q.agg = nat.COUNT
+            assert eng.reduce(q).value == c["COUNT"]
+            q.agg = nat.SUM
+        if "where" in call:
+            w = call["where"]
+            q.has_where, q.where_min, q.where_max = 1, w["range"][0], w["range"][1]
+            rw = eng.reduce(q)
+            assert rw.n == w["n"] and rw.visited == g["n"]
+            assert rel(rw.sum, w["fsum"]) <= SUM_TOL
+            q.has_where = 0
+        # record-returning form: identical rows, identical order (CLT: as a multiset)
+        got = eng.gather(q)
+        idx = (got["id"] - 1).astype(np.uint64)
+        if call.get("sorted"):
+            idx = np.sort(idx)
+        assert digest(idx) == g, call
+        assert got.tobytes() == rows[(got["id"] - 1)].tobytes()
+
+
+@pytest.mark.parametrize("n", [10_000, 1_000_000])
+def test_seeded_random_pointer_seeds(nat, golden, table, engines, n):
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(n)
+    for call in golden["tables"][str(n)]["random_seeds"]:
+        q = make_query(nat.M_RANDOM_POINTER, call["pct"], seed=int(call["args"][0]))
+        res = eng.reduce(q)
+        assert res.visited == call["idx"]["n"] and rel(res.sum, call["fsum"]) <= SUM_TOL
+        got = eng.gather(q)
+        assert digest((got["id"] - 1).astype(np.uint64)) == call["idx"]
+
+
+@pytest.mark.parametrize("n", [10_000, 100_007, 1_000_000])
+def test_exact_scans(nat, oracle, golden, table, engines, n):
+    from approximatequeryengine_amd.engine import make_query
+    T, eng = golden["tables"][str(n)], engines(n)
+    r = eng.reduce(make_query(nat.M_EXACT, 100.0, agg=nat.SUM))
+    assert r.n == n and rel(r.value, T["exact"]["sum_amount"]) <= SUM_TOL
+    assert r.ci_lower == r.value == r.ci_upper
+    assert rel(eng.reduce(make_query(nat.M_EXACT, 100.0, agg=nat.AVG)).value, T["exact"]["sum_amount"] / n) <= SUM_TOL
+    assert eng.reduce(make_query(nat.M_EXACT, 100.0, agg=nat.COUNT)).value == n
+    for w in T["exact"]["where"]:
+        rw = eng.reduce(make_query(nat.M_EXACT, 100.0, where=tuple(w["range"])))
+        assert (rel(rw.value, w["sum"]) <= SUM_TOL) if w["sum"] else rw.value == 0.0
+
+
+CLT_CASES = [
+    # (N, pct, conf, check_interval, T, e, R0, growth)
+    (100_000, 20.0, 0.95, 10, 4, 2.0, 10, 1),      # reference cadence, converges (rule A) -> top-up
+    (100_000, 20.0, 0.95, 10, 4, 0.0, 10, 1),      # never converges: full dual-pointer sweep
+    (100_000, 20.0, 0.99, 10, 4, 1.0, 64, 2),      # geometric rounds
+    (100_007, 10.0, 0.90, 20, 6, 3.0, 20, 1),
+    (100_007, 5.0, 0.95, 4, 3, 0.5, 16, 3),
+    (1_000_000, 20.0, 0.95, 10, 4, 1.0, 1024, 2),
+    (1_000_000, 20.0, 0.95, 10, 4, 0.01, 4096, 2), # e = 0.01 % never converges at 1M
+    (10_000, 33.3, 0.95, 10, 2, 5.0, 10, 1),
+    (10_000, 100.0, 0.95, 10, 4, 0.0, 7, 1),
+    (10_000, 20.0, 0.95, 10, 1, 2.0, 10, 1),       # T=1: no fast pointer at all
+]
+
+
+@pytest.mark.parametrize("case", CLT_CASES, ids=lambda c: "N%d_p%g_T%d_e%g_R%d_g%d" % (c[0], c[1], c[4], c[5], c[6], c[7]))
+def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
+    from approximatequeryengine_amd.engine import make_query
+    n, pct, conf, ci, T, e, R0, g = case
+    rows, eng = table(n), engines(n)
+    rc, want, idx = oracle.clt_run(rows, pct, conf, ci, T, e, R0=R0, growth=g, want_idx=True)
+    assert rc == 0
+    q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=conf, check_interval=ci,
+                   num_threads=T, max_error_percent=e, clt_round0=R0, clt_growth=g)
+    res = eng.reduce(q)
+    assert res.converged == want.converged, (res.converged, want.converged)
+    assert res.rounds == want.rounds
+    assert res.topup == want.topup
+    assert res.n == want.final.n == res.visited
+    assert rel(res.sum, want.final.sum) <= SUM_TOL
+    assert rel(res.m2, want.final.m2) <= 1e-9
+    est = want.final.sum / want.final.n
+    assert rel(res.value, est) <= EST_TOL
+    moe, lo, hi = oracle.ci_cli(nat.AVG, n, want.final.n, want.final.m2, est)
+    assert rel(res.ci_lower, lo) <= EST_TOL and rel(res.ci_upper, hi) <= EST_TOL
+    got = eng.gather(q)
+    assert np.array_equal(np.sort(got["id"] - 1), np.sort(idx.astype(np.int64)))
+
+
+def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
+    """Where the reference divides by zero (DB.cpp:927, 985, 993) the C ABI returns AQE_ERR_INVALID."""
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(10_000)
+    for kw in (dict(sample_percent=0.01, num_threads=4), dict(sample_percent=10.0, check_interval=1)):
+        q = make_query(nat.M_CLT_DUAL_POINTER, **kw)
+        with pytest.raises(nat.AqeError) as ei:
+            eng.reduce(q)
+        assert ei.value.status == nat.ERR_INVALID
+    with pytest.raises(nat.AqeError):
+        eng.reduce(make_query(nat.M_DUAL_POINTER, 0.02))
+
+
+def test_conventions_and_where_composition(nat, oracle, table, engines):
+    """C++ convention (DB.cpp:303-315), raw sum (DB.cpp:2046) and block ∘ WHERE ∘ scale (config 5)."""
+    from approximatequeryengine_amd.engine import make_query
+    n = 1_000_000
+    rows, eng = table(n), engines(n)
+    idx = oracle.idx_block(n, 1.0, 1000)
+    for where in (None, (250.0, 750.0), (0.0, 10.0), (2000.0, 3000.0)):
+        m = oracle.moments_idx(rows, idx, where=where)
+        for agg in (nat.SUM, nat.AVG, nat.COUNT):
+            q = make_query(nat.M_BLOCK, 1.0, agg=agg, convention=nat.EST_CPP, where=where, block_size=1000)
+            r = eng.reduce(q)
+            assert r.n == m.n and r.visited == len(idx)
+            want = oracle.lib.aqo_estimate_cpp(agg, n, 1.0, len(idx), m.sum)
+            assert (rel(r.value, want) <= EST_TOL) if want else r.value == 0.0
+        r = eng.reduce(make_query(nat.M_BLOCK, 1.0, convention=nat.EST_RAW, where=where, block_size=1000))
+        assert (rel(r.value, m.sum) <= SUM_TOL) if m.n else r.value == 0.0
+    # region-stride reducer: fast_aggregated_memory_stride_sum semantics with seeded starts
+    for seed in (1, 7, 42):
+        idx = oracle.idx_region_stride(n, 1.0, 4, seed)
+        r = eng.reduce(make_query(nat.M_REGION_STRIDE, 1.0, convention=nat.EST_RAW, num_threads=4, seed=seed))
+        assert r.n == len(idx) and rel(r.value, oracle.moments_idx(rows, idx).sum) <= SUM_TOL
+
+
+def test_edge_shapes(nat, oracle, table):
+    """Empty and tiny tables, 100 % samples, ragged tails, block sizes that do not divide N."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    for n in (0, 1, 63, 64, 65, 511, 513, 1000, 4097):
+        rows = table(max(n, 1))[:n]
+        with Engine(0) as eng:
+            eng.stage_records(rows, keep_aos=True)
+            for q, idx in (
+                (make_query(nat.M_MEMORY_STRIDE, 50.0), oracle.idx_memory_stride(n, 50.0)),
+                (make_query(nat.M_MEMORY_STRIDE, 100.0), oracle.idx_memory_stride(n, 100.0)),
+                (make_query(nat.M_BLOCK, 30.0, block_size=7), oracle.idx_block(n, 30.0, 7)),
+                (make_query(nat.M_PAGE, 100.0, block_size=4096), oracle.idx_page(n, 100.0, 4096)),
+                (make_query(nat.M_RANDOM_POINTER, 100.0, seed=3), oracle.idx_random_pointer(n, 100.0, 3)),
+                (make_query(nat.M_PARALLEL_BLOCK, 60.0, block_size=5, num_threads=3), oracle.idx_parallel_block(n, 60.0, 5, 3)),
+                (make_query(nat.M_EXACT, 100.0), np.arange(n, dtype=np.uint64)),
+            ):
+                r = eng.reduce(q)
+                assert r.visited == len(idx), (n, q.method)
+                if len(idx):
+                    assert rel(r.sum, oracle.moments_idx(rows, idx).sum) <= SUM_TOL
+                else:
+                    assert r.value == 0.0 and r.n == 0
+                if q.method != nat.M_EXACT:
+                    got = eng.gather(q)
+                    assert np.array_equal(got["id"] - 1, idx.astype(np.int64))
+
+
+def test_numerical_stability_large_offset(nat, oracle):
+    """amounts = 1e9 + tiny noise: the shifted/Welford accumulation keeps the variance (hence the CI)
+    where a raw sum-of-squares would lose every digit."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 200_000
+    rows = oracle.synth(n, 7)
+    rows["amount"] = 1e9 + (rows["amount"] - 500.0) * 1e-3
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)
+        idx = oracle.idx_memory_stride(n, 10.0)
+        m = oracle.moments_idx(rows, idx)
+        r = eng.reduce(make_query(nat.M_MEMORY_STRIDE, 10.0, agg=nat.AVG))
+        assert rel(r.value, m.sum / m.n) <= 1e-12
+        assert rel(r.m2, m.m2) <= 1e-6
+        moe, lo, hi = oracle.ci_cli(nat.AVG, n, m.n, m.m2, m.sum / m.n)
+        assert rel(r.ci_upper - r.ci_lower, hi - lo) <= 1e-6
+
+
+def test_run_to_run_bitwise_reproducible(nat, engines):
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(1_000_000)
+    for q in (make_query(nat.M_MEMORY_STRIDE, 20.0), make_query(nat.M_BLOCK, 5.0),
+              make_query(nat.M_CLT_DUAL_POINTER, 20.0, max_error_percent=0.0, clt_round0=2048, clt_growth=2)):
+        a = eng.reduce(q)
+        for _ in range(20):
+            b = eng.reduce(q)
+            assert (a.sum, a.sumsq, a.value, a.ci_lower, a.n) == (b.sum, b.sumsq, b.value, b.ci_lower, b.n)
+
+
+def test_file_staging_round_trip(nat, oracle, golden, table, tmp_path):
+    """The reference's file format (DB.cpp:665-711): stage from a file, save, byte-identical."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 50_000
+    rows = table(100_000)[:n]
+    p = tmp_path / "t.db"
+    assert oracle.file_write(p, rows) == 0
+    with Engine(0) as eng:
+        eng.stage_file(p, keep_aos=True)
+        assert eng.info().global_rows == n
+        r = eng.reduce(make_query(nat.M_EXACT, 100.0))
+        assert rel(r.value, math.fsum(rows["amount"])) <= SUM_TOL
+        q = tmp_path / "out.db"
+        eng.save_file(q)
+        assert q.read_bytes()[24:] == p.read_bytes()[24:]
+        assert q.read_bytes()[:8] == p.read_bytes()[:8] and q.read_bytes()[16:24] == p.read_bytes()[16:24]
+        # a shard of the file, staged amount-only
+        eng.stage_file(p, shard_lo=10_000, n_local=20_000, keep_aos=False)
+        t = eng.info()
+        assert (t.global_rows, t.shard_lo, t.local_rows, t.has_aos) == (n, 10_000, 20_000, 0)
+        assert t.shift == rows["amount"][0]
+
+
+def test_synthetic_generator_matches_oracle(nat, oracle):
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 300_001
+    rows = oracle.synth(n, 42)
+    with Engine(0) as eng:
+        eng.generate_synthetic(n, seed=42, keep_aos=True)
+        assert eng.info().shift == rows["amount"][0]
+        got = eng.gather(make_query(nat.M_MEMORY_STRIDE, 100.0))
+        assert got.tobytes() == rows.tobytes()
+        r = eng.reduce(make_query(nat.M_EXACT, 100.0))
+        assert rel(r.value, math.fsum(rows["amount"])) <= SUM_TOL
+
+
+def test_sharded_plan_api_single_gpu_virtual_shards(nat, oracle, table):
+    """G virtual shards on one GPU through the stepwise API: per-round partial vectors summed on the host
+    stand in for the all-reduce; result identical to the single-shard query for G in {1,2,3,8}."""
+    import ctypes as C
+    from approximatequeryengine_amd.engine import Engine, make_query
+    import torch
+    n = 100_007
+    rows = table(n)
+    queries = [
+        make_query(nat.M_MEMORY_STRIDE, 1.0),
+        make_query(nat.M_BLOCK, 5.0, where=(250.0, 750.0)),
+        make_query(nat.M_RANDOM_POINTER, 2.0, seed=9),
+        make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=1.0, clt_round0=256, clt_growth=2, num_threads=8),
+        make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.0, clt_round0=4096, clt_growth=2),
+    ]
+    with Engine(0) as whole:
+        whole.stage_records(rows, keep_aos=False)
+        refs = [whole.reduce(q) for q in queries]
+    for G in (1, 2, 3, 8):
+        bounds = [(g * n) // G for g in range(G + 1)]
+        engs = []
+        for g in range(G):
+            e = Engine(0)
+            e.stage_records(rows[bounds[g]:bounds[g + 1]], shard_lo=bounds[g], n_global=n, keep_aos=False)
+            e.set_shift(float(rows["amount"][0]))
+            engs.append(e)
+        side = torch.cuda.Stream()
+        st = side.cuda_stream
+        for q, want in zip(queries, refs):
+            plans = [e.plan(q) for e in engs]
+            rounds, topup = plans[0].rounds, plans[0].has_topup
+            with torch.cuda.stream(side):
+                vecs = torch.zeros(G, nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
+                for p in plans:
+                    p.reset(st)
+                for r in range(rounds + (1 if topup else 0)):
+                    vecs.zero_()  # a launch that leaves early (should_stop) writes nothing
+                    for g, p in enumerate(plans):
+                        p.enqueue_round(r, vecs[g].data_ptr(), st)
+                    total = vecs.sum(0)  # stand-in for the all-reduce, same stream => ordered
+                    for p in plans:
+                        p.enqueue_update(r, total.data_ptr(), st)
+                outs = []
+                for p in plans:
+                    p.enqueue_finalize(st)
+                    outs.append(p.fetch(st))
+            for o_ in outs:
+                assert (o_.n, o_.visited, o_.converged, o_.rounds, o_.topup) == (want.n, want.visited, want.converged, want.rounds, want.topup)
+                assert rel(o_.sum, want.sum) <= SUM_TOL and rel(o_.value, want.value) <= EST_TOL
+                assert rel(o_.ci_lower, want.ci_lower) <= EST_TOL
+            for p in plans:
+                p.close()
+        for e in engs:
+            e.close()
