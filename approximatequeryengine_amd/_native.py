@@ -112,6 +112,9 @@ def lib() -> C.CDLL:
         "aqe_plan_reset": (C.c_int, [vp, vp]),
         "aqe_plan_fetch": (C.c_int, [vp, P(Result), vp]),
         "aqe_plan_last_kernel_ms": (C.c_int, [vp, P(C.c_float)]),
+        "aqe_plan_set_profiling": (C.c_int, [vp, C.c_int]),
+        "aqe_plan_launch_ms": (C.c_int, [vp, P(C.c_float), u32, P(u32)]),
+        "aqe_plan_launch_samples": (C.c_int, [vp, P(u64), u32, P(u32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -69,6 +69,10 @@ struct aqe_plan {
     aqe_result* h_result = nullptr;  // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
+    bool profile = false;
+    std::vector<hipEvent_t> lev;
+    uint32_t lev_used = 0;
 };
 
 namespace {
@@ -108,6 +112,7 @@ void destroy_plan(aqe_plan* p) {
     if (p->h_result) (void)hipHostFree(p->h_result);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (auto e : p->lev) (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -200,8 +205,11 @@ hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStr
 int enqueue_launch(aqe_plan* p, const LaunchDesc& L, bool topup, bool fused, double* out_vec, hipStream_t s) {
     aqe_ctx* c = p->ctx;
     RoundLaunch a = round_launch(p, L, topup, fused, out_vec);
+    const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
+    if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
     if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s));
     else HIPCHK(c, launch_round(a, s));
+    if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
     return AQE_OK;
 }
 
@@ -276,6 +284,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s) {
     aqe_ctx* c = p->ctx;
     HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
     HIPCHK(c, hipEventRecord(p->ev0, s));
+    p->lev_used = 0;
     for (const auto& L : p->rounds) {
         int rc = enqueue_launch(p, L, false, true, nullptr, s);
         if (rc != AQE_OK) return rc;
@@ -652,6 +661,7 @@ int aqe_plan_reset(aqe_plan* p, void* stream) {
     hipStream_t s = pick(p, stream);
     HIPCHK(p->ctx, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
     p->timed = false;
+    p->lev_used = 0;
     return AQE_OK;
 }
 
@@ -704,6 +714,44 @@ int aqe_plan_last_kernel_ms(aqe_plan* p, float* ms) {
     if (!p->timed) return fail(p->ctx, AQE_ERR_INVALID, "no timed execution yet");
     HIPCHK(p->ctx, hipEventSynchronize(p->ev1));
     HIPCHK(p->ctx, hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return AQE_OK;
+}
+
+int aqe_plan_set_profiling(aqe_plan* p, int enable) {
+    if (!p) return AQE_ERR_INVALID;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    p->profile = enable != 0;
+    const size_t want = 2 * (p->rounds.size() + 1);
+    while (p->profile && p->lev.size() < want) {
+        hipEvent_t e;
+        HIPCHK(p->ctx, hipEventCreate(&e));
+        p->lev.push_back(e);
+    }
+    p->lev_used = 0;
+    return AQE_OK;
+}
+
+int aqe_plan_launch_ms(aqe_plan* p, float* ms, uint32_t cap, uint32_t* n_out) {
+    if (!p || !n_out) return AQE_ERR_INVALID;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    *n_out = p->lev_used;
+    if (!ms) return AQE_OK;
+    if (cap < p->lev_used) return fail(p->ctx, AQE_ERR_CAPACITY, "launch_ms buffer too small");
+    for (uint32_t i = 0; i < p->lev_used; ++i) {
+        HIPCHK(p->ctx, hipEventSynchronize(p->lev[2 * i + 1]));
+        HIPCHK(p->ctx, hipEventElapsedTime(&ms[i], p->lev[2 * i], p->lev[2 * i + 1]));
+    }
+    return AQE_OK;
+}
+
+int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, uint32_t* n_out) {
+    if (!p || !n_out) return AQE_ERR_INVALID;
+    const uint32_t n = static_cast<uint32_t>(p->rounds.size()) + (p->host.has_topup ? 1u : 0u);
+    *n_out = n;
+    if (!samples) return AQE_OK;
+    if (cap < n) return AQE_ERR_CAPACITY;
+    for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
+    if (p->host.has_topup) samples[p->rounds.size()] = p->topup.samples;
     return AQE_OK;
 }
 

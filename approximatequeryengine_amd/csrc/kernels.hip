@@ -280,7 +280,7 @@ __global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* ou
     double moe = 0.0;  // CLI:279-282: two-pass variance, fixed 1.96
     if (n > 1.0) moe = 1.96 * sqrt(m2 / (n - 1.0)) / sqrt(n);
     double value = 0.0, margin = 0.0;
-    if (n > 0.0 || p.is_exact) {
+    {
         if (p.is_exact) {  // DB.cpp:242-274
             value = p.agg == AQE_SUM ? S : p.agg == AQE_AVG ? (N > 0.0 ? S / N : 0.0) : (visited > n ? n : N);
         } else if (p.convention == AQE_EST_CLI) {  // CLI:189-200; interval CLI:284-291

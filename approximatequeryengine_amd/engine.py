@@ -66,6 +66,23 @@ class Plan:
         self._chk(nat.lib().aqe_plan_fetch(self._h, C.byref(res), C.c_void_p(stream)))
         return res
 
+    def set_profiling(self, enable: bool = True):
+        self._chk(nat.lib().aqe_plan_set_profiling(self._h, int(enable)))
+
+    def launch_ms(self):
+        n = C.c_uint32()
+        self._chk(nat.lib().aqe_plan_launch_ms(self._h, None, 0, C.byref(n)))
+        buf = (C.c_float * max(n.value, 1))()
+        self._chk(nat.lib().aqe_plan_launch_ms(self._h, buf, n.value, C.byref(n)))
+        return list(buf[: n.value])
+
+    def launch_samples(self):
+        n = C.c_uint32()
+        self._chk(nat.lib().aqe_plan_launch_samples(self._h, None, 0, C.byref(n)))
+        buf = (C.c_uint64 * max(n.value, 1))()
+        self._chk(nat.lib().aqe_plan_launch_samples(self._h, buf, n.value, C.byref(n)))
+        return list(buf[: n.value])
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._chk(nat.lib().aqe_plan_last_kernel_ms(self._h, C.byref(ms)))

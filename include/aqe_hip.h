@@ -227,6 +227,14 @@ AQE_API int aqe_plan_reset(aqe_plan* plan, void* stream); /* re-arm a plan for a
 AQE_API int aqe_plan_fetch(aqe_plan* plan, aqe_result* out, void* stream); /* synchronises */
 /* device time between the first and last kernel of the most recent execution (HIP events) */
 AQE_API int aqe_plan_last_kernel_ms(aqe_plan* plan, float* ms);
+/* Per-launch timing for roofline reports: with profiling on, every sweep launch (rounds, top-up) of the
+ * next executions is bracketed by its own HIP event pair on the launch stream; aqe_plan_launch_ms
+ * returns the elapsed time of each launch of the most recent execution, in launch order. */
+AQE_API int aqe_plan_set_profiling(aqe_plan* plan, int enable);
+AQE_API int aqe_plan_launch_ms(aqe_plan* plan, float* ms, uint32_t cap, uint32_t* n_out);
+/* samples (sampled rows) each sweep launch of this shard folds, in launch order; the top-up entry is
+ * its upper bound */
+AQE_API int aqe_plan_launch_samples(const aqe_plan* plan, uint64_t* samples, uint32_t cap, uint32_t* n_out);
 
 #ifdef __cplusplus
 }
