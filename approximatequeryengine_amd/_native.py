@@ -73,6 +73,13 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime.  When both live in one process torch's copy must be the
+    # one that gets loaded (loading /opt/rocm's first leaves torch without a device), so import torch
+    # before dlopen-ing the library.  torch stays optional: without it the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = Path(os.environ.get("AQE_HIP_LIB", LIB))
     if not path.exists() or "AQE_HIP_LIB" not in os.environ:
         path = build_native()

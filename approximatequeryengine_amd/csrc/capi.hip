@@ -172,7 +172,21 @@ FoldParams fold_params(const aqe_plan* p, bool topup) {
     return f;
 }
 
-RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, bool topup, bool fused, double* out_vec) {
+FinalizeParams finalize_params(const aqe_plan* p) {
+    FinalizeParams f{};
+    f.n_global = p->ctx->n_global;
+    f.pct = p->q.sample_percent;
+    f.agg = p->q.agg;
+    f.convention = p->q.convention;
+    f.is_exact = p->q.method == AQE_M_EXACT;
+    f.is_clt = p->host.is_clt;
+    return f;
+}
+
+// `index` is the launch's position in the query: rounds 0..R-1, then the top-up.  The first launch
+// folds into a zeroed state (no memset), later CLT launches test should_stop on entry, and in the fused
+// single-GPU form the last launch also writes the result.
+RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec) {
     const aqe_ctx* c = p->ctx;
     RoundLaunch a{};
     a.amount = c->amount;
@@ -188,8 +202,13 @@ RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, bool topup, boo
     a.out_vec = out_vec;
     a.state = p->d_state;
     a.fused = fused ? 1 : 0;
-    a.check_stop = p->host.is_clt ? 1 : 0;
+    a.check_stop = (p->host.is_clt && index > 0 && !topup) ? 1 : 0;
+    a.reset_state = (index == 0 && !topup) ? 1 : 0;
+    const uint32_t last = static_cast<uint32_t>(p->rounds.size()) - (p->host.has_topup ? 0u : 1u);
+    a.do_finalize = (fused && index == last) ? 1 : 0;
     a.fold = fold_params(p, topup);
+    a.fin = finalize_params(p);
+    a.result = p->d_result;
     return a;
 }
 
@@ -202,26 +221,15 @@ int plan_is_current(aqe_plan* p) {
 
 hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStream_t>(stream) : p->ctx->stream; }
 
-int enqueue_launch(aqe_plan* p, const LaunchDesc& L, bool topup, bool fused, double* out_vec, hipStream_t s) {
+int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, hipStream_t s) {
     aqe_ctx* c = p->ctx;
-    RoundLaunch a = round_launch(p, L, topup, fused, out_vec);
+    RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec);
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
     if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
     if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s));
     else HIPCHK(c, launch_round(a, s));
     if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
     return AQE_OK;
-}
-
-FinalizeParams finalize_params(const aqe_plan* p) {
-    FinalizeParams f{};
-    f.n_global = p->ctx->n_global;
-    f.pct = p->q.sample_percent;
-    f.agg = p->q.agg;
-    f.convention = p->q.convention;
-    f.is_exact = p->q.method == AQE_M_EXACT;
-    f.is_clt = p->host.is_clt;
-    return f;
 }
 
 int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
@@ -282,18 +290,21 @@ int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
 
 int enqueue_all(aqe_plan* p, hipStream_t s) {
     aqe_ctx* c = p->ctx;
-    HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
     HIPCHK(c, hipEventRecord(p->ev0, s));
     p->lev_used = 0;
-    for (const auto& L : p->rounds) {
-        int rc = enqueue_launch(p, L, false, true, nullptr, s);
-        if (rc != AQE_OK) return rc;
+    if (p->rounds.empty()) {  // nothing to sample (empty table / zero target): a zero state, finalized
+        HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
+        HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
+    } else {
+        for (uint32_t i = 0; i < p->rounds.size(); ++i) {
+            int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
+        if (p->host.has_topup) {
+            int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
     }
-    if (p->host.has_topup) {
-        int rc = enqueue_launch(p, p->topup, true, true, nullptr, s);
-        if (rc != AQE_OK) return rc;
-    }
-    HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
     HIPCHK(c, hipEventRecord(p->ev1, s));
     p->timed = true;
     return AQE_OK;
@@ -659,7 +670,7 @@ int aqe_plan_reset(aqe_plan* p, void* stream) {
     if (rc != AQE_OK) return rc;
     HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
     hipStream_t s = pick(p, stream);
-    HIPCHK(p->ctx, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
+    if (p->rounds.empty()) HIPCHK(p->ctx, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
     p->timed = false;
     p->lev_used = 0;
     return AQE_OK;
@@ -672,7 +683,7 @@ int aqe_plan_enqueue_round(aqe_plan* p, uint32_t round, double* dev_vec, void* s
     HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
     const bool topup = round == p->rounds.size() && p->host.has_topup;
     if (!topup && round >= p->rounds.size()) return fail(p->ctx, AQE_ERR_INVALID, "round out of range");
-    return enqueue_launch(p, topup ? p->topup : p->rounds[round], topup, false, dev_vec, pick(p, stream));
+    return enqueue_launch(p, topup ? p->topup : p->rounds[round], round, topup, false, dev_vec, pick(p, stream));
 }
 
 int aqe_plan_enqueue_update(aqe_plan* p, uint32_t round, const double* dev_vec, void* stream) {
@@ -682,7 +693,7 @@ int aqe_plan_enqueue_update(aqe_plan* p, uint32_t round, const double* dev_vec, 
     HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
     const bool topup = round == p->rounds.size() && p->host.has_topup;
     if (!topup && round >= p->rounds.size()) return fail(p->ctx, AQE_ERR_INVALID, "round out of range");
-    HIPCHK(p->ctx, launch_update(p->d_state, dev_vec, fold_params(p, topup), pick(p, stream)));
+    HIPCHK(p->ctx, launch_update(p->d_state, dev_vec, fold_params(p, topup), (round == 0 && !topup) ? 1 : 0, pick(p, stream)));
     return AQE_OK;
 }
 

@@ -54,133 +54,211 @@ __device__ __forceinline__ void welford_merge(double& n, double& mean, double& m
 }
 
 // Fold one launch's reduced vector into the query state and take the CLT decision.
-__device__ void fold(QueryState* s, const double* vec, const FoldParams& p) {
+__device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], const FoldParams& p) {
     if (p.is_topup) {  // DB.cpp:1031-1040: systematic rows appended to the sample
-        welford_merge(s->n_p, s->mean_p, s->m2_p, vec[0], vec[1], vec[2], p.shift);
-        s->topup += vec[0];
-        s->visited += vec[6];
+        welford_merge(s.n_p, s.mean_p, s.m2_p, vec[0], vec[1], vec[2], p.shift);
+        s.topup += vec[0];
+        s.visited += vec[6];
         return;
     }
-    welford_merge(s->n_a, s->mean_a, s->m2_a, vec[0], vec[1], vec[2], p.shift);
-    welford_merge(s->n_b, s->mean_b, s->m2_b, vec[3], vec[4], vec[5], p.shift);
-    welford_merge(s->n_p, s->mean_p, s->m2_p, vec[0], vec[1], vec[2], p.shift);
-    welford_merge(s->n_p, s->mean_p, s->m2_p, vec[3], vec[4], vec[5], p.shift);
-    s->visited += vec[6];
-    s->rounds += 1;
+    welford_merge(s.n_a, s.mean_a, s.m2_a, vec[0], vec[1], vec[2], p.shift);
+    welford_merge(s.n_b, s.mean_b, s.m2_b, vec[3], vec[4], vec[5], p.shift);
+    welford_merge(s.n_p, s.mean_p, s.m2_p, vec[0], vec[1], vec[2], p.shift);
+    welford_merge(s.n_p, s.mean_p, s.m2_p, vec[3], vec[4], vec[5], p.shift);
+    s.visited += vec[6];
+    s.rounds += 1;
     if (!p.is_clt) return;
     // rule A, DB.cpp:936-961, on the pooled (all-reduced) moments
-    const double n = s->n_p;
+    const double n = s.n_p;
     if (n >= 30.0) {
-        double var = s->m2_p / (n - 1.0);
+        double var = s.m2_p / (n - 1.0);
         double se = sqrt(var / n);
-        double err = (p.z * se / s->mean_p) * 100.0;
+        double err = (p.z * se / s.mean_p) * 100.0;
         if (err <= p.e && n >= 50.0) {
-            s->converged = 1;
-            s->stop = 1;
+            s.converged = 1;
+            s.stop = 1;
             return;
         }
     }
     // rule B, DB.cpp:993-1016: slow pointers cross-validate the fast pointers' mean
-    if (s->n_b >= 20.0 && s->n_a >= 30.0 && s->mean_a > 0.0) {
-        double diff = fabs(s->mean_b - s->mean_a) / s->mean_a;
-        if (diff <= p.e / 100.0 && s->n_a >= static_cast<double>(p.base / 2)) {
-            s->converged = 2;
-            s->stop = 1;
+    if (s.n_b >= 20.0 && s.n_a >= 30.0 && s.mean_a > 0.0) {
+        double diff = fabs(s.mean_b - s.mean_a) / s.mean_a;
+        if (diff <= p.e / 100.0 && s.n_a >= static_cast<double>(p.base / 2)) {
+            s.converged = 2;
+            s.stop = 1;
         }
     }
 }
 
-// Workgroup epilogue shared by k_round and k_indexed: wave64 shuffle tree -> LDS -> one 64-byte partial
-// per workgroup, published with write-through (sc1) stores by ONE lane, then an agent-scope ticket.
-// The workgroup that draws the last ticket re-reads every partial with sc1 loads in a fixed order
-// (deterministic sum), resets the ticket and folds.  (cdna_hip_programming.md G16, counter form.)
-__device__ void finish_block(const Acc& acc, const RoundLaunch& a) {
-    __shared__ double red[kWavesPerBlock][kVec];
-    __shared__ double tree[kBlockThreads];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Estimate + interval from the folded state (CLI:189-200, 277-291; DB.cpp:303-315).
+__device__ __forceinline__ void finalize(const QueryState& s, const FinalizeParams& p, aqe_result* out) {
+    aqe_result r;
+    const double n = s.n_p, mean = n > 0.0 ? s.mean_p : 0.0, m2 = s.m2_p, visited = s.visited;
+    const double N = static_cast<double>(p.n_global);
+    const double S = n * mean;
+    r.sum = S;
+    r.sumsq = m2 + n * mean * mean;
+    r.mean = mean;
+    r.m2 = m2;
+    r.n = static_cast<uint64_t>(n);
+    r.visited = static_cast<uint64_t>(visited);
+    r.topup = static_cast<uint64_t>(s.topup);
+    r.converged = s.converged;
+    r.rounds = s.rounds;
+    r.kernel_ms = 0.0;
+    r.bytes_algorithmic = r.visited * 8ull;
 
-    double r[7];
-    r[0] = wave_sum(static_cast<double>(acc.na));
-    r[1] = wave_sum(acc.sa);
-    r[2] = wave_sum(acc.qa);
-    r[3] = wave_sum(static_cast<double>(acc.nb));
-    r[4] = wave_sum(acc.sb);
-    r[5] = wave_sum(acc.qb);
-    r[6] = wave_sum(static_cast<double>(acc.nv));
+    double moe = 0.0;  // CLI:279-282: two-pass variance, fixed 1.96
+    if (n > 1.0) moe = 1.96 * sqrt(m2 / (n - 1.0)) / sqrt(n);
+    double value = 0.0, margin = 0.0;
+    if (p.is_exact) {  // DB.cpp:242-274
+        value = p.agg == AQE_SUM ? S : p.agg == AQE_AVG ? (N > 0.0 ? S / N : 0.0) : (visited > n ? n : N);
+    } else if (p.convention == AQE_EST_CLI) {  // CLI:189-200; interval CLI:284-291
+        const double scale = visited > 0.0 ? N / visited : 0.0;
+        if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
+        else if (p.agg == AQE_COUNT) { value = visited > n ? n * scale : (visited > 0.0 ? N : 0.0); }
+        else { value = n > 0.0 ? S / n : 0.0; margin = moe; }
+    } else if (p.convention == AQE_EST_CPP) {  // DB.cpp:303-315; interval scaled as executor.cpp:192-197
+        const double scale = 100.0 / p.pct;
+        if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
+        else if (p.agg == AQE_AVG) { value = N > 0.0 ? S * scale / N : 0.0; margin = moe; }
+        else { value = static_cast<double>(static_cast<uint64_t>(visited * scale)); }
+    } else {  // raw sample aggregate, DB.cpp:2046
+        if (p.agg == AQE_SUM) { value = S; margin = moe * n; }
+        else if (p.agg == AQE_AVG) { value = mean; margin = moe; }
+        else { value = visited; }
+    }
+    r.value = value;
+    r.margin = margin;
+    r.ci_lower = value - margin;
+    r.ci_upper = value + margin;
+    *out = r;
+}
+
+// Sum 7 per-thread values over the workgroup in a fixed order: wave64 shuffle tree, then the four
+// wave results through LDS.  The totals are valid in thread 0.  `red` must be quiescent on entry.
+__device__ __forceinline__ void block_sum7(double (&v)[7], double (*red)[kVec]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = wave_sum(v[k]);
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) red[wave][k] = r[k];
+        for (int k = 0; k < 7; ++k) red[wave][k] = v[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double* mine = a.partials + static_cast<size_t>(blockIdx.x) * kVec;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            double v = red[0][k];
-            for (int w = 1; w < kWavesPerBlock; ++w) v += red[w][k];
-            __hip_atomic_store(mine + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double t = red[0][k];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) t += red[w][k];
+            v[k] = t;
         }
+    }
+}
+
+// Thread 0 of the folding workgroup: write the reduced vector, fold it into the running state
+// (starting from zero on a query's first launch), and finish the query on its last launch.
+__device__ __forceinline__ void fold_and_finish(const double (&tot)[7], const RoundLaunch& a) {
+    double vec[kVec];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) vec[k] = tot[k];
+    vec[7] = 0.0;
+    if (a.out_vec) {
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) a.out_vec[k] = vec[k];
+    }
+    if (a.fused) {
+        QueryState st;
+        if (a.reset_state) st = QueryState{}; else st = *a.state;
+        fold(st, vec, a.fold);
+        *a.state = st;
+        if (a.do_finalize) finalize(st, a.fin, a.result);
+    }
+}
+
+// Workgroup epilogue shared by k_round and k_indexed: block sum -> one 56-byte partial per workgroup,
+// published with write-through (sc1) stores by ONE lane, then an agent-scope ticket.  The workgroup
+// that draws the last ticket re-reads every partial with sc1 loads in a fixed order (deterministic
+// sum), resets the ticket and folds.  (cdna_hip_programming.md G16, counter form.)
+__device__ __forceinline__ void finish_block(const Acc& acc, const RoundLaunch& a) {
+    __shared__ double red[kWavesPerBlock][kVec];
+    __shared__ int s_last;
+    double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
+                   static_cast<double>(acc.nv)};
+    block_sum7(v, red);
+    if (gridDim.x == 1) {  // a launch small enough for one workgroup needs no hand-off
+        if (threadIdx.x == 0) fold_and_finish(v, a);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        double* mine = a.partials + static_cast<size_t>(blockIdx.x) * kVec;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) __hip_atomic_store(mine + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial is out before the ticket is drawn
         unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (ticket == gridDim.x - 1);
     }
     __syncthreads();
     if (!s_last) return;
-
-    double tot[7];
+    double t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += kBlockThreads) {
+        const double* p = a.partials + static_cast<size_t>(b) * kVec;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        double v = 0.0;
-        for (unsigned b = threadIdx.x; b < gridDim.x; b += kBlockThreads)
-            v += __hip_atomic_load(a.partials + static_cast<size_t>(b) * kVec + k, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        tree[threadIdx.x] = v;
-        __syncthreads();
-        for (int h = kBlockThreads / 2; h > 0; h >>= 1) {
-            if (static_cast<int>(threadIdx.x) < h) tree[threadIdx.x] += tree[threadIdx.x + h];
-            __syncthreads();
-        }
-        tot[k] = tree[0];
-        __syncthreads();
+        for (int k = 0; k < 7; ++k) t[k] += __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();  // `red` is reused
+    block_sum7(t, red);
     if (threadIdx.x == 0) {
         __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double vec[kVec];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) vec[k] = tot[k];
-        vec[7] = 0.0;
-        if (a.out_vec) {
-#pragma unroll
-            for (int k = 0; k < kVec; ++k) a.out_vec[k] = vec[k];
-        }
-        if (a.fused) fold(a.state, vec, a.fold);
+        fold_and_finish(t, a);
     }
 }
 
-__device__ __forceinline__ void accumulate(Acc& acc, double x, bool ok, bool group_b, const RoundLaunch& a) {
-    if (!ok) return;
-    acc.nv += 1;
-    if (a.has_where && !(x >= a.wmin && x <= a.wmax)) return;  // inclusive both ends, DB.cpp:329
-    double d = x - a.fold.shift;
-    if (group_b) {
-        acc.nb += 1; acc.sb += d; acc.qb += d * d;
-    } else {
-        acc.na += 1; acc.sa += d; acc.qa += d * d;
-    }
+// Per-tile accumulator (one pointer group per tile), merged into the lane's two groups with selects:
+// a data-dependent choice of WHICH accumulator to update makes hipcc index the struct in scratch.
+struct TileAcc {
+    double s = 0.0, q = 0.0;
+    unsigned n = 0, nv = 0;
+};
+
+__device__ __forceinline__ void accumulate(TileAcc& t, double x, bool ok, const RoundLaunch& a) {
+    const bool pass = ok && (!a.has_where || (x >= a.wmin && x <= a.wmax));  // inclusive both ends, DB.cpp:329
+    const double d = pass ? x - a.fold.shift : 0.0;
+    t.nv += ok ? 1u : 0u;
+    t.n += pass ? 1u : 0u;
+    t.s += d;
+    t.q += d * d;
+}
+
+__device__ __forceinline__ void merge_tile(Acc& acc, const TileAcc& t, bool group_b) {
+    acc.nv += t.nv;
+    acc.na += group_b ? 0u : t.n;
+    acc.nb += group_b ? t.n : 0u;
+    acc.sa += group_b ? 0.0 : t.s;
+    acc.sb += group_b ? t.s : 0.0;
+    acc.qa += group_b ? 0.0 : t.q;
+    acc.qb += group_b ? t.q : 0.0;
 }
 
 // Early-outs every launch of a query shares: should_stop (DB.cpp:930/987) and the top-up gate.
-// Returns false when the whole grid must leave without touching anything.
+// Returns false when the whole grid must leave without sweeping; the query's last launch still
+// finishes the query (one thread) in that case.
 __device__ __forceinline__ bool launch_is_live(const RoundLaunch& a, u64& ord_limit) {
     ord_limit = ~0ull;
+    bool live = true;
     if (a.fold.is_topup) {
         double collected = a.state->n_p;
-        if (!(collected < static_cast<double>(a.fold.base / 4))) return false;  // DB.cpp:1032
-        ord_limit = static_cast<u64>(static_cast<double>(a.fold.base) - collected);  // size() < base, DB.cpp:1037
-        return true;
+        live = collected < static_cast<double>(a.fold.base / 4);  // DB.cpp:1032
+        if (live) ord_limit = static_cast<u64>(static_cast<double>(a.fold.base) - collected);  // DB.cpp:1037
+    } else if (a.check_stop) {
+        live = a.state->stop == 0;
     }
-    return !(a.check_stop && a.state->stop);
+    if (!live && a.fused && a.do_finalize && blockIdx.x == 0 && threadIdx.x == 0) {
+        QueryState st = *a.state;
+        finalize(st, a.fin, a.result);
+    }
+    return live;
 }
 
 // One wave folds one tile (64 * kTileUnroll ordinals of one segment of one family) per iteration.
@@ -211,17 +289,23 @@ __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
         const u64 oi0 = j * kTileOrdinals + lane;
         const bool group_b = F.group != 0;
 
+        // Every load of the tile is issued before the first use.  Out-of-window lanes load row 0 of the
+        // shard instead of branching around the load (a per-element branch would serialise the eight
+        // round trips: cdna_hip_programming.md §5 item 4c).
         double v[kTileUnroll];
         bool ok[kTileUnroll];
 #pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) {  // issue every load of the tile before the first use
+        for (int k = 0; k < kTileUnroll; ++k) {
             const u64 oi = oi0 + static_cast<u64>(k) * 64;
             const u64 o = seg_ord0 + oi;
             ok[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
-            v[k] = ok[k] ? base[oi * step] : 0.0;
+            const double* p = ok[k] ? base + oi * step : a.amount;
+            v[k] = *p;
         }
+        TileAcc ta;
 #pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) accumulate(acc, v[k], ok[k], group_b, a);
+        for (int k = 0; k < kTileUnroll; ++k) accumulate(ta, v[k], ok[k], a);
+        merge_tile(acc, ta, group_b);
     }
     finish_block(acc, a);
 }
@@ -233,77 +317,45 @@ __global__ __launch_bounds__(kBlockThreads) void k_indexed(RoundLaunch a, const 
     Acc acc;
     constexpr u64 kChunk = static_cast<u64>(kBlockThreads) * kTileUnroll;
     for (u64 c0 = static_cast<u64>(blockIdx.x) * kChunk; c0 < n_idx; c0 += static_cast<u64>(gridDim.x) * kChunk) {
-        double v[kTileUnroll];
+        u64 row[kTileUnroll];
         bool ok[kTileUnroll];
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) {
             const u64 i = c0 + threadIdx.x + static_cast<u64>(k) * kBlockThreads;
             ok[k] = i < n_idx;
-            v[k] = ok[k] ? a.amount[idx[i] - a.shard_lo] : 0.0;
+            row[k] = idx[ok[k] ? i : 0];
         }
+        double v[kTileUnroll];
 #pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) accumulate(acc, v[k], ok[k], false, a);
+        for (int k = 0; k < kTileUnroll; ++k) v[k] = a.amount[row[k] - a.shard_lo];
+        TileAcc ta;
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) accumulate(ta, v[k], ok[k], a);
+        merge_tile(acc, ta, false);
     }
     finish_block(acc, a);
 }
 
-__global__ void k_update(QueryState* s, const double* vec, FoldParams p) {
+__global__ void k_update(QueryState* s, const double* vec, FoldParams p, int reset_state) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    QueryState st;
+    if (reset_state) st = QueryState{}; else st = *s;
     if (p.is_topup) {
-        if (!(s->n_p < static_cast<double>(p.base / 4))) return;  // same gate as the top-up launch
-    } else if (s->stop) {
+        if (!(st.n_p < static_cast<double>(p.base / 4))) return;  // same gate as the top-up launch
+    } else if (st.stop) {
         return;  // a round enqueued after the stop never ran: nothing to fold
     }
     double v[kVec];
+#pragma unroll
     for (int k = 0; k < kVec; ++k) v[k] = vec[k];
-    fold(s, v, p);
+    fold(st, v, p);
+    *s = st;
 }
 
 __global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    aqe_result r;
-    const double n = s->n_p, mean = n > 0.0 ? s->mean_p : 0.0, m2 = s->m2_p, visited = s->visited;
-    const double N = static_cast<double>(p.n_global);
-    const double S = n * mean;
-    r.sum = S;
-    r.sumsq = m2 + n * mean * mean;
-    r.mean = mean;
-    r.m2 = m2;
-    r.n = static_cast<uint64_t>(n);
-    r.visited = static_cast<uint64_t>(visited);
-    r.topup = static_cast<uint64_t>(s->topup);
-    r.converged = s->converged;
-    r.rounds = s->rounds;
-    r.kernel_ms = 0.0;
-    r.bytes_algorithmic = r.visited * 8ull;
-
-    double moe = 0.0;  // CLI:279-282: two-pass variance, fixed 1.96
-    if (n > 1.0) moe = 1.96 * sqrt(m2 / (n - 1.0)) / sqrt(n);
-    double value = 0.0, margin = 0.0;
-    {
-        if (p.is_exact) {  // DB.cpp:242-274
-            value = p.agg == AQE_SUM ? S : p.agg == AQE_AVG ? (N > 0.0 ? S / N : 0.0) : (visited > n ? n : N);
-        } else if (p.convention == AQE_EST_CLI) {  // CLI:189-200; interval CLI:284-291
-            const double scale = visited > 0.0 ? N / visited : 0.0;
-            if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
-            else if (p.agg == AQE_COUNT) { value = visited > n ? n * scale : N; }
-            else { value = n > 0.0 ? S / n : 0.0; margin = moe; }
-        } else if (p.convention == AQE_EST_CPP) {  // DB.cpp:303-315; interval scaled as executor.cpp:192-197
-            const double scale = 100.0 / p.pct;
-            if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
-            else if (p.agg == AQE_AVG) { value = N > 0.0 ? S * scale / N : 0.0; margin = moe; }
-            else { value = static_cast<double>(static_cast<uint64_t>(visited * scale)); }
-        } else {  // raw sample aggregate, DB.cpp:2046
-            if (p.agg == AQE_SUM) { value = S; margin = moe * n; }
-            else if (p.agg == AQE_AVG) { value = mean; margin = moe; }
-            else { value = visited; }
-        }
-    }
-    r.value = value;
-    r.margin = margin;
-    r.ci_lower = value - margin;
-    r.ci_upper = value + margin;
-    *out = r;
+    QueryState st = *s;
+    finalize(st, p, out);
 }
 
 // ---- record-returning samplers: gather 32-byte rows ---------------------------------------------
@@ -416,8 +468,8 @@ hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_
     return hipGetLastError();
 }
 
-hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, s, state, vec, p);
+hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, int reset_state, hipStream_t s) {
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, s, state, vec, p, reset_state);
     return hipGetLastError();
 }
 

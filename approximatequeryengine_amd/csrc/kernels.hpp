@@ -51,6 +51,12 @@ struct FoldParams {
     int32_t pad;
 };
 
+struct FinalizeParams {
+    uint64_t n_global;
+    double pct;
+    int32_t agg, convention, is_exact, is_clt;
+};
+
 struct RoundLaunch {
     const double* amount;   // this shard's amount column
     uint64_t shard_lo;
@@ -65,18 +71,16 @@ struct RoundLaunch {
     QueryState* state;
     int32_t fused;          // last arriver folds into state (single-GPU form)
     int32_t check_stop;     // leave at once when state->stop is set
+    int32_t reset_state;    // first launch of a query: fold into a zeroed state (no separate memset)
+    int32_t do_finalize;    // last launch of a query (fused form): the folding thread also writes the result
     FoldParams fold;
-};
-
-struct FinalizeParams {
-    uint64_t n_global;
-    double pct;
-    int32_t agg, convention, is_exact, is_clt;
+    FinalizeParams fin;
+    aqe_result* result;
 };
 
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s);
 hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s);
-hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, hipStream_t s);
+hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, int reset_state, hipStream_t s);
 hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe_result* out, hipStream_t s);
 
 hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFamily* fams, uint32_t nfam,
