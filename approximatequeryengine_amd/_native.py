@@ -19,6 +19,7 @@ SUM, AVG, COUNT = 0, 1, 2
 EST_CLI, EST_CPP, EST_RAW = 0, 1, 2
 Q_NO_TOPUP = 1
 F_TOPUP = 1
+F_PAIR = 2
 STAGE_KEEP_AOS = 1
 MOMENT_VEC = 8
 
@@ -49,7 +50,8 @@ class Result(C.Structure):
 
 class Family(C.Structure):
     _fields_ = [("row0", C.c_uint64), ("pitch", C.c_uint64), ("seg_len", C.c_uint64), ("step", C.c_uint64),
-                ("ord_lo", C.c_uint64), ("ord_hi", C.c_uint64), ("group", C.c_uint32), ("flags", C.c_uint32)]
+                ("ord_lo", C.c_uint64), ("ord_hi", C.c_uint64), ("row0_b", C.c_uint64), ("ord_lo_b", C.c_uint64),
+                ("ord_hi_b", C.c_uint64), ("group", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class TableInfo(C.Structure):

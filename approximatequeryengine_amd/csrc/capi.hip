@@ -140,13 +140,21 @@ void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f,
     DevFamily d{};
     d.row0 = f.row0; d.pitch = f.pitch; d.seg_len = f.seg_len; d.step = f.step;
     d.ord_lo = f.ord_lo; d.ord_hi = f.ord_hi; d.group = f.group; d.flags = f.flags;
-    const uint64_t s_lo = f.ord_lo / f.seg_len, s_hi = (f.ord_hi - 1) / f.seg_len;
+    uint64_t win_lo = f.ord_lo, win_hi = f.ord_hi;  // ordinals the tiles must cover
+    uint64_t size_b = 0;
+    if (f.flags & AQE_F_PAIR) {
+        d.row0_b = f.row0_b; d.ord_lo_b = f.ord_lo_b; d.ord_hi_b = f.ord_hi_b;
+        win_lo = std::min(win_lo, f.ord_lo_b);
+        win_hi = std::max(win_hi, f.ord_hi_b);
+        size_b = f.ord_hi_b - f.ord_lo_b;
+    }
+    const uint64_t s_lo = win_lo / f.seg_len, s_hi = (win_hi - 1) / f.seg_len;
     uint64_t ntiles;
     d.seg_lo = s_lo;
     if (s_lo == s_hi) {
         d.tiles_per_seg = 0;
-        d.j_lo = (f.ord_lo % f.seg_len) / kTileOrdinals;
-        ntiles = ((f.ord_hi - 1) % f.seg_len) / kTileOrdinals + 1 - d.j_lo;
+        d.j_lo = (win_lo % f.seg_len) / kTileOrdinals;
+        ntiles = ((win_hi - 1) % f.seg_len) / kTileOrdinals + 1 - d.j_lo;
     } else {
         d.tiles_per_seg = (f.seg_len + kTileOrdinals - 1) / kTileOrdinals;
         d.j_lo = 0;
@@ -155,9 +163,11 @@ void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f,
     d.tile_begin = L.ntiles;
     d.out_begin = out_pos;
     out_pos += f.ord_hi - f.ord_lo;
+    d.out_begin_b = out_pos;
+    out_pos += size_b;
     L.ntiles += ntiles;
     L.nfam += 1;
-    L.samples += f.ord_hi - f.ord_lo;
+    L.samples += (f.ord_hi - f.ord_lo) + size_b;
     out.push_back(d);
 }
 
@@ -288,9 +298,9 @@ int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     return AQE_OK;
 }
 
-int enqueue_all(aqe_plan* p, hipStream_t s) {
+int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
     aqe_ctx* c = p->ctx;
-    HIPCHK(c, hipEventRecord(p->ev0, s));
+    if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
     p->lev_used = 0;
     if (p->rounds.empty()) {  // nothing to sample (empty table / zero target): a zero state, finalized
         HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
@@ -305,8 +315,8 @@ int enqueue_all(aqe_plan* p, hipStream_t s) {
             if (rc != AQE_OK) return rc;
         }
     }
-    HIPCHK(c, hipEventRecord(p->ev1, s));
-    p->timed = true;
+    if (timed) HIPCHK(c, hipEventRecord(p->ev1, s));
+    p->timed = timed;
     return AQE_OK;
 }
 
@@ -436,8 +446,8 @@ int aqe_create(int device_id, aqe_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "hipSetDevice failed");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "stream creation failed");
     if (hipMalloc(reinterpret_cast<void**>(&c->partials), sizeof(double) * kVec * kMaxBlocks) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->counter), 64) != hipSuccess ||
-        hipMemset(c->counter, 0, 64) != hipSuccess || hipMemset(c->partials, 0, sizeof(double) * kVec * kMaxBlocks) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&c->counter), sizeof(unsigned) * kCounterWords) != hipSuccess ||
+        hipMemset(c->counter, 0, sizeof(unsigned) * kCounterWords) != hipSuccess || hipMemset(c->partials, 0, sizeof(double) * kVec * kMaxBlocks) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "scratch allocation failed");
     *out = c.release();
     return AQE_OK;
@@ -709,7 +719,7 @@ int aqe_plan_enqueue_all(aqe_plan* p, void* stream) {
     int rc = plan_is_current(p);
     if (rc != AQE_OK) return rc;
     HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
-    return enqueue_all(p, pick(p, stream));
+    return enqueue_all(p, pick(p, stream), p->profile);
 }
 
 int aqe_plan_fetch(aqe_plan* p, aqe_result* out, void* stream) {
@@ -775,7 +785,7 @@ int aqe_reduce(aqe_ctx* c, const aqe_query* q, aqe_result* out) {
     aqe_plan* p = nullptr;
     int rc = cached_plan(c, q, &p);
     if (rc != AQE_OK) return rc;
-    rc = enqueue_all(p, c->stream);
+    rc = enqueue_all(p, c->stream, true);
     if (rc != AQE_OK) return rc;
     return fetch(p, out, c->stream);
 }
@@ -795,7 +805,7 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
     uint64_t topup_rows = 0;
     if (p->host.is_clt) {
         aqe_result r;
-        rc = enqueue_all(p, c->stream);
+        rc = enqueue_all(p, c->stream, false);
         if (rc == AQE_OK) rc = fetch(p, &r, c->stream);
         if (rc != AQE_OK) return rc;
         rounds_used = static_cast<uint32_t>(r.rounds);
@@ -825,7 +835,7 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
                                       p->h_fams.begin() + static_cast<long>(p->topup.fam_offset + p->topup.nfam));
             uint64_t pos = total - topup_rows;
             for (auto& f : tf) {
-                f.ord_hi = std::min<uint64_t>(f.ord_hi, topup_rows);
+                f.ord_hi = std::min<uint64_t>(f.ord_hi, std::max<uint64_t>(topup_rows, f.ord_lo));
                 f.out_begin = pos;
                 f.flags = 0;
             }

@@ -196,8 +196,21 @@ __device__ __forceinline__ void finish_block(const Acc& acc, const RoundLaunch& 
 #pragma unroll
         for (int k = 0; k < 7; ++k) __hip_atomic_store(mine + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial is out before the ticket is drawn
-        unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket == gridDim.x - 1);
+        // two-level ticket: shard (blockIdx % kShards), then the top counter
+        const unsigned shards = gridDim.x < static_cast<unsigned>(kShards) ? gridDim.x : static_cast<unsigned>(kShards);
+        const unsigned sh = blockIdx.x % shards;
+        const unsigned members = (gridDim.x - sh + shards - 1) / shards;
+        unsigned* cs = a.counter + static_cast<size_t>(sh) * kShardStride;
+        unsigned* ct = a.counter + static_cast<size_t>(kShards) * kShardStride;
+        int last = 0;
+        if (__hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(cs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
+                __hip_atomic_store(ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -209,10 +222,7 @@ __device__ __forceinline__ void finish_block(const Acc& acc, const RoundLaunch& 
     }
     __syncthreads();  // `red` is reused
     block_sum7(t, red);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fold_and_finish(t, a);
-    }
+    if (threadIdx.x == 0) fold_and_finish(t, a);
 }
 
 // Per-tile accumulator (one pointer group per tile), merged into the lane's two groups with selects:
@@ -287,11 +297,35 @@ __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
         const u64 ord_hi = (F.flags & AQE_F_TOPUP) ? (F.ord_hi < ord_limit ? F.ord_hi : ord_limit) : F.ord_hi;
         const double* base = a.amount + (F.row0 + seg * F.pitch - a.shard_lo);
         const u64 oi0 = j * kTileOrdinals + lane;
-        const bool group_b = F.group != 0;
 
         // Every load of the tile is issued before the first use.  Out-of-window lanes load row 0 of the
         // shard instead of branching around the load (a per-element branch would serialise the eight
         // round trips: cdna_hip_programming.md §5 item 4c).
+        if (F.flags & AQE_F_PAIR) {
+            // fast + slow pointer of one region in one sweep: the two rows of an ordinal sit in the same
+            // or the neighbouring cache line, so the region's lines are fetched once for both groups.
+            const double* base_b = a.amount + (F.row0_b - a.shard_lo);
+            const u64 lo_b = F.ord_lo_b, hi_b = F.ord_hi_b;
+            double va[kTileUnroll], vb[kTileUnroll];
+            bool oka[kTileUnroll], okb[kTileUnroll];
+#pragma unroll
+            for (int k = 0; k < kTileUnroll; ++k) {
+                const u64 o = oi0 + static_cast<u64>(k) * 64;
+                oka[k] = o >= ord_lo && o < ord_hi;
+                okb[k] = o >= lo_b && o < hi_b;
+                const double* pa = oka[k] ? base + o * step : a.amount;
+                const double* pb = okb[k] ? base_b + o * step : a.amount;
+                va[k] = *pa;
+                vb[k] = *pb;
+            }
+            TileAcc ta, tb;
+#pragma unroll
+            for (int k = 0; k < kTileUnroll; ++k) { accumulate(ta, va[k], oka[k], a); accumulate(tb, vb[k], okb[k], a); }
+            merge_tile(acc, ta, false);
+            merge_tile(acc, tb, true);
+            continue;
+        }
+        const bool group_b = F.group != 0;
         double v[kTileUnroll];
         bool ok[kTileUnroll];
 #pragma unroll
@@ -380,6 +414,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __re
         else { seg = F.seg_lo + lt / F.tiles_per_seg; j = lt % F.tiles_per_seg; }
         const u64 seg_ord0 = seg * F.seg_len;
         const u64 row_base = F.row0 + seg * F.pitch - shard_lo;
+        const bool pair = (F.flags & AQE_F_PAIR) != 0;
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) {
             const u64 oi = j * kTileOrdinals + lane + static_cast<u64>(k) * 64;
@@ -387,6 +422,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __re
             if (oi < F.seg_len && o >= F.ord_lo && o < F.ord_hi) {
                 const u64 row = row_base + oi * F.step;
                 const u64 pos = F.out_begin + (o - F.ord_lo);
+                uint4 a = src[2 * row], b = src[2 * row + 1];
+                dst[2 * pos] = a;
+                dst[2 * pos + 1] = b;
+            }
+            if (pair && o >= F.ord_lo_b && o < F.ord_hi_b) {
+                const u64 row = F.row0_b - shard_lo + o * F.step;
+                const u64 pos = F.out_begin_b + (o - F.ord_lo_b);
                 uint4 a = src[2 * row], b = src[2 * row + 1];
                 dst[2 * pos] = a;
                 dst[2 * pos + 1] = b;

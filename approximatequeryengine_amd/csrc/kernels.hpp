@@ -15,6 +15,12 @@ constexpr int kTileUnroll = 8;              // loads in flight per lane
 constexpr int kTileOrdinals = 64 * kTileUnroll;  // ordinals one wave folds per tile
 constexpr int kMaxBlocks = 2048;            // 8 workgroups per CU on 256 CUs
 constexpr int kVec = AQE_MOMENT_VEC;
+// Arrival tickets are sharded: a same-address device atomic costs ~20 ns and serialises, so 2048
+// workgroups on one counter would spend 40 us arriving.  Workgroup b draws from shard b % kShards (each on
+// its own 128-byte line); the last of a shard draws from the top counter.
+constexpr int kShards = 64;
+constexpr int kShardStride = 32;  // u32 words between shard counters (128 B)
+constexpr int kCounterWords = (kShards + 1) * kShardStride;
 
 // A family as the device sees it: the ABI family plus its tile decomposition.
 struct DevFamily {
@@ -25,6 +31,8 @@ struct DevFamily {
     uint64_t tiles_per_seg;  // 0: the window lies in one segment and tile j starts at ordinal (j_lo+j)*tile
     uint64_t j_lo;
     uint64_t out_begin;      // gather: position of ordinal ord_lo in the output
+    uint64_t row0_b, ord_lo_b, ord_hi_b;  // AQE_F_PAIR: the slow pointer sharing this sweep (group 1)
+    uint64_t out_begin_b;
     uint32_t group, flags;
 };
 

@@ -58,12 +58,34 @@ u64 first_ordinal_at_or_after(const aqe_family& f, u64 a, u64 b, u64 row) {
 }
 
 void clip_push(std::vector<aqe_family>& out, aqe_family f, ClipWindow w) {
-    if (f.ord_hi <= f.ord_lo) return;
-    u64 a = first_ordinal_at_or_after(f, f.ord_lo, f.ord_hi, w.lo);
-    u64 b = first_ordinal_at_or_after(f, a, f.ord_hi, w.hi);
-    if (b <= a) return;
+    u64 a = 0, b = 0;
+    if (f.ord_hi > f.ord_lo) {
+        a = first_ordinal_at_or_after(f, f.ord_lo, f.ord_hi, w.lo);
+        b = first_ordinal_at_or_after(f, a, f.ord_hi, w.hi);
+    }
     f.ord_lo = a;
-    f.ord_hi = b;
+    f.ord_hi = b > a ? b : a;
+    if (f.flags & AQE_F_PAIR) {  // second pointer: row_b(o) = row0_b + o*step, single segment
+        aqe_family g = f;
+        g.row0 = f.row0_b; g.ord_lo = f.ord_lo_b; g.ord_hi = f.ord_hi_b; g.pitch = 0;
+        g.seg_len = ~0ull;  // one segment: o / seg_len == 0
+        u64 c = 0, d = 0;
+        if (g.ord_hi > g.ord_lo) {
+            c = first_ordinal_at_or_after(g, g.ord_lo, g.ord_hi, w.lo);
+            d = first_ordinal_at_or_after(g, c, g.ord_hi, w.hi);
+        }
+        f.ord_lo_b = c;
+        f.ord_hi_b = d > c ? d : c;
+        if (f.ord_hi_b <= f.ord_lo_b) {  // only the first pointer has rows here: plain family
+            f.flags &= ~AQE_F_PAIR;
+            f.row0_b = f.ord_lo_b = f.ord_hi_b = 0;
+        } else if (f.ord_hi <= f.ord_lo) {  // only the second pointer: make it the plain family
+            f.row0 = f.row0_b; f.ord_lo = f.ord_lo_b; f.ord_hi = f.ord_hi_b; f.group = 1;
+            f.flags &= ~AQE_F_PAIR;
+            f.row0_b = f.ord_lo_b = f.ord_hi_b = 0;
+        }
+    }
+    if (f.ord_hi <= f.ord_lo) return;
     out.push_back(f);
 }
 
@@ -348,16 +370,36 @@ int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::st
             for (const auto& w : ws) { P.clt.max_count = std::max(P.clt.max_count, w.count); P.global_samples += w.count; }
             u64 R = q.clt_round0 ? q.clt_round0 : static_cast<u64>(q.check_interval);
             u64 g = q.clt_growth ? q.clt_growth : 1;
+            // A fast and a slow pointer that sweep the same region with the same step (the usual case:
+            // equal thread counts, region/(base/F) >= 3) are emitted as ONE pair family so the GPU reads
+            // each cache line of the region once for both.
+            const bool pairable = (F == S);
             u64 b0 = 0;
             while (b0 < P.clt.max_count) {
                 u64 b1 = (R > P.clt.max_count - b0) ? P.clt.max_count : b0 + R;
                 std::vector<aqe_family> rf;
-                for (const auto& w : ws) {
-                    u64 k1 = std::min(b1, w.count);
-                    if (k1 <= b0) continue;
+                auto window = [&](const W& w, u64& lo, u64& hi) { lo = std::min(b0, w.count); hi = std::min(b1, w.count); };
+                for (int t = 0; t < T; ++t) {
+                    const W& w = ws[static_cast<size_t>(t)];
+                    u64 lo, hi;
+                    window(w, lo, hi);
+                    if (pairable && t < F && ws[static_cast<size_t>(F + t)].step == w.step) {
+                        const W& v = ws[static_cast<size_t>(F + t)];
+                        u64 lo2, hi2;
+                        window(v, lo2, hi2);
+                        if (hi <= lo && hi2 <= lo2) continue;
+                        aqe_family f = strided(w.first, w.step, std::max(w.count, v.count), 0);
+                        f.ord_lo = lo; f.ord_hi = hi;
+                        f.flags = AQE_F_PAIR;
+                        f.row0_b = v.first; f.ord_lo_b = lo2; f.ord_hi_b = hi2;
+                        clip_push(rf, f, shard);
+                        continue;
+                    }
+                    if (pairable && t >= F && ws[static_cast<size_t>(t - F)].step == w.step) continue;  // emitted with its fast twin
+                    if (hi <= lo) continue;
                     aqe_family f = strided(w.first, w.step, w.count, w.group);
-                    f.ord_lo = b0;
-                    f.ord_hi = k1;
+                    f.ord_lo = lo;
+                    f.ord_hi = hi;
                     clip_push(rf, f, shard);
                 }
                 P.round_fams.push_back(std::move(rf));

@@ -46,7 +46,11 @@ int random_pointer_indices(uint64_t n_global, double pct, uint32_t seed, ClipWin
                            std::vector<uint64_t>& out, std::string& err);
 
 // total ordinals in a family window
-inline uint64_t family_size(const aqe_family& f) { return f.ord_hi > f.ord_lo ? f.ord_hi - f.ord_lo : 0; }
+inline uint64_t family_size(const aqe_family& f) {
+    uint64_t n = f.ord_hi > f.ord_lo ? f.ord_hi - f.ord_lo : 0;
+    if ((f.flags & AQE_F_PAIR) && f.ord_hi_b > f.ord_lo_b) n += f.ord_hi_b - f.ord_lo_b;
+    return n;
+}
 
 // row of ordinal o
 inline uint64_t family_row(const aqe_family& f, uint64_t o) {

@@ -130,14 +130,19 @@ typedef struct aqe_result {
 } aqe_result;
 
 /* One arithmetic family of sampled rows: row(o) = row0 + (o / seg_len) * pitch + (o % seg_len) * step
- * for ordinals o in [ord_lo, ord_hi).  Every deterministic sampler is a short list of these. */
+ * for ordinals o in [ord_lo, ord_hi).  Every deterministic sampler is a short list of these.
+ * A PAIR family carries a second pointer with the same step over the same rows — the reference's
+ * fast and slow pointer of one region (DB.cpp:925-927 / 983-987) — so one sweep serves both:
+ * row_b(o) = row0_b + o * step for o in [ord_lo_b, ord_hi_b), folded into group 1. */
 typedef struct aqe_family {
     uint64_t row0, pitch, seg_len, step;
     uint64_t ord_lo, ord_hi;
+    uint64_t row0_b, ord_lo_b, ord_hi_b; /* AQE_F_PAIR only */
     uint32_t group; /* 0 = fast pointers / default, 1 = slow pointers */
     uint32_t flags; /* AQE_F_* */
 } aqe_family;
 #define AQE_F_TOPUP 1u /* ord_hi is further limited on the device to base - collected */
+#define AQE_F_PAIR 2u  /* second pointer present (single segment families only) */
 
 typedef struct aqe_table_info {
     uint64_t global_rows, shard_lo, local_rows;
