@@ -18,6 +18,7 @@ M_PARALLEL_POINTER, M_REGION_STRIDE = 12, 13
 SUM, AVG, COUNT = 0, 1, 2
 EST_CLI, EST_CPP, EST_RAW = 0, 1, 2
 Q_NO_TOPUP = 1
+Q_NO_PERSIST = 2
 F_TOPUP = 1
 F_PAIR = 2
 STAGE_KEEP_AOS = 1
@@ -42,6 +43,7 @@ class Result(C.Structure):
         ("sum", C.c_double), ("sumsq", C.c_double), ("mean", C.c_double), ("m2", C.c_double),
         ("n", C.c_uint64), ("visited", C.c_uint64), ("topup", C.c_uint64), ("converged", C.c_int32),
         ("rounds", C.c_int32), ("kernel_ms", C.c_double), ("bytes_algorithmic", C.c_uint64),
+        ("device_status", C.c_int32), ("reserved1", C.c_int32),
     ]
 
     def as_dict(self):

@@ -16,8 +16,8 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libaqe_hip.so"
-SOURCES = [CSRC / "capi.hip", CSRC / "kernels.hip", CSRC / "planner.cpp"]
-HEADERS = [CSRC / "kernels.hpp", CSRC / "planner.hpp", ROOT / "include" / "aqe_hip.h"]
+SOURCES = [CSRC / "capi.hip", CSRC / "kernels.hip", CSRC / "persist.hip", CSRC / "planner.cpp"]
+HEADERS = [CSRC / "kernels.hpp", CSRC / "device_common.hpp", CSRC / "planner.hpp", ROOT / "include" / "aqe_hip.h"]
 ARCH = "gfx950"
 
 

@@ -50,6 +50,11 @@ struct aqe_ctx {
     // scratch shared by every launch of this context (one query in flight per context)
     double* partials = nullptr;
     unsigned* counter = nullptr;
+    // persistent sweep (persist.hip): fixed grid of 2 workgroups per CU, control block, per-round partials
+    unsigned persist_grid = 0;
+    PersistCtl* d_ctl = nullptr;
+    double* d_ppart = nullptr;
+    unsigned long long epoch = 1;
     // prepared plans of aqe_reduce / aqe_gather, keyed by the query bytes
     std::vector<std::pair<aqe_query, aqe_plan*>> cache;
 };
@@ -69,6 +74,14 @@ struct aqe_plan {
     aqe_result* h_result = nullptr;  // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // single-launch form of the rounds (persist.hip), used by the fused single-GPU path when eligible
+    bool persist = false;
+    DevFamily* d_pfams = nullptr;
+    uint32_t p_nfam = 0;
+    uint16_t* d_expected = nullptr;
+    uint64_t p_ntiles = 0;
+    uint64_t p_samples = 0;
+    uint64_t round_begin[kMaxPersistRounds + 1] = {0};
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
     bool profile = false;
     std::vector<hipEvent_t> lev;
@@ -107,6 +120,8 @@ void destroy_plan(aqe_plan* p) {
     if (!p) return;
     if (p->d_fams) (void)hipFree(p->d_fams);
     if (p->d_idx) (void)hipFree(p->d_idx);
+    if (p->d_pfams) (void)hipFree(p->d_pfams);
+    if (p->d_expected) (void)hipFree(p->d_expected);
     if (p->d_state) (void)hipFree(p->d_state);
     if (p->d_result) (void)hipFree(p->d_result);
     if (p->h_result) (void)hipHostFree(p->h_result);
@@ -193,20 +208,28 @@ FinalizeParams finalize_params(const aqe_plan* p) {
     return f;
 }
 
+SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam) {
+    const aqe_ctx* c = p->ctx;
+    SweepCommon s{};
+    s.amount = c->amount;
+    s.shard_lo = c->shard_lo;
+    s.fams = fams;
+    s.nfam = nfam;
+    s.has_where = p->q.has_where ? 1 : 0;
+    s.wmin = p->q.where_min;
+    s.wmax = p->q.where_max;
+    s.shift = c->shift;
+    return s;
+}
+
 // `index` is the launch's position in the query: rounds 0..R-1, then the top-up.  The first launch
 // folds into a zeroed state (no memset), later CLT launches test should_stop on entry, and in the fused
 // single-GPU form the last launch also writes the result.
 RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec) {
     const aqe_ctx* c = p->ctx;
     RoundLaunch a{};
-    a.amount = c->amount;
-    a.shard_lo = c->shard_lo;
-    a.fams = p->d_fams ? p->d_fams + L.fam_offset : nullptr;
-    a.nfam = L.nfam;
+    a.sw = sweep_common(p, p->d_fams ? p->d_fams + L.fam_offset : nullptr, L.nfam);
     a.ntiles = L.ntiles;
-    a.has_where = p->q.has_where ? 1 : 0;
-    a.wmin = p->q.where_min;
-    a.wmax = p->q.where_max;
     a.partials = c->partials;
     a.counter = c->counter;
     a.out_vec = out_vec;
@@ -276,6 +299,50 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         HIPCHK(c, hipMemcpy(p->d_idx, p->host.random_idx.data(), p->host.random_idx.size() * sizeof(uint64_t),
                             hipMemcpyHostToDevice));
     }
+    {   // persistent single-launch form of the rounds
+        const size_t R = p->rounds.size();
+        bool ok = !(q->flags & AQE_Q_NO_PERSIST) && !p->host.is_random && R >= 2 && R <= static_cast<size_t>(kMaxPersistRounds) &&
+                  c->persist_grid > 0 && c->shard_lo == 0 && c->n_local == c->n_global;
+        for (size_t r = 0; ok && r < R; ++r) ok = p->rounds[r].ntiles > 0;
+        if (ok) {
+            std::vector<DevFamily> pf;
+            uint64_t tiles = 0;
+            for (size_t r = 0; r < R; ++r) {
+                const LaunchDesc& L = p->rounds[r];
+                p->round_begin[r] = tiles;
+                for (uint32_t i = 0; i < L.nfam; ++i) {
+                    DevFamily d = p->h_fams[L.fam_offset + i];
+                    d.tile_begin += tiles;
+                    pf.push_back(d);
+                }
+                tiles += L.ntiles;
+                p->p_samples += L.samples;
+            }
+            p->round_begin[R] = tiles;
+            p->p_ntiles = tiles;
+            p->p_nfam = static_cast<uint32_t>(pf.size());
+            const uint64_t G = c->persist_grid, W = G * kWavesPerBlock;
+            auto wave_has = [&](uint64_t w, uint64_t b0, uint64_t b1) {
+                if (b1 <= b0) return false;
+                return b0 + ((w + W - (b0 % W)) % W) < b1;
+            };
+            std::vector<uint16_t> ex(R * (kPersistShards + 1), 0);
+            for (size_t r = 0; r < R; ++r) {
+                uint16_t* e = &ex[r * (kPersistShards + 1)];
+                for (uint64_t b = 0; b < G; ++b) {
+                    bool has = false;
+                    for (uint64_t j = 0; j < kWavesPerBlock; ++j) has = has || wave_has(b * kWavesPerBlock + j, p->round_begin[r], p->round_begin[r + 1]);
+                    if (has) e[b % kPersistShards]++;
+                }
+                for (int s = 0; s < kPersistShards; ++s) if (e[s]) e[kPersistShards]++;
+            }
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_pfams), pf.size() * sizeof(DevFamily)));
+            HIPCHK(c, hipMemcpy(p->d_pfams, pf.data(), pf.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_expected), ex.size() * sizeof(uint16_t)));
+            HIPCHK(c, hipMemcpy(p->d_expected, ex.data(), ex.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            p->persist = true;
+        }
+    }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
     HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_result), sizeof(aqe_result)));
@@ -306,9 +373,29 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
         HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
         HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
     } else {
-        for (uint32_t i = 0; i < p->rounds.size(); ++i) {
-            int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
-            if (rc != AQE_OK) return rc;
+        if (p->persist) {
+            PersistLaunch a{};
+            a.sw = sweep_common(p, p->d_pfams, p->p_nfam);
+            a.ntiles = p->p_ntiles;
+            for (size_t r = 0; r <= p->rounds.size(); ++r) a.round_begin[r] = p->round_begin[r];
+            a.rounds = static_cast<uint32_t>(p->rounds.size());
+            a.epoch = c->epoch++;
+            a.ctl = c->d_ctl;
+            a.partials = c->d_ppart;
+            a.expected = p->d_expected;
+            a.state = p->d_state;
+            a.fold = fold_params(p, false);
+            a.fin = finalize_params(p);
+            a.result = p->d_result;
+            const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
+            if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
+            HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s));
+            if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
+        } else {
+            for (uint32_t i = 0; i < p->rounds.size(); ++i) {
+                int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
+                if (rc != AQE_OK) return rc;
+            }
         }
         if (p->host.has_topup) {
             int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
@@ -325,6 +412,10 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     HIPCHK(c, hipMemcpyAsync(p->h_result, p->d_result, sizeof(aqe_result), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     *out = *p->h_result;
+    if (out->device_status != 0) {  // the round protocol gave up waiting: counters may be left mid-count
+        (void)hipMemset(c->d_ctl, 0, sizeof(PersistCtl));
+        return fail(c, AQE_ERR_HIP, "device-side round protocol timed out");
+    }
     if (p->timed) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) out->kernel_ms = ms;
@@ -449,6 +540,11 @@ int aqe_create(int device_id, aqe_ctx** out) {
         hipMalloc(reinterpret_cast<void**>(&c->counter), sizeof(unsigned) * kCounterWords) != hipSuccess ||
         hipMemset(c->counter, 0, sizeof(unsigned) * kCounterWords) != hipSuccess || hipMemset(c->partials, 0, sizeof(double) * kVec * kMaxBlocks) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "scratch allocation failed");
+    c->persist_grid = static_cast<unsigned>(2 * prop.multiProcessorCount);
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_ctl), sizeof(PersistCtl)) != hipSuccess ||
+        hipMemset(c->d_ctl, 0, sizeof(PersistCtl)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_ppart), sizeof(double) * kVec * c->persist_grid * kMaxPersistRounds) != hipSuccess)
+        return fail(nullptr, AQE_ERR_HIP, "persistent-sweep scratch allocation failed");
     *out = c.release();
     return AQE_OK;
 }
@@ -461,6 +557,8 @@ void aqe_destroy(aqe_ctx* c) {
     free_table(c);
     if (c->partials) (void)hipFree(c->partials);
     if (c->counter) (void)hipFree(c->counter);
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
+    if (c->d_ppart) (void)hipFree(c->d_ppart);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -742,7 +840,7 @@ int aqe_plan_set_profiling(aqe_plan* p, int enable) {
     if (!p) return AQE_ERR_INVALID;
     HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
     p->profile = enable != 0;
-    const size_t want = 2 * (p->rounds.size() + 1);
+    const size_t want = 2 * (p->rounds.size() + 2);
     while (p->profile && p->lev.size() < want) {
         hipEvent_t e;
         HIPCHK(p->ctx, hipEventCreate(&e));
@@ -767,12 +865,15 @@ int aqe_plan_launch_ms(aqe_plan* p, float* ms, uint32_t cap, uint32_t* n_out) {
 
 int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, uint32_t* n_out) {
     if (!p || !n_out) return AQE_ERR_INVALID;
-    const uint32_t n = static_cast<uint32_t>(p->rounds.size()) + (p->host.has_topup ? 1u : 0u);
+    // the fused single-GPU path runs every round in ONE launch when the plan has a persistent form
+    const uint32_t sweeps = p->persist ? 1u : static_cast<uint32_t>(p->rounds.size());
+    const uint32_t n = sweeps + (p->host.has_topup ? 1u : 0u);
     *n_out = n;
     if (!samples) return AQE_OK;
     if (cap < n) return AQE_ERR_CAPACITY;
-    for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
-    if (p->host.has_topup) samples[p->rounds.size()] = p->topup.samples;
+    if (p->persist) samples[0] = p->p_samples;
+    else for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
+    if (p->host.has_topup) samples[sweeps] = p->topup.samples;
     return AQE_OK;
 }
 

@@ -12,128 +12,10 @@
 //   should_stop polling DB.cpp:930, 987                     -> QueryState::stop tested on kernel entry
 //   top-up              DB.cpp:1031-1040                    -> k_round with FoldParams::is_topup
 //   estimators + CI     enhanced_aqe_cli.py:189-200, 277-291; DB.cpp:303-315 -> k_finalize
-#include "kernels.hpp"
+#include "device_common.hpp"
 
 namespace aqe {
 namespace {
-
-typedef unsigned long long u64;
-
-__device__ __forceinline__ u64 uniform64(u64 x) {
-    unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(x));
-    unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(x >> 32));
-    return (static_cast<u64>(hi) << 32) | lo;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;  // valid in lane 0; fixed tree => bitwise reproducible
-}
-
-struct Acc {
-    double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
-    unsigned na = 0, nb = 0, nv = 0;
-};
-
-// Chan/Welford merge of a batch given as shifted sums (n, sum(x-c), sum (x-c)^2) into (n, mean, m2).
-__device__ __forceinline__ void welford_merge(double& n, double& mean, double& m2, double nb, double sd,
-                                              double qd, double c) {
-    if (!(nb > 0.0)) return;
-    double mb = c + sd / nb;
-    double m2b = qd - sd * sd / nb;
-    if (m2b < 0.0) m2b = 0.0;
-    if (!(n > 0.0)) {
-        n = nb; mean = mb; m2 = m2b;
-        return;
-    }
-    double tot = n + nb, delta = mb - mean;
-    mean += delta * (nb / tot);
-    m2 += m2b + delta * delta * (n * nb / tot);
-    n = tot;
-}
-
-// Fold one launch's reduced vector into the query state and take the CLT decision.
-__device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], const FoldParams& p) {
-    if (p.is_topup) {  // DB.cpp:1031-1040: systematic rows appended to the sample
-        welford_merge(s.n_p, s.mean_p, s.m2_p, vec[0], vec[1], vec[2], p.shift);
-        s.topup += vec[0];
-        s.visited += vec[6];
-        return;
-    }
-    welford_merge(s.n_a, s.mean_a, s.m2_a, vec[0], vec[1], vec[2], p.shift);
-    welford_merge(s.n_b, s.mean_b, s.m2_b, vec[3], vec[4], vec[5], p.shift);
-    welford_merge(s.n_p, s.mean_p, s.m2_p, vec[0], vec[1], vec[2], p.shift);
-    welford_merge(s.n_p, s.mean_p, s.m2_p, vec[3], vec[4], vec[5], p.shift);
-    s.visited += vec[6];
-    s.rounds += 1;
-    if (!p.is_clt) return;
-    // rule A, DB.cpp:936-961, on the pooled (all-reduced) moments
-    const double n = s.n_p;
-    if (n >= 30.0) {
-        double var = s.m2_p / (n - 1.0);
-        double se = sqrt(var / n);
-        double err = (p.z * se / s.mean_p) * 100.0;
-        if (err <= p.e && n >= 50.0) {
-            s.converged = 1;
-            s.stop = 1;
-            return;
-        }
-    }
-    // rule B, DB.cpp:993-1016: slow pointers cross-validate the fast pointers' mean
-    if (s.n_b >= 20.0 && s.n_a >= 30.0 && s.mean_a > 0.0) {
-        double diff = fabs(s.mean_b - s.mean_a) / s.mean_a;
-        if (diff <= p.e / 100.0 && s.n_a >= static_cast<double>(p.base / 2)) {
-            s.converged = 2;
-            s.stop = 1;
-        }
-    }
-}
-
-// Estimate + interval from the folded state (CLI:189-200, 277-291; DB.cpp:303-315).
-__device__ __forceinline__ void finalize(const QueryState& s, const FinalizeParams& p, aqe_result* out) {
-    aqe_result r;
-    const double n = s.n_p, mean = n > 0.0 ? s.mean_p : 0.0, m2 = s.m2_p, visited = s.visited;
-    const double N = static_cast<double>(p.n_global);
-    const double S = n * mean;
-    r.sum = S;
-    r.sumsq = m2 + n * mean * mean;
-    r.mean = mean;
-    r.m2 = m2;
-    r.n = static_cast<uint64_t>(n);
-    r.visited = static_cast<uint64_t>(visited);
-    r.topup = static_cast<uint64_t>(s.topup);
-    r.converged = s.converged;
-    r.rounds = s.rounds;
-    r.kernel_ms = 0.0;
-    r.bytes_algorithmic = r.visited * 8ull;
-
-    double moe = 0.0;  // CLI:279-282: two-pass variance, fixed 1.96
-    if (n > 1.0) moe = 1.96 * sqrt(m2 / (n - 1.0)) / sqrt(n);
-    double value = 0.0, margin = 0.0;
-    if (p.is_exact) {  // DB.cpp:242-274
-        value = p.agg == AQE_SUM ? S : p.agg == AQE_AVG ? (N > 0.0 ? S / N : 0.0) : (visited > n ? n : N);
-    } else if (p.convention == AQE_EST_CLI) {  // CLI:189-200; interval CLI:284-291
-        const double scale = visited > 0.0 ? N / visited : 0.0;
-        if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
-        else if (p.agg == AQE_COUNT) { value = visited > n ? n * scale : (visited > 0.0 ? N : 0.0); }
-        else { value = n > 0.0 ? S / n : 0.0; margin = moe; }
-    } else if (p.convention == AQE_EST_CPP) {  // DB.cpp:303-315; interval scaled as executor.cpp:192-197
-        const double scale = 100.0 / p.pct;
-        if (p.agg == AQE_SUM) { value = S * scale; margin = moe * scale; }
-        else if (p.agg == AQE_AVG) { value = N > 0.0 ? S * scale / N : 0.0; margin = moe; }
-        else { value = static_cast<double>(static_cast<uint64_t>(visited * scale)); }
-    } else {  // raw sample aggregate, DB.cpp:2046
-        if (p.agg == AQE_SUM) { value = S; margin = moe * n; }
-        else if (p.agg == AQE_AVG) { value = mean; margin = moe; }
-        else { value = visited; }
-    }
-    r.value = value;
-    r.margin = margin;
-    r.ci_lower = value - margin;
-    r.ci_upper = value + margin;
-    *out = r;
-}
 
 // Sum 7 per-thread values over the workgroup in a fixed order: wave64 shuffle tree, then the four
 // wave results through LDS.  The totals are valid in thread 0.  `red` must be quiescent on entry.
@@ -225,32 +107,6 @@ __device__ __forceinline__ void finish_block(const Acc& acc, const RoundLaunch& 
     if (threadIdx.x == 0) fold_and_finish(t, a);
 }
 
-// Per-tile accumulator (one pointer group per tile), merged into the lane's two groups with selects:
-// a data-dependent choice of WHICH accumulator to update makes hipcc index the struct in scratch.
-struct TileAcc {
-    double s = 0.0, q = 0.0;
-    unsigned n = 0, nv = 0;
-};
-
-__device__ __forceinline__ void accumulate(TileAcc& t, double x, bool ok, const RoundLaunch& a) {
-    const bool pass = ok && (!a.has_where || (x >= a.wmin && x <= a.wmax));  // inclusive both ends, DB.cpp:329
-    const double d = pass ? x - a.fold.shift : 0.0;
-    t.nv += ok ? 1u : 0u;
-    t.n += pass ? 1u : 0u;
-    t.s += d;
-    t.q += d * d;
-}
-
-__device__ __forceinline__ void merge_tile(Acc& acc, const TileAcc& t, bool group_b) {
-    acc.nv += t.nv;
-    acc.na += group_b ? 0u : t.n;
-    acc.nb += group_b ? t.n : 0u;
-    acc.sa += group_b ? 0.0 : t.s;
-    acc.sb += group_b ? t.s : 0.0;
-    acc.qa += group_b ? 0.0 : t.q;
-    acc.qb += group_b ? t.q : 0.0;
-}
-
 // Early-outs every launch of a query shares: should_stop (DB.cpp:930/987) and the top-up gate.
 // Returns false when the whole grid must leave without sweeping; the query's last launch still
 // finishes the query (one thread) in that case.
@@ -279,68 +135,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
     const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
     Acc acc;
-    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) {
-        // wave-uniform tile decode
-        unsigned lo = 0, hi = a.nfam;
-        while (hi - lo > 1) {
-            unsigned mid = (lo + hi) >> 1;
-            if (a.fams[mid].tile_begin <= t) lo = mid; else hi = mid;
-        }
-        const DevFamily& F = a.fams[lo];
-        const u64 lt = t - F.tile_begin;
-        u64 seg, j;
-        if (F.tiles_per_seg == 0) { seg = F.seg_lo; j = F.j_lo + lt; }
-        else { seg = F.seg_lo + lt / F.tiles_per_seg; j = lt % F.tiles_per_seg; }
-        const u64 seg_len = F.seg_len, step = F.step;
-        const u64 seg_ord0 = seg * seg_len;
-        const u64 ord_lo = F.ord_lo;
-        const u64 ord_hi = (F.flags & AQE_F_TOPUP) ? (F.ord_hi < ord_limit ? F.ord_hi : ord_limit) : F.ord_hi;
-        const double* base = a.amount + (F.row0 + seg * F.pitch - a.shard_lo);
-        const u64 oi0 = j * kTileOrdinals + lane;
-
-        // Every load of the tile is issued before the first use.  Out-of-window lanes load row 0 of the
-        // shard instead of branching around the load (a per-element branch would serialise the eight
-        // round trips: cdna_hip_programming.md §5 item 4c).
-        if (F.flags & AQE_F_PAIR) {
-            // fast + slow pointer of one region in one sweep: the two rows of an ordinal sit in the same
-            // or the neighbouring cache line, so the region's lines are fetched once for both groups.
-            const double* base_b = a.amount + (F.row0_b - a.shard_lo);
-            const u64 lo_b = F.ord_lo_b, hi_b = F.ord_hi_b;
-            double va[kTileUnroll], vb[kTileUnroll];
-            bool oka[kTileUnroll], okb[kTileUnroll];
-#pragma unroll
-            for (int k = 0; k < kTileUnroll; ++k) {
-                const u64 o = oi0 + static_cast<u64>(k) * 64;
-                oka[k] = o >= ord_lo && o < ord_hi;
-                okb[k] = o >= lo_b && o < hi_b;
-                const double* pa = oka[k] ? base + o * step : a.amount;
-                const double* pb = okb[k] ? base_b + o * step : a.amount;
-                va[k] = *pa;
-                vb[k] = *pb;
-            }
-            TileAcc ta, tb;
-#pragma unroll
-            for (int k = 0; k < kTileUnroll; ++k) { accumulate(ta, va[k], oka[k], a); accumulate(tb, vb[k], okb[k], a); }
-            merge_tile(acc, ta, false);
-            merge_tile(acc, tb, true);
-            continue;
-        }
-        const bool group_b = F.group != 0;
-        double v[kTileUnroll];
-        bool ok[kTileUnroll];
-#pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) {
-            const u64 oi = oi0 + static_cast<u64>(k) * 64;
-            const u64 o = seg_ord0 + oi;
-            ok[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
-            const double* p = ok[k] ? base + oi * step : a.amount;
-            v[k] = *p;
-        }
-        TileAcc ta;
-#pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) accumulate(ta, v[k], ok[k], a);
-        merge_tile(acc, ta, group_b);
-    }
+    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) sweep_tile(a.sw, t, lane, ord_limit, acc);
     finish_block(acc, a);
 }
 
@@ -361,10 +156,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_indexed(RoundLaunch a, const 
         }
         double v[kTileUnroll];
 #pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) v[k] = a.amount[row[k] - a.shard_lo];
+        for (int k = 0; k < kTileUnroll; ++k) v[k] = a.sw.amount[row[k] - a.sw.shard_lo];
         TileAcc ta;
 #pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) accumulate(ta, v[k], ok[k], a);
+        for (int k = 0; k < kTileUnroll; ++k) accumulate(ta, v[k], ok[k], a.sw);
         merge_tile(acc, ta, false);
     }
     finish_block(acc, a);

@@ -47,7 +47,7 @@ struct QueryState {
     int32_t stop;              // should_stop: set by the CLT rules, read by every later launch
     int32_t converged;         // 0 none, 1 error rule, 2 cross-validation rule
     int32_t rounds;            // rounds folded
-    int32_t pad;
+    int32_t error;             // device protocol error (persistent sweep timed out waiting for a decision)
 };
 
 struct FoldParams {
@@ -65,14 +65,20 @@ struct FinalizeParams {
     int32_t agg, convention, is_exact, is_clt;
 };
 
-struct RoundLaunch {
+// What a tile sweep needs: the column, the family table and the row filter.
+struct SweepCommon {
     const double* amount;   // this shard's amount column
     uint64_t shard_lo;
     const DevFamily* fams;
     uint32_t nfam;
-    uint64_t ntiles;
     int32_t has_where;
     double wmin, wmax;
+    double shift;           // c of the shifted sums
+};
+
+struct RoundLaunch {
+    SweepCommon sw;
+    uint64_t ntiles;
     double* partials;       // [kMaxBlocks][kVec]
     unsigned* counter;      // arrival ticket, zero between launches
     double* out_vec;        // reduced vector of this launch (may be null)
@@ -85,6 +91,38 @@ struct RoundLaunch {
     FinalizeParams fin;
     aqe_result* result;
 };
+
+// ---- persistent single-launch sweep of a multi-round (CLT) query: persist.hip ------------------
+constexpr int kMaxPersistRounds = 32;
+constexpr int kPersistShards = 16;
+constexpr int kCtlStride = 32;  // u32 words between counters (128-byte lines)
+
+// Control block in device memory (zeroed once per context; the protocol leaves every counter at zero).
+struct PersistCtl {
+    unsigned long long dec[kMaxPersistRounds];  // (epoch << 8) | code: 1 continue, 2 stop; one writer per round
+    unsigned long long stop_word;               // (epoch << 8) | 1 once a decider has stopped the query
+    unsigned long long pad[15];
+    unsigned shard_cnt[kMaxPersistRounds][kPersistShards][kCtlStride];
+    unsigned top_cnt[kMaxPersistRounds][kCtlStride];
+};
+
+struct PersistLaunch {
+    SweepCommon sw;            // family table of ALL rounds, tile_begin numbered across the whole launch
+    uint64_t ntiles;
+    uint64_t round_begin[kMaxPersistRounds + 1];  // first tile of each round; [rounds] == ntiles
+    uint32_t rounds;
+    uint32_t pad;
+    unsigned long long epoch;  // distinguishes this launch's decisions from the previous launch's
+    PersistCtl* ctl;
+    double* partials;          // [rounds][gridDim.x][kVec]
+    const uint16_t* expected;  // [rounds][kPersistShards + 1]: participating workgroups per shard, then shards
+    QueryState* state;
+    FoldParams fold;
+    FinalizeParams fin;
+    aqe_result* result;
+};
+
+hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s);
 
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s);
 hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s);

@@ -1,0 +1,222 @@
+// persist.hip — single-launch sweep of a multi-round (CLT) query with device-side early termination.
+//
+// The reference's CLT monitor (custom_bplus_db.cpp:885-1043) lets its fast/slow pointer threads poll an
+// atomic<bool> should_stop on every iteration (DB.cpp:930, 987) while one of them recomputes the running
+// statistics every check_interval samples.  On the GPU a launch costs 3-5 us and a grid-wide barrier 4-10 us,
+// so a launch or a barrier per convergence step would cost more than the whole 10 M-row sweep (12 us).
+// Instead ONE launch sweeps every round speculatively:
+//
+//   * tiles of all rounds form one list in round order; wave w owns tiles w, w+W, w+2W, ...  Waves never
+//     wait for each other: while round r is being decided the chip is already sweeping rounds r+1, r+2...
+//   * when the last wave of a workgroup leaves round r it publishes the workgroup's partial
+//     (n, S-c n, Q) x {fast, slow} with write-through stores and draws a ticket (sharded counters);
+//   * the wave that draws round r's last ticket is its DECIDER: it waits for round r-1's decision (already
+//     under way, never the other way round, so no cycle), sums the partials in workgroup order
+//     (bit-reproducible), folds them into the running Welford state, applies the CLT rules
+//     (DB.cpp:936-961, 993-1016) and publishes continue/stop;
+//   * every wave reads the stop word beside the loads of each tile (an sc1 load in the same vmcnt queue):
+//     after a stop it sweeps nothing more and only hands in its remaining tickets, so every counter is
+//     back at zero when the launch ends;
+//   * the answer is the state after the FIRST round whose pooled moments satisfy the rule — work done
+//     speculatively past that round is discarded, so results do not depend on timing.
+//
+// Hand-offs follow cdna_hip_programming.md Guideline 16 in its all-sc1 form: every shared word is written
+// by ONE lane with 8-byte agent-scope stores, drained (s_waitcnt vmcnt(0)) before the ticket / decision
+// that publishes it, and read with agent-scope loads.  Every spin is bounded.
+#include "device_common.hpp"
+
+namespace aqe {
+namespace {
+
+constexpr unsigned kCodeContinue = 1, kCodeStop = 2;
+#define AQE_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// does wave `w` (of W) own a tile in [b0, b1)?  Its tiles are w, w+W, ...
+__device__ __forceinline__ bool wave_has_tile(u64 w, u64 W, u64 b0, u64 b1) {
+    if (b1 <= b0) return false;
+    const u64 first = b0 + ((w + W - (b0 % W)) % W);
+    return first < b1;
+}
+
+__device__ __forceinline__ bool block_has_tile(u64 b, u64 W, u64 b0, u64 b1) {
+    return wave_has_tile(4 * b, W, b0, b1) || wave_has_tile(4 * b + 1, W, b0, b1) ||
+           wave_has_tile(4 * b + 2, W, b0, b1) || wave_has_tile(4 * b + 3, W, b0, b1);
+}
+
+__device__ __forceinline__ void state_load(QueryState& st, const QueryState* g) {
+    static_assert(sizeof(QueryState) % 8 == 0, "state is moved as 8-byte words");
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(&st);
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(g);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(QueryState) / 8; ++i) d[i] = __hip_atomic_load(s + i, AQE_RLX);
+}
+
+__device__ __forceinline__ void state_store(QueryState* g, const QueryState& st) {
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&st);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(g);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(QueryState) / 8; ++i) __hip_atomic_store(d + i, s[i], AQE_RLX);
+}
+
+// The decider of round r (one whole wave).
+__device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
+    const unsigned long long tag = P.epoch << 8;
+    unsigned prev = kCodeContinue;
+    int timed_out = 0;
+    if (r > 0) {
+        unsigned long long d = 0;
+        unsigned spins = 0;
+        for (;;) {
+            d = __hip_atomic_load(&P.ctl->dec[r - 1], AQE_RLX);
+            if ((d >> 8) == P.epoch) break;
+            if (++spins > (1u << 22)) { timed_out = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        prev = timed_out ? kCodeStop : static_cast<unsigned>(d & 0xff);
+    }
+    if (prev == kCodeStop) {  // the query ended in an earlier round: this round is not folded
+        if (lane == 0) {
+            if (timed_out) {
+                QueryState st;
+                state_load(st, P.state);
+                st.error = 1;
+                state_store(P.state, st);
+                finalize(st, P.fin, P.result);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&P.ctl->stop_word, tag | 1ull, AQE_RLX);
+            }
+            __hip_atomic_store(&P.ctl->dec[r], tag | kCodeStop, AQE_RLX);
+        }
+        return;
+    }
+    // sum the participating workgroups' partials in workgroup order
+    const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
+    const u64 b0 = P.round_begin[r], b1 = P.round_begin[r + 1];
+    const double* part = P.partials + static_cast<size_t>(r) * gridDim.x * kVec;
+    double t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (unsigned b = lane; b < gridDim.x; b += 64) {
+        if (!block_has_tile(b, W, b0, b1)) continue;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t[k] += __hip_atomic_load(part + static_cast<size_t>(b) * kVec + k, AQE_RLX);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) t[k] = wave_sum(t[k]);
+    if (lane == 0) {
+        QueryState st;
+        if (r == 0) st = QueryState{}; else state_load(st, P.state);
+        double vec[kVec];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) vec[k] = t[k];
+        vec[7] = 0.0;
+        fold(st, vec, P.fold);
+        const bool stop = st.stop != 0 || r + 1 == P.rounds;
+        state_store(P.state, st);
+        if (stop) finalize(st, P.fin, P.result);  // the top-up launch, if it runs, rewrites the result
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // state (and result) are out before the decision is
+        if (stop) __hip_atomic_store(&P.ctl->stop_word, tag | 1ull, AQE_RLX);
+        __hip_atomic_store(&P.ctl->dec[r], tag | (stop ? kCodeStop : kCodeContinue), AQE_RLX);
+    }
+}
+
+// Last wave of this workgroup to leave round r: publish the workgroup's partial (unless the round was
+// abandoned after a stop) and draw the workgroup's ticket.
+__device__ __forceinline__ void block_publish(const PersistLaunch& P, unsigned r, int lane, bool with_partial,
+                                              double (*lds_part)[kWavesPerBlock][kVec]) {
+    if (with_partial && lane < 7) {
+        double s = lds_part[r][0][lane];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) s += lds_part[r][w][lane];
+        __hip_atomic_store(P.partials + (static_cast<size_t>(r) * gridDim.x + blockIdx.x) * kVec + lane, s, AQE_RLX);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned decider = 0;
+    if (lane == 0) {
+        const uint16_t* ex = P.expected + static_cast<size_t>(r) * (kPersistShards + 1);
+        const unsigned sh = blockIdx.x % kPersistShards;
+        unsigned* cs = &P.ctl->shard_cnt[r][sh][0];
+        if (__hip_atomic_fetch_add(cs, 1u, AQE_RLX) + 1 == ex[sh]) {
+            __hip_atomic_store(cs, 0u, AQE_RLX);
+            unsigned* ct = &P.ctl->top_cnt[r][0];
+            if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) + 1 == ex[kPersistShards]) {
+                __hip_atomic_store(ct, 0u, AQE_RLX);
+                decider = 1;
+            }
+        }
+    }
+    decider = __builtin_amdgcn_readfirstlane(decider);
+    if (decider) decide_round(P, r, lane);
+}
+
+// A wave leaves round r: hand its sums to the workgroup (LDS) and, if it is the workgroup's last wave in
+// that round, publish.  with_partial=false after a stop: tickets only.
+__device__ __forceinline__ void leave_round(const PersistLaunch& P, unsigned r, const Acc& acc, int lane, unsigned wave,
+                                            bool with_partial, double (*lds_part)[kWavesPerBlock][kVec], unsigned* lds_cnt) {
+    if (with_partial) {
+        double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
+                       static_cast<double>(acc.nv)};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = wave_sum(v[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) lds_part[r][wave][k] = v[k];
+        }
+    }
+    const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
+    const u64 b0 = P.round_begin[r], b1 = P.round_begin[r + 1];
+    unsigned nw = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kWavesPerBlock; ++j) nw += wave_has_tile(static_cast<u64>(blockIdx.x) * kWavesPerBlock + j, W, b0, b1) ? 1u : 0u;
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&lds_cnt[r], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old + 1 == nw) block_publish(P, r, lane, with_partial, lds_part);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P) {
+    __shared__ double lds_part[kMaxPersistRounds][kWavesPerBlock][kVec];
+    __shared__ unsigned lds_cnt[kMaxPersistRounds];
+    for (unsigned i = threadIdx.x; i < kMaxPersistRounds * kWavesPerBlock * kVec; i += kBlockThreads) (&lds_part[0][0][0])[i] = 0.0;
+    if (threadIdx.x < kMaxPersistRounds) lds_cnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = threadIdx.x >> 6;
+    const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
+    const u64 w = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + wave);
+    const unsigned long long stop_tag = (P.epoch << 8) | 1ull;
+
+    Acc acc;
+    unsigned r = 0;
+    bool open = false;     // the wave has swept at least one tile of round r
+    bool stopped = false;
+    u64 t = w;
+    for (; t < P.ntiles; t += W) {
+        while (t >= P.round_begin[r + 1]) {  // tile t belongs to a later round: leave the ones in between
+            if (open) { leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt); acc = Acc{}; open = false; }
+            ++r;
+        }
+        // should_stop (DB.cpp:930/987): one sc1 load issued beside the tile's own loads
+        const unsigned long long sw = __hip_atomic_load(&P.ctl->stop_word, AQE_RLX);
+        sweep_tile(P.sw, t, lane, ~0ull, acc);
+        open = true;
+        if (sw == stop_tag) { stopped = true; break; }
+    }
+    if (!stopped) {
+        if (open) leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt);
+        return;
+    }
+    // A stop was published (necessarily for a round before r): hand in the tickets of round r and of every
+    // later round this wave owns tiles in, sweeping nothing, so that all counters return to zero.
+    leave_round(P, r, acc, lane, wave, false, lds_part, lds_cnt);
+    for (unsigned q = r + 1; q < P.rounds; ++q)
+        if (wave_has_tile(w, W, P.round_begin[q], P.round_begin[q + 1])) leave_round(P, q, acc, lane, wave, false, lds_part, lds_cnt);
+}
+
+}  // namespace
+
+hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kBlockThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace aqe

@@ -172,9 +172,10 @@ def main():
             lat.append(time.perf_counter() - t1)
         lat.sort()
 
-    launches = len(samples)
-    avg_launch_ms = sum(sum_ms) / prof_steps / launches
-    visited_local = sum(samples[:-1]) if plan.has_topup else sum(samples)  # the top-up never fires here
+    sweeps = len(samples) - (1 if plan.has_topup else 0)  # the top-up launch never fires here: not a sweep
+    launches = sweeps
+    avg_launch_ms = sum(sum_ms[:sweeps]) / prof_steps / launches
+    visited_local = sum(samples[:sweeps])
     bytes_per_launch = 8.0 * visited_local / launches
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     per_launch = [{"samples": int(s), "avg_us": 1e3 * m / prof_steps,
@@ -196,7 +197,7 @@ def main():
                             "should_stop armed on every launch), table resident in HBM",
                 "rows_per_gpu": rows, "global_rows": n_global, "sample_percent": pct, "error_percent": e,
                 "pointers": 4 * world, "samples_per_query_per_gpu": int(last.visited if world == 1 else visited_local),
-                "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_query": launches + 1,
+                "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_query": len(samples),
                 "collectives_per_query": (launches if world > 1 else 0),
                 "unit_definition": "one 10M-row region aggregate per GPU per query; a global query over N regions counts N",
             },
@@ -206,12 +207,12 @@ def main():
                        "converged": int(last.converged), "rounds": int(last.rounds),
                        "same_as_first": bool(first.value == last.value)},
             "roofline": {
-                "bound": "hbm", "kernel": "k_round", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_sweep_persist" if world == 1 else "k_round", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms,
                 "launches_per_query": launches, "per_launch": per_launch,
-                "note": "8 B per sampled row (SoA f64 amount column) / mean k_round duration from per-launch HIP "
-                        "event pairs; traffic (FETCH_SIZE) is in profiles/",
+                "note": "8 B per sampled row (SoA f64 amount column) / mean sweep-kernel duration from per-launch HIP "
+                        "event pairs on the launch stream; the top-up launch (a no-op here) is excluded",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

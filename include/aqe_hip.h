@@ -108,7 +108,8 @@ typedef struct aqe_query {
                                  reference's stale-cache quirk DB.cpp:188-191 is not reproduced)  */
 } aqe_query;
 
-#define AQE_Q_NO_TOPUP 1u /* CLT: skip the systematic top-up of DB.cpp:1031-1040 */
+#define AQE_Q_NO_TOPUP 1u   /* CLT: skip the systematic top-up of DB.cpp:1031-1040 */
+#define AQE_Q_NO_PERSIST 2u /* run every round as its own launch even on one GPU (same results) */
 
 /* Everything a caller of the reference computes from a sample, produced on the device. */
 typedef struct aqe_result {
@@ -127,6 +128,8 @@ typedef struct aqe_result {
     int32_t rounds;    /* CLT: rounds folded before the stop                                 */
     double kernel_ms;  /* device time of this query's kernels (events on the query stream)   */
     uint64_t bytes_algorithmic; /* 8 B per visited sample (SoA amount column)                 */
+    int32_t device_status; /* 0 ok; nonzero: the device-side round protocol reported an error   */
+    int32_t reserved1;
 } aqe_result;
 
 /* One arithmetic family of sampled rows: row(o) = row0 + (o / seg_len) * pitch + (o % seg_len) * step

@@ -169,6 +169,11 @@ CLT_CASES = [
     (10_000, 33.3, 0.95, 10, 2, 5.0, 10, 1),
     (10_000, 100.0, 0.95, 10, 4, 0.0, 7, 1),
     (10_000, 20.0, 0.95, 10, 1, 2.0, 10, 1),       # T=1: no fast pointer at all
+    (1_000_000, 20.0, 0.95, 10, 4, 1.0, 4096, 4),  # the bench schedule, early stop
+    (1_000_000, 20.0, 0.95, 10, 4, 0.0, 4096, 4),  # the bench schedule, full sweep
+    (1_000_000, 10.0, 0.95, 10, 8, 0.3, 16, 2),    # 15 rounds, stops in the middle, rounds abandoned
+    (1_000_000, 20.0, 0.95, 10, 5, 0.2, 100, 3),   # odd thread count: fast and slow regions differ (no pairs)
+    (100_007, 20.0, 0.95, 10, 64, 1.0, 8, 2),      # 64 pointers
 ]
 
 
@@ -181,7 +186,13 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     assert rc == 0
     q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=conf, check_interval=ci,
                    num_threads=T, max_error_percent=e, clt_round0=R0, clt_growth=g)
+    # the same query as one launch per round: must agree with the single persistent launch bit for bit
+    q.flags = nat.Q_NO_PERSIST
+    multi = eng.reduce(q)
+    q.flags = 0
     res = eng.reduce(q)
+    assert (res.n, res.sum, res.sumsq, res.value, res.ci_lower, res.converged, res.rounds, res.topup) == \
+        (multi.n, multi.sum, multi.sumsq, multi.value, multi.ci_lower, multi.converged, multi.rounds, multi.topup)
     assert res.converged == want.converged, (res.converged, want.converged)
     assert res.rounds == want.rounds
     assert res.topup == want.topup
@@ -275,6 +286,26 @@ def test_numerical_stability_large_offset(nat, oracle):
         assert rel(r.m2, m.m2) <= 1e-6
         moe, lo, hi = oracle.ci_cli(nat.AVG, n, m.n, m.m2, m.sum / m.n)
         assert rel(r.ci_upper - r.ci_lower, hi - lo) <= 1e-6
+
+
+def test_persistent_sweep_stress_alternating_queries(nat, oracle, table, engines):
+    """Back-to-back persistent launches with different round counts, early stops and full sweeps: every
+    result must equal its first execution (tickets return to zero, epochs separate launches)."""
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(1_000_000)
+    qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=r0, clt_growth=g, num_threads=T)
+          for e, r0, g, T in ((1.0, 4096, 4, 4), (0.0, 4096, 4, 4), (0.3, 16, 2, 8), (5.0, 64, 2, 4), (0.05, 1024, 2, 6),
+                              (2.0, 8, 2, 2), (0.0, 100_000, 2, 4))]
+    first = [eng.reduce(q) for q in qs]
+    for rep in range(15):
+        for q, f in zip(qs, first):
+            r = eng.reduce(q)
+            assert r.device_status == 0
+            assert (r.n, r.sum, r.sumsq, r.converged, r.rounds, r.topup, r.value) == \
+                (f.n, f.sum, f.sumsq, f.converged, f.rounds, f.topup, f.value), (rep, q.max_error_percent)
+    # a non-CLT query in between uses the ordinary launch and must not disturb anything
+    assert eng.reduce(make_query(nat.M_BLOCK, 5.0)).n == 50_000
+    assert eng.reduce(qs[0]).sum == first[0].sum
 
 
 def test_run_to_run_bitwise_reproducible(nat, engines):
