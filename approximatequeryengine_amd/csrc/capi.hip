@@ -54,6 +54,7 @@ struct aqe_ctx {
     unsigned persist_grid = 0;
     PersistCtl* d_ctl = nullptr;
     double* d_ppart = nullptr;
+    double* d_spart = nullptr;
     unsigned long long epoch = 1;
     // prepared plans of aqe_reduce / aqe_gather, keyed by the query bytes
     std::vector<std::pair<aqe_query, aqe_plan*>> cache;
@@ -322,10 +323,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             p->p_ntiles = tiles;
             p->p_nfam = static_cast<uint32_t>(pf.size());
             const uint64_t G = c->persist_grid, W = G * kWavesPerBlock;
-            auto wave_has = [&](uint64_t w, uint64_t b0, uint64_t b1) {
-                if (b1 <= b0) return false;
-                return b0 + ((w + W - (b0 % W)) % W) < b1;
-            };
+            auto wave_has = [&](uint64_t w, uint64_t b0, uint64_t b1) { return b0 + ((w - b0) & (W - 1)) < b1; };
             std::vector<uint16_t> ex(R * (kPersistShards + 1), 0);
             for (size_t r = 0; r < R; ++r) {
                 uint16_t* e = &ex[r * (kPersistShards + 1)];
@@ -382,6 +380,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             a.epoch = c->epoch++;
             a.ctl = c->d_ctl;
             a.partials = c->d_ppart;
+            a.shard_partials = c->d_spart;
             a.expected = p->d_expected;
             a.state = p->d_state;
             a.fold = fold_params(p, false);
@@ -540,10 +539,15 @@ int aqe_create(int device_id, aqe_ctx** out) {
         hipMalloc(reinterpret_cast<void**>(&c->counter), sizeof(unsigned) * kCounterWords) != hipSuccess ||
         hipMemset(c->counter, 0, sizeof(unsigned) * kCounterWords) != hipSuccess || hipMemset(c->partials, 0, sizeof(double) * kVec * kMaxBlocks) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "scratch allocation failed");
-    c->persist_grid = static_cast<unsigned>(2 * prop.multiProcessorCount);
+    // 2 workgroups per CU, rounded down to a power of two (the wave->tile map uses masks), at most 1024
+    c->persist_grid = 16;
+    while (c->persist_grid * 2 <= static_cast<unsigned>(2 * prop.multiProcessorCount) && c->persist_grid < 1024) c->persist_grid *= 2;
     if (hipMalloc(reinterpret_cast<void**>(&c->d_ctl), sizeof(PersistCtl)) != hipSuccess ||
         hipMemset(c->d_ctl, 0, sizeof(PersistCtl)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_ppart), sizeof(double) * kVec * c->persist_grid * kMaxPersistRounds) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&c->d_ppart), sizeof(double) * kVec * c->persist_grid * kMaxPersistRounds) != hipSuccess ||
+        hipMemset(c->d_ppart, 0, sizeof(double) * kVec * c->persist_grid * kMaxPersistRounds) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_spart), sizeof(double) * kVec * kPersistShards * kMaxPersistRounds) != hipSuccess ||
+        hipMemset(c->d_spart, 0, sizeof(double) * kVec * kPersistShards * kMaxPersistRounds) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "persistent-sweep scratch allocation failed");
     *out = c.release();
     return AQE_OK;
@@ -559,6 +563,7 @@ void aqe_destroy(aqe_ctx* c) {
     if (c->counter) (void)hipFree(c->counter);
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->d_ppart) (void)hipFree(c->d_ppart);
+    if (c->d_spart) (void)hipFree(c->d_spart);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

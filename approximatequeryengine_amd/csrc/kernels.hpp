@@ -115,6 +115,7 @@ struct PersistLaunch {
     unsigned long long epoch;  // distinguishes this launch's decisions from the previous launch's
     PersistCtl* ctl;
     double* partials;          // [rounds][gridDim.x][kVec]
+    double* shard_partials;    // [rounds][kPersistShards][kVec]
     const uint16_t* expected;  // [rounds][kPersistShards + 1]: participating workgroups per shard, then shards
     QueryState* state;
     FoldParams fold;

@@ -31,10 +31,9 @@ namespace {
 constexpr unsigned kCodeContinue = 1, kCodeStop = 2;
 #define AQE_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-// does wave `w` (of W) own a tile in [b0, b1)?  Its tiles are w, w+W, ...
+// does wave `w` (of W, a power of two) own a tile in [b0, b1)?  Its tiles are w, w+W, ...
 __device__ __forceinline__ bool wave_has_tile(u64 w, u64 W, u64 b0, u64 b1) {
-    if (b1 <= b0) return false;
-    const u64 first = b0 + ((w + W - (b0 % W)) % W);
+    const u64 first = b0 + ((w - b0) & (W - 1));  // smallest t >= b0 with t = w (mod W)
     return first < b1;
 }
 
@@ -58,9 +57,28 @@ __device__ __forceinline__ void state_store(QueryState* g, const QueryState& st)
     for (unsigned i = 0; i < sizeof(QueryState) / 8; ++i) __hip_atomic_store(d + i, s[i], AQE_RLX);
 }
 
-// The decider of round r (one whole wave).
+// xor-butterfly over the lanes that share (lane & 7): every lane ends with the sum of its 8-lane class.
+__device__ __forceinline__ double class_sum8(double v) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+constexpr int kMaxBlocksPerShard = 64;  // persist_grid <= 1024
+
+// The decider of round r (one whole wave): sums the 16 shard partials, folds, decides.
 __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
     const unsigned long long tag = P.epoch << 8;
+    // This round's shard partials do not depend on the previous decision: fetch them before waiting.
+    // lane -> value k = lane & 7 (k = 7 idle) of shards j and j + 8, j = lane >> 3.
+    const int k = lane & 7, j = lane >> 3;
+    const uint16_t* ex = P.expected + static_cast<size_t>(r) * (kPersistShards + 1);
+    const double* sp = P.shard_partials + static_cast<size_t>(r) * kPersistShards * kVec;
+    const bool use0 = k < 7 && ex[j] != 0, use1 = k < 7 && ex[j + 8] != 0;
+    const double x0 = __hip_atomic_load(sp + (use0 ? j * kVec + k : 0), AQE_RLX);
+    const double x1 = __hip_atomic_load(sp + (use1 ? (j + 8) * kVec + k : 0), AQE_RLX);
+
     unsigned prev = kCodeContinue;
     int timed_out = 0;
     if (r > 0) {
@@ -89,25 +107,15 @@ __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
         }
         return;
     }
-    // sum the participating workgroups' partials in workgroup order
-    const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
-    const u64 b0 = P.round_begin[r], b1 = P.round_begin[r + 1];
-    const double* part = P.partials + static_cast<size_t>(r) * gridDim.x * kVec;
-    double t[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (unsigned b = lane; b < gridDim.x; b += 64) {
-        if (!block_has_tile(b, W, b0, b1)) continue;
+    // shards in ascending order within a lane (j, then j + 8), then the fixed butterfly over j
+    const double tot = class_sum8((use0 ? x0 : 0.0) + (use1 ? x1 : 0.0));
+    double vec[kVec];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) t[k] += __hip_atomic_load(part + static_cast<size_t>(b) * kVec + k, AQE_RLX);
-    }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) t[k] = wave_sum(t[k]);
+    for (int q = 0; q < 7; ++q) vec[q] = __shfl(tot, q, 64);
+    vec[7] = 0.0;
     if (lane == 0) {
         QueryState st;
         if (r == 0) st = QueryState{}; else state_load(st, P.state);
-        double vec[kVec];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) vec[k] = t[k];
-        vec[7] = 0.0;
         fold(st, vec, P.fold);
         const bool stop = st.stop != 0 || r + 1 == P.rounds;
         state_store(P.state, st);
@@ -118,8 +126,34 @@ __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
     }
 }
 
+// Last workgroup of shard `sh` to arrive in round r: sum the shard's workgroup partials (workgroups
+// sh, sh+16, ... that own tiles of the round) in ascending workgroup order and publish ONE shard partial.
+__device__ __forceinline__ void shard_reduce(const PersistLaunch& P, unsigned r, unsigned sh, int lane) {
+    const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
+    const u64 b0 = P.round_begin[r], b1 = P.round_begin[r + 1];
+    const unsigned per_shard = gridDim.x / kPersistShards;
+    const double* part = P.partials + static_cast<size_t>(r) * gridDim.x * kVec;
+    const int k = lane & 7, j = lane >> 3;
+    double x[kMaxBlocksPerShard / 8];
+    bool use[kMaxBlocksPerShard / 8];
+#pragma unroll
+    for (int i = 0; i < kMaxBlocksPerShard / 8; ++i) {  // member index m = j + 8 i, workgroup b = sh + 16 m
+        const unsigned m = static_cast<unsigned>(j + 8 * i);
+        const unsigned b = sh + kPersistShards * m;
+        use[i] = k < 7 && m < per_shard && block_has_tile(b, W, b0, b1);
+        x[i] = __hip_atomic_load(part + (use[i] ? static_cast<size_t>(b) * kVec + k : 0), AQE_RLX);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kMaxBlocksPerShard / 8; ++i) s += use[i] ? x[i] : 0.0;
+    s = class_sum8(s);
+    if (lane < 7) __hip_atomic_store(P.shard_partials + (static_cast<size_t>(r) * kPersistShards + sh) * kVec + lane, s, AQE_RLX);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Last wave of this workgroup to leave round r: publish the workgroup's partial (unless the round was
-// abandoned after a stop) and draw the workgroup's ticket.
+// abandoned after a stop) and draw the workgroup's ticket; the shard's last workgroup reduces the shard
+// and draws the shard's ticket; the last shard decides.
 __device__ __forceinline__ void block_publish(const PersistLaunch& P, unsigned r, int lane, bool with_partial,
                                               double (*lds_part)[kWavesPerBlock][kVec]) {
     if (with_partial && lane < 7) {
@@ -129,22 +163,27 @@ __device__ __forceinline__ void block_publish(const PersistLaunch& P, unsigned r
         __hip_atomic_store(P.partials + (static_cast<size_t>(r) * gridDim.x + blockIdx.x) * kVec + lane, s, AQE_RLX);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned decider = 0;
+    const uint16_t* ex = P.expected + static_cast<size_t>(r) * (kPersistShards + 1);
+    const unsigned sh = blockIdx.x % kPersistShards;
+    unsigned shard_last = 0;
     if (lane == 0) {
-        const uint16_t* ex = P.expected + static_cast<size_t>(r) * (kPersistShards + 1);
-        const unsigned sh = blockIdx.x % kPersistShards;
         unsigned* cs = &P.ctl->shard_cnt[r][sh][0];
         if (__hip_atomic_fetch_add(cs, 1u, AQE_RLX) + 1 == ex[sh]) {
             __hip_atomic_store(cs, 0u, AQE_RLX);
-            unsigned* ct = &P.ctl->top_cnt[r][0];
-            if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) + 1 == ex[kPersistShards]) {
-                __hip_atomic_store(ct, 0u, AQE_RLX);
-                decider = 1;
-            }
+            shard_last = 1;
         }
     }
-    decider = __builtin_amdgcn_readfirstlane(decider);
-    if (decider) decide_round(P, r, lane);
+    if (!__builtin_amdgcn_readfirstlane(shard_last)) return;
+    if (with_partial) shard_reduce(P, r, sh, lane);  // an abandoned round is never folded: tickets only
+    unsigned decider = 0;
+    if (lane == 0) {
+        unsigned* ct = &P.ctl->top_cnt[r][0];
+        if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) + 1 == ex[kPersistShards]) {
+            __hip_atomic_store(ct, 0u, AQE_RLX);
+            decider = 1;
+        }
+    }
+    if (__builtin_amdgcn_readfirstlane(decider)) decide_round(P, r, lane);
 }
 
 // A wave leaves round r: hand its sums to the workgroup (LDS) and, if it is the workgroup's last wave in
