@@ -67,62 +67,70 @@ __device__ __forceinline__ double class_sum8(double v) {
 
 constexpr int kMaxBlocksPerShard = 64;  // persist_grid <= 1024
 
-// The decider of round r (one whole wave): sums the 16 shard partials, folds, decides.
+// The decider of round r (one whole wave).  Deciders do not chain: each one announces that its round's
+// shard partials are complete, waits until every earlier round has announced the same, and then replays
+// the folds of rounds 0..r from the shard partials itself (the decision is a pure function of them).
+// Exactly one decider finds that ITS round is the first to satisfy the stop rule (or is the last round):
+// that one writes the state and the result and raises should_stop.  All others have nothing to publish.
 __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
     const unsigned long long tag = P.epoch << 8;
-    // This round's shard partials do not depend on the previous decision: fetch them before waiting.
-    // lane -> value k = lane & 7 (k = 7 idle) of shards j and j + 8, j = lane >> 3.
-    const int k = lane & 7, j = lane >> 3;
-    const uint16_t* ex = P.expected + static_cast<size_t>(r) * (kPersistShards + 1);
-    const double* sp = P.shard_partials + static_cast<size_t>(r) * kPersistShards * kVec;
-    const bool use0 = k < 7 && ex[j] != 0, use1 = k < 7 && ex[j + 8] != 0;
-    const double x0 = __hip_atomic_load(sp + (use0 ? j * kVec + k : 0), AQE_RLX);
-    const double x1 = __hip_atomic_load(sp + (use1 ? (j + 8) * kVec + k : 0), AQE_RLX);
-
-    unsigned prev = kCodeContinue;
+    if (lane == 0) __hip_atomic_store(&P.ctl->dec[r], tag | kCodeContinue, AQE_RLX);  // "round r is complete"
+    // wait for rounds 0..r-1 (lane q watches round q); leave early if an earlier round already stopped
+    bool abandoned = false;
     int timed_out = 0;
-    if (r > 0) {
-        unsigned long long d = 0;
-        unsigned spins = 0;
-        for (;;) {
-            d = __hip_atomic_load(&P.ctl->dec[r - 1], AQE_RLX);
-            if ((d >> 8) == P.epoch) break;
-            if (++spins > (1u << 22)) { timed_out = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        prev = timed_out ? kCodeStop : static_cast<unsigned>(d & 0xff);
+    for (unsigned spins = 0;; ++spins) {
+        const bool mine = static_cast<unsigned>(lane) < r;
+        const unsigned long long d = __hip_atomic_load(&P.ctl->dec[mine ? lane : r], AQE_RLX);
+        const unsigned long long sw = __hip_atomic_load(&P.ctl->stop_word, AQE_RLX);
+        if (sw == (tag | 1ull)) { abandoned = true; break; }
+        if (__all(!mine || (d >> 8) == P.epoch)) break;
+        if (spins > (1u << 22)) { timed_out = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
     }
-    if (prev == kCodeStop) {  // the query ended in an earlier round: this round is not folded
-        if (lane == 0) {
-            if (timed_out) {
-                QueryState st;
-                state_load(st, P.state);
-                st.error = 1;
-                state_store(P.state, st);
-                finalize(st, P.fin, P.result);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&P.ctl->stop_word, tag | 1ull, AQE_RLX);
-            }
-            __hip_atomic_store(&P.ctl->dec[r], tag | kCodeStop, AQE_RLX);
-        }
-        return;
-    }
-    // shards in ascending order within a lane (j, then j + 8), then the fixed butterfly over j
-    const double tot = class_sum8((use0 ? x0 : 0.0) + (use1 ? x1 : 0.0));
-    double vec[kVec];
+    if (abandoned) return;
+    // replay: lane -> value k = lane & 7 (k = 7 idle) of shards j and j + 8, j = lane >> 3
+    const int k = lane & 7, j = lane >> 3;
+    QueryState st{};
+    bool stop = false;
+    if (!timed_out) {
+        for (unsigned q0 = 0; q0 <= r && !stop; q0 += 4) {  // four rounds of loads in flight at a time
+            double x0[4], x1[4];
+            bool u0[4], u1[4];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) vec[q] = __shfl(tot, q, 64);
-    vec[7] = 0.0;
+            for (unsigned i = 0; i < 4; ++i) {
+                const unsigned q = q0 + i <= r ? q0 + i : r;
+                const uint16_t* ex = P.expected + static_cast<size_t>(q) * (kPersistShards + 1);
+                const double* sp = P.shard_partials + static_cast<size_t>(q) * kPersistShards * kVec;
+                u0[i] = k < 7 && ex[j] != 0;
+                u1[i] = k < 7 && ex[j + 8] != 0;
+                x0[i] = __hip_atomic_load(sp + (u0[i] ? j * kVec + k : 0), AQE_RLX);
+                x1[i] = __hip_atomic_load(sp + (u1[i] ? (j + 8) * kVec + k : 0), AQE_RLX);
+            }
+#pragma unroll
+            for (unsigned i = 0; i < 4; ++i) {
+                // shards in ascending order within a lane (j, then j + 8), then the fixed butterfly over j
+                const double tot = class_sum8((u0[i] ? x0[i] : 0.0) + (u1[i] ? x1[i] : 0.0));
+                double vec[kVec];
+#pragma unroll
+                for (int c = 0; c < 7; ++c) vec[c] = __shfl(tot, c, 64);
+                vec[7] = 0.0;
+                if (q0 + i <= r && !stop) {  // wave-uniform
+                    fold(st, vec, P.fold);
+                    stop = st.stop != 0;
+                    if (stop && q0 + i < r) return;  // an earlier round ends the query: its decider reports it
+                }
+            }
+        }
+    } else {
+        st.error = 1;
+    }
+    stop = stop || timed_out || r + 1 == P.rounds;
+    if (!stop) return;
     if (lane == 0) {
-        QueryState st;
-        if (r == 0) st = QueryState{}; else state_load(st, P.state);
-        fold(st, vec, P.fold);
-        const bool stop = st.stop != 0 || r + 1 == P.rounds;
         state_store(P.state, st);
-        if (stop) finalize(st, P.fin, P.result);  // the top-up launch, if it runs, rewrites the result
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // state (and result) are out before the decision is
-        if (stop) __hip_atomic_store(&P.ctl->stop_word, tag | 1ull, AQE_RLX);
-        __hip_atomic_store(&P.ctl->dec[r], tag | (stop ? kCodeStop : kCodeContinue), AQE_RLX);
+        finalize(st, P.fin, P.result);  // the top-up launch, if it runs, rewrites the result
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&P.ctl->stop_word, tag | 1ull, AQE_RLX);
     }
 }
 
