@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -55,6 +56,7 @@ struct aqe_ctx {
     PersistCtl* d_ctl = nullptr;
     double* d_ppart = nullptr;
     double* d_spart = nullptr;
+    unsigned long long* d_stamps = nullptr;  // diagnostics (env AQE_PERSIST_STAMPS)
     unsigned long long epoch = 1;
     // prepared plans of aqe_reduce / aqe_gather, keyed by the query bytes
     std::vector<std::pair<aqe_query, aqe_plan*>> cache;
@@ -102,6 +104,16 @@ int fail(aqe_ctx* c, int code, const std::string& msg) {
         if (e__ != hipSuccess)                                                                     \
             return fail(ctx, AQE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
     } while (0)
+
+// Shift c of the shifted moments: the mean of the table's first rows (up to 1024), so that one outlying
+// first row cannot push c outside the data's range.  Every shard of a table must use the same value.
+constexpr uint64_t kShiftRows = 1024;
+double shift_of_rows(const aqe_record* rows, uint64_t n) {
+    const uint64_t m = std::min<uint64_t>(n, kShiftRows);
+    double s = 0.0;
+    for (uint64_t i = 0; i < m; ++i) s += rows[i].amount;
+    return m ? s / static_cast<double>(m) : 0.0;
+}
 
 void free_table(aqe_ctx* c) {
     if (c->owns_table) {
@@ -202,6 +214,7 @@ FinalizeParams finalize_params(const aqe_plan* p) {
     FinalizeParams f{};
     f.n_global = p->ctx->n_global;
     f.pct = p->q.sample_percent;
+    f.shift = p->ctx->shift;
     f.agg = p->q.agg;
     f.convention = p->q.convention;
     f.is_exact = p->q.method == AQE_M_EXACT;
@@ -386,6 +399,11 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             a.fold = fold_params(p, false);
             a.fin = finalize_params(p);
             a.result = p->d_result;
+            a.stamps = c->d_stamps;
+            if (c->d_stamps) {
+                HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kWavesPerBlock + 8 * kMaxPersistRounds), s));
+                HIPCHK(c, hipStreamSynchronize(s));
+            }
             const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
             if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
             HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s));
@@ -411,6 +429,29 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     HIPCHK(c, hipMemcpyAsync(p->h_result, p->d_result, sizeof(aqe_result), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     *out = *p->h_result;
+    if (c->d_stamps && p->persist) {
+        const size_t W = static_cast<size_t>(c->persist_grid) * kWavesPerBlock;
+        std::vector<unsigned long long> st(8 * W + 8 * kMaxPersistRounds);
+        (void)hipMemcpy(st.data(), c->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = std::fopen(std::getenv("AQE_PERSIST_STAMPS"), "a")) {
+            unsigned long long t0 = ~0ull, s_hi = 0, f_lo = ~0ull, f_hi = 0, l_hi = 0, e_hi = 0;
+            for (size_t w = 0; w < W; ++w) {
+                const unsigned long long* q = &st[8 * w];
+                if (q[0]) { t0 = std::min(t0, q[0]); s_hi = std::max(s_hi, q[0]); }
+                if (q[1]) { f_lo = std::min(f_lo, q[1]); f_hi = std::max(f_hi, q[1]); }
+                l_hi = std::max(l_hi, q[2]);
+                e_hi = std::max(e_hi, q[3]);
+            }
+            auto us = [&](unsigned long long v) { return v == 0 || v == ~0ull ? -1.0 : (static_cast<double>(v) - static_cast<double>(t0)) / 100.0; };
+            std::fprintf(f, "starts ..%.2f first-tile %.2f..%.2f last-tile %.2f end %.2f |", us(s_hi), us(f_lo), us(f_hi), us(l_hi), us(e_hi));
+            for (size_t r = 0; r < p->rounds.size(); ++r) {
+                const unsigned long long* q = &st[8 * W + 8 * r];
+                std::fprintf(f, " r%zu: shard %.2f chosen %.2f waited %.2f done %.2f |", r, us(q[2]), us(q[3]), us(q[4]), us(q[5]));
+            }
+            std::fprintf(f, "\n");
+            std::fclose(f);
+        }
+    }
     if (out->device_status != 0) {  // the round protocol gave up waiting: counters may be left mid-count
         (void)hipMemset(c->d_ctl, 0, sizeof(PersistCtl));
         return fail(c, AQE_ERR_HIP, "device-side round protocol timed out");
@@ -433,7 +474,7 @@ int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64
     c->shard_lo = shard_lo;
     c->n_local = n_local;
     c->staged = true;
-    c->shift = n_local ? rows[0].amount : 0.0;  // callers sharding a table overwrite this (aqe_set_shift)
+    c->shift = shift_of_rows(rows, n_local);  // shards other than the first are given the table's value (aqe_set_shift)
     if (n_local == 0) return AQE_OK;
     // Double-buffered pinned bounce: the CPU fills buffer b while the DMA engine drains buffer b^1.
     // Without KEEP_AOS only the amount column crosses PCIe (8 of every 32 bytes).
@@ -539,9 +580,9 @@ int aqe_create(int device_id, aqe_ctx** out) {
         hipMalloc(reinterpret_cast<void**>(&c->counter), sizeof(unsigned) * kCounterWords) != hipSuccess ||
         hipMemset(c->counter, 0, sizeof(unsigned) * kCounterWords) != hipSuccess || hipMemset(c->partials, 0, sizeof(double) * kVec * kMaxBlocks) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "scratch allocation failed");
-    // 2 workgroups per CU, rounded down to a power of two (the wave->tile map uses masks), at most 1024
+    // 4 workgroups per CU, rounded down to a power of two (the wave->tile map uses masks), at most 1024
     c->persist_grid = 16;
-    while (c->persist_grid * 2 <= static_cast<unsigned>(2 * prop.multiProcessorCount) && c->persist_grid < 1024) c->persist_grid *= 2;
+    while (c->persist_grid * 2 <= static_cast<unsigned>(4 * prop.multiProcessorCount) && c->persist_grid < 1024) c->persist_grid *= 2;
     if (hipMalloc(reinterpret_cast<void**>(&c->d_ctl), sizeof(PersistCtl)) != hipSuccess ||
         hipMemset(c->d_ctl, 0, sizeof(PersistCtl)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_ppart), sizeof(double) * kVec * c->persist_grid * kMaxPersistRounds) != hipSuccess ||
@@ -549,6 +590,9 @@ int aqe_create(int device_id, aqe_ctx** out) {
         hipMalloc(reinterpret_cast<void**>(&c->d_spart), sizeof(double) * kVec * kPersistShards * kMaxPersistRounds) != hipSuccess ||
         hipMemset(c->d_spart, 0, sizeof(double) * kVec * kPersistShards * kMaxPersistRounds) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "persistent-sweep scratch allocation failed");
+    if (std::getenv("AQE_PERSIST_STAMPS") &&
+        hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 8 * (8 * static_cast<size_t>(c->persist_grid) * kWavesPerBlock + 8 * kMaxPersistRounds)) != hipSuccess)
+        return fail(nullptr, AQE_ERR_HIP, "stamp buffer allocation failed");
     *out = c.release();
     return AQE_OK;
 }
@@ -564,6 +608,7 @@ void aqe_destroy(aqe_ctx* c) {
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->d_ppart) (void)hipFree(c->d_ppart);
     if (c->d_spart) (void)hipFree(c->d_spart);
+    if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -599,7 +644,7 @@ int aqe_stage_file(aqe_ctx* c, const char* path, uint64_t shard_lo, uint64_t n_l
     (void)madvise(mf.base, mf.bytes, MADV_SEQUENTIAL);
     const aqe_record* rows = reinterpret_cast<const aqe_record*>(static_cast<const char*>(mf.base) + 24);
     rc = stage_from_host(c, rows + shard_lo, n_local, shard_lo, count, flags);
-    if (rc == AQE_OK && count) c->shift = rows[0].amount;  // global row 0: identical on every shard
+    if (rc == AQE_OK && count) c->shift = shift_of_rows(rows, count);  // from the table's head: identical on every shard
     return rc;
 }
 
@@ -634,12 +679,17 @@ int aqe_generate_synthetic(aqe_ctx* c, uint64_t n_local, uint64_t shard_lo, uint
     c->shard_lo = shard_lo;
     c->n_local = n_local;
     c->staged = true;
-    {   // amount of global row 0, the same expression the kernel evaluates
-        uint64_t z = seed + 0x9E3779B97F4A7C15ULL;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-        z ^= z >> 31;
-        c->shift = 1.0 + 999.0 * (static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0));
+    {   // shift from the table's first rows, evaluated with the expression the kernel uses (every shard agrees)
+        const uint64_t m = std::min<uint64_t>(n_global, kShiftRows);
+        double acc = 0.0;
+        for (uint64_t i = 0; i < m; ++i) {
+            uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            acc += 1.0 + 999.0 * (static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0));
+        }
+        c->shift = m ? acc / static_cast<double>(m) : 0.0;
     }
     HIPCHK(c, launch_synth(c->aos, c->amount, n_local, shard_lo, seed, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -33,44 +33,39 @@ struct Acc {
     unsigned na = 0, nb = 0, nv = 0;
 };
 
-// Chan/Welford merge of a batch given as shifted sums (n, sum(x-c), sum (x-c)^2) into (n, mean, m2).
-__device__ __forceinline__ void welford_merge(double& n, double& mean, double& m2, double nb, double sd,
-                                              double qd, double c) {
-    if (!(nb > 0.0)) return;
-    double mb = c + sd / nb;
-    double m2b = qd - sd * sd / nb;
-    if (m2b < 0.0) m2b = 0.0;
-    if (!(n > 0.0)) {
-        n = nb; mean = mb; m2 = m2b;
-        return;
-    }
-    double tot = n + nb, delta = mb - mean;
-    mean += delta * (nb / tot);
-    m2 += m2b + delta * delta * (n * nb / tot);
-    n = tot;
+// mean and centred second moment of a group from its shifted sums (n, S_d = sum(x-c), Q_d = sum (x-c)^2):
+// mean = c + S_d/n, M2 = Q_d - S_d^2/n.  With c inside the data's range the subtraction is benign; this is
+// the shifted-data form of the running mean/variance (Chan, Golub & LeVeque 1983), and unlike Welford's
+// recurrence its partial states merge by plain addition — which is what lets workgroups, rounds and GPUs
+// (one all-reduce SUM) combine in any grouping.
+__device__ __forceinline__ void mean_m2(double n, double sd, double qd, double c, double& mean, double& m2) {
+    mean = c + sd / n;
+    m2 = qd - sd * sd / n;
+    if (m2 < 0.0) m2 = 0.0;
 }
 
 // Fold one launch's reduced vector into the query state and take the CLT decision.
 __device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], const FoldParams& p) {
     if (p.is_topup) {  // DB.cpp:1031-1040: systematic rows appended to the sample
-        welford_merge(s.n_p, s.mean_p, s.m2_p, vec[0], vec[1], vec[2], p.shift);
+        s.n_p += vec[0]; s.sd_p += vec[1]; s.qd_p += vec[2];
         s.topup += vec[0];
         s.visited += vec[6];
         return;
     }
-    welford_merge(s.n_a, s.mean_a, s.m2_a, vec[0], vec[1], vec[2], p.shift);
-    welford_merge(s.n_b, s.mean_b, s.m2_b, vec[3], vec[4], vec[5], p.shift);
-    welford_merge(s.n_p, s.mean_p, s.m2_p, vec[0], vec[1], vec[2], p.shift);
-    welford_merge(s.n_p, s.mean_p, s.m2_p, vec[3], vec[4], vec[5], p.shift);
+    s.n_a += vec[0]; s.sd_a += vec[1]; s.qd_a += vec[2];
+    s.n_b += vec[3]; s.sd_b += vec[4]; s.qd_b += vec[5];
+    s.n_p += vec[0] + vec[3]; s.sd_p += vec[1] + vec[4]; s.qd_p += vec[2] + vec[5];
     s.visited += vec[6];
     s.rounds += 1;
     if (!p.is_clt) return;
     // rule A, DB.cpp:936-961, on the pooled (all-reduced) moments
     const double n = s.n_p;
     if (n >= 30.0) {
-        double var = s.m2_p / (n - 1.0);
+        double mean, m2;
+        mean_m2(n, s.sd_p, s.qd_p, p.shift, mean, m2);
+        double var = m2 / (n - 1.0);
         double se = sqrt(var / n);
-        double err = (p.z * se / s.mean_p) * 100.0;
+        double err = (p.z * se / mean) * 100.0;
         if (err <= p.e && n >= 50.0) {
             s.converged = 1;
             s.stop = 1;
@@ -78,11 +73,14 @@ __device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], c
         }
     }
     // rule B, DB.cpp:993-1016: slow pointers cross-validate the fast pointers' mean
-    if (s.n_b >= 20.0 && s.n_a >= 30.0 && s.mean_a > 0.0) {
-        double diff = fabs(s.mean_b - s.mean_a) / s.mean_a;
-        if (diff <= p.e / 100.0 && s.n_a >= static_cast<double>(p.base / 2)) {
-            s.converged = 2;
-            s.stop = 1;
+    if (s.n_b >= 20.0 && s.n_a >= 30.0) {
+        const double mean_a = p.shift + s.sd_a / s.n_a, mean_b = p.shift + s.sd_b / s.n_b;
+        if (mean_a > 0.0) {
+            double diff = fabs(mean_b - mean_a) / mean_a;
+            if (diff <= p.e / 100.0 && s.n_a >= static_cast<double>(p.base / 2)) {
+                s.converged = 2;
+                s.stop = 1;
+            }
         }
     }
 }
@@ -90,11 +88,13 @@ __device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], c
 // Estimate + interval from the folded state (CLI:189-200, 277-291; DB.cpp:303-315).
 __device__ __forceinline__ void finalize(const QueryState& s, const FinalizeParams& p, aqe_result* out) {
     aqe_result r;
-    const double n = s.n_p, mean = n > 0.0 ? s.mean_p : 0.0, m2 = s.m2_p, visited = s.visited;
+    const double n = s.n_p, visited = s.visited, c = p.shift;
+    double mean = 0.0, m2 = 0.0;
+    if (n > 0.0) mean_m2(n, s.sd_p, s.qd_p, c, mean, m2);
     const double N = static_cast<double>(p.n_global);
-    const double S = n * mean;
+    const double S = s.sd_p + n * c;
     r.sum = S;
-    r.sumsq = m2 + n * mean * mean;
+    r.sumsq = s.qd_p + 2.0 * c * s.sd_p + n * c * c;
     r.mean = mean;
     r.m2 = m2;
     r.n = static_cast<uint64_t>(n);
@@ -160,18 +160,31 @@ __device__ __forceinline__ void merge_tile(Acc& acc, const TileAcc& t, bool grou
     acc.qb += group_b ? t.q : 0.0;
 }
 
+// Family tables are tiny (1-64 entries) and every tile decode walks them: keep a copy in LDS so the
+// decode costs LDS reads instead of a chain of dependent global loads.  Returns the table to use.
+constexpr unsigned kMaxLdsFams = 64;
+__device__ __forceinline__ const DevFamily* stage_families(const SweepCommon& a, DevFamily* lds) {
+    if (a.nfam > kMaxLdsFams) return a.fams;
+    constexpr unsigned kWords = sizeof(DevFamily) / 8;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.fams);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(lds);
+    for (unsigned i = threadIdx.x; i < a.nfam * kWords; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return lds;
+}
+
 // One wave folds tile `t` of the launch's family table: 64 * kTileUnroll ordinals of one segment of one
 // family (both pointers of a PAIR family).  All indices are wave-uniform except the lane's ordinal.
 // Every load of the tile is issued before the first use; out-of-window lanes load row 0 of the shard
 // instead of branching around the load (a per-element branch would serialise the round trips:
 // cdna_hip_programming.md §5 item 4c).
-__device__ __forceinline__ void sweep_tile(const SweepCommon& a, u64 t, int lane, u64 ord_limit, Acc& acc) {
+__device__ __forceinline__ void sweep_tile(const SweepCommon& a, const DevFamily* fams, u64 t, int lane, u64 ord_limit, Acc& acc) {
     unsigned lo = 0, hi = a.nfam;
     while (hi - lo > 1) {
         unsigned mid = (lo + hi) >> 1;
-        if (a.fams[mid].tile_begin <= t) lo = mid; else hi = mid;
+        if (fams[mid].tile_begin <= t) lo = mid; else hi = mid;
     }
-    const DevFamily& F = a.fams[lo];
+    const DevFamily& F = fams[lo];
     const u64 lt = t - F.tile_begin;
     u64 seg, j;
     if (F.tiles_per_seg == 0) { seg = F.seg_lo; j = F.j_lo + lt; }

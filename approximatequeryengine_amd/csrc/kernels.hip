@@ -129,13 +129,15 @@ __device__ __forceinline__ bool launch_is_live(const RoundLaunch& a, u64& ord_li
 
 // One wave folds one tile (64 * kTileUnroll ordinals of one segment of one family) per iteration.
 __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
+    __shared__ DevFamily lds_fams[kMaxLdsFams];
     u64 ord_limit;
     if (!launch_is_live(a, ord_limit)) return;
+    const DevFamily* fams = stage_families(a.sw, lds_fams);
     const int lane = threadIdx.x & 63;
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
     const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
     Acc acc;
-    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) sweep_tile(a.sw, t, lane, ord_limit, acc);
+    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) sweep_tile(a.sw, fams, t, lane, ord_limit, acc);
     finish_block(acc, a);
 }
 

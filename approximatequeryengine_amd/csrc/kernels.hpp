@@ -36,12 +36,13 @@ struct DevFamily {
     uint32_t group, flags;
 };
 
-// Running state of one query on the device: Welford triples folded round by round, the CLT
+// Running state of one query on the device: moment triples folded round by round, the CLT
 // decision, and the should_stop flag later launches test on entry.
 struct QueryState {
-    double n_a, mean_a, m2_a;  // group a: fast pointers (or every sample of a non-CLT query)
-    double n_b, mean_b, m2_b;  // group b: slow pointers
-    double n_p, mean_p, m2_p;  // pooled a+b, plus the top-up
+    // shifted sums (n, sum(x-c), sum (x-c)^2): additive, so folds are exact re-groupings
+    double n_a, sd_a, qd_a;    // group a: fast pointers (or every sample of a non-CLT query)
+    double n_b, sd_b, qd_b;    // group b: slow pointers
+    double n_p, sd_p, qd_p;    // pooled a+b, plus the top-up
     double visited;            // samples drawn (>= n_p when a WHERE filter drops some)
     double topup;              // rows added by the top-up
     int32_t stop;              // should_stop: set by the CLT rules, read by every later launch
@@ -62,6 +63,7 @@ struct FoldParams {
 struct FinalizeParams {
     uint64_t n_global;
     double pct;
+    double shift;
     int32_t agg, convention, is_exact, is_clt;
 };
 
@@ -121,6 +123,7 @@ struct PersistLaunch {
     FoldParams fold;
     FinalizeParams fin;
     aqe_result* result;
+    unsigned long long* stamps;  // diagnostics only (AQE_PERSIST_STAMPS): s_memrealtime marks, else null
 };
 
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s);

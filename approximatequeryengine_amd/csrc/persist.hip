@@ -31,6 +31,24 @@ namespace {
 constexpr unsigned kCodeContinue = 1, kCodeStop = 2;
 #define AQE_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// Diagnostics: with a stamp buffer attached, every wave marks its own slots with plain stores (no
+// contention), in 100 MHz s_memrealtime ticks.  Layout: [wave][8] then, per round r, [8] decider slots.
+// wave slots: 0 start, 1 first tile swept, 2 last tile swept, 3 end; round slots: 3 decider chosen,
+// 4 decider past its wait, 5 decider done, 2 (max over shards) shard reduce done.
+__device__ __forceinline__ void stamp_wave(const PersistLaunch& P, unsigned slot, int lane) {
+    if (P.stamps && lane == 0) {
+        const u64 w = static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+        P.stamps[w * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+__device__ __forceinline__ void stamp_max(const PersistLaunch& P, unsigned slot, int lane) {
+    if (P.stamps && lane == 0) {
+        const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
+        atomicMax(P.stamps + W * 8 + (slot - 8), __builtin_amdgcn_s_memrealtime());
+    }
+}
+__device__ __forceinline__ void stamp_min(const PersistLaunch&, unsigned, int) {}
+
 // does wave `w` (of W, a power of two) own a tile in [b0, b1)?  Its tiles are w, w+W, ...
 __device__ __forceinline__ bool wave_has_tile(u64 w, u64 W, u64 b0, u64 b1) {
     const u64 first = b0 + ((w - b0) & (W - 1));  // smallest t >= b0 with t = w (mod W)
@@ -74,6 +92,7 @@ constexpr int kMaxBlocksPerShard = 64;  // persist_grid <= 1024
 // that one writes the state and the result and raises should_stop.  All others have nothing to publish.
 __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
     const unsigned long long tag = P.epoch << 8;
+    stamp_max(P, 8 + 8 * r + 3, lane);
     if (lane == 0) __hip_atomic_store(&P.ctl->dec[r], tag | kCodeContinue, AQE_RLX);  // "round r is complete"
     // wait for rounds 0..r-1 (lane q watches round q); leave early if an earlier round already stopped
     bool abandoned = false;
@@ -88,6 +107,7 @@ __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
         __builtin_amdgcn_s_sleep(1);
     }
     if (abandoned) return;
+    stamp_max(P, 8 + 8 * r + 4, lane);
     // replay: lane -> value k = lane & 7 (k = 7 idle) of shards j and j + 8, j = lane >> 3
     const int k = lane & 7, j = lane >> 3;
     QueryState st{};
@@ -132,6 +152,7 @@ __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&P.ctl->stop_word, tag | 1ull, AQE_RLX);
     }
+    stamp_max(P, 8 + 8 * r + 5, lane);
 }
 
 // Last workgroup of shard `sh` to arrive in round r: sum the shard's workgroup partials (workgroups
@@ -183,6 +204,7 @@ __device__ __forceinline__ void block_publish(const PersistLaunch& P, unsigned r
     }
     if (!__builtin_amdgcn_readfirstlane(shard_last)) return;
     if (with_partial) shard_reduce(P, r, sh, lane);  // an abandoned round is never folded: tickets only
+    stamp_max(P, 8 + 8 * r + 2, lane);
     unsigned decider = 0;
     if (lane == 0) {
         unsigned* ct = &P.ctl->top_cnt[r][0];
@@ -222,8 +244,10 @@ __device__ __forceinline__ void leave_round(const PersistLaunch& P, unsigned r, 
 __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P) {
     __shared__ double lds_part[kMaxPersistRounds][kWavesPerBlock][kVec];
     __shared__ unsigned lds_cnt[kMaxPersistRounds];
+    __shared__ DevFamily lds_fams[kMaxLdsFams];
     for (unsigned i = threadIdx.x; i < kMaxPersistRounds * kWavesPerBlock * kVec; i += kBlockThreads) (&lds_part[0][0][0])[i] = 0.0;
     if (threadIdx.x < kMaxPersistRounds) lds_cnt[threadIdx.x] = 0;
+    const DevFamily* fams = stage_families(P.sw, lds_fams);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -231,6 +255,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P
     const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
     const u64 w = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + wave);
     const unsigned long long stop_tag = (P.epoch << 8) | 1ull;
+    stamp_wave(P, 0, lane);
 
     Acc acc;
     unsigned r = 0;
@@ -244,12 +269,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P
         }
         // should_stop (DB.cpp:930/987): one sc1 load issued beside the tile's own loads
         const unsigned long long sw = __hip_atomic_load(&P.ctl->stop_word, AQE_RLX);
-        sweep_tile(P.sw, t, lane, ~0ull, acc);
+        sweep_tile(P.sw, fams, t, lane, ~0ull, acc);
+        if (t == w) stamp_wave(P, 1, lane);
         open = true;
         if (sw == stop_tag) { stopped = true; break; }
     }
     if (!stopped) {
+        stamp_wave(P, 2, lane);
         if (open) leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt);
+        stamp_wave(P, 3, lane);
         return;
     }
     // A stop was published (necessarily for a round before r): hand in the tickets of round r and of every
@@ -257,6 +285,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P
     leave_round(P, r, acc, lane, wave, false, lds_part, lds_cnt);
     for (unsigned q = r + 1; q < P.rounds; ++q)
         if (wave_has_tile(w, W, P.round_begin[q], P.round_begin[q + 1])) leave_round(P, q, acc, lane, wave, false, lds_part, lds_cnt);
+    stamp_wave(P, 3, lane);
 }
 
 }  // namespace

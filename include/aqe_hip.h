@@ -149,7 +149,7 @@ typedef struct aqe_family {
 
 typedef struct aqe_table_info {
     uint64_t global_rows, shard_lo, local_rows;
-    double shift;        /* c of the shifted moments (amount of global row 0 unless set)     */
+    double shift;        /* c of the shifted moments (mean of the table's first <=1024 rows unless set) */
     int32_t has_aos;     /* 32-byte rows resident (record-returning samplers available)      */
     int32_t device_id;
     uint64_t hbm_bytes;  /* bytes this context holds in HBM                                  */
