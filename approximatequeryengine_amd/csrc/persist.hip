@@ -28,7 +28,7 @@
 namespace aqe {
 namespace {
 
-constexpr unsigned kCodeContinue = 1, kCodeStop = 2;
+constexpr unsigned kCodeContinue = 1;
 #define AQE_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // Diagnostics: with a stamp buffer attached, every wave marks its own slots with plain stores (no
@@ -90,7 +90,7 @@ constexpr int kMaxBlocksPerShard = 64;  // persist_grid <= 1024
 // the folds of rounds 0..r from the shard partials itself (the decision is a pure function of them).
 // Exactly one decider finds that ITS round is the first to satisfy the stop rule (or is the last round):
 // that one writes the state and the result and raises should_stop.  All others have nothing to publish.
-__device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
+__device__ void decide_round(const PersistLaunch& P, unsigned r, int lane, const uint16_t* lds_ex) {
     const unsigned long long tag = P.epoch << 8;
     stamp_max(P, 8 + 8 * r + 3, lane);
     if (lane == 0) __hip_atomic_store(&P.ctl->dec[r], tag | kCodeContinue, AQE_RLX);  // "round r is complete"
@@ -113,13 +113,13 @@ __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
     QueryState st{};
     bool stop = false;
     if (!timed_out) {
-        for (unsigned q0 = 0; q0 <= r && !stop; q0 += 4) {  // four rounds of loads in flight at a time
-            double x0[4], x1[4];
-            bool u0[4], u1[4];
+        for (unsigned q0 = 0; q0 <= r && !stop; q0 += 8) {  // eight rounds of loads in flight at a time
+            double x0[8], x1[8];
+            bool u0[8], u1[8];
 #pragma unroll
-            for (unsigned i = 0; i < 4; ++i) {
+            for (unsigned i = 0; i < 8; ++i) {
                 const unsigned q = q0 + i <= r ? q0 + i : r;
-                const uint16_t* ex = P.expected + static_cast<size_t>(q) * (kPersistShards + 1);
+                const uint16_t* ex = lds_ex + static_cast<size_t>(q) * (kPersistShards + 1);
                 const double* sp = P.shard_partials + static_cast<size_t>(q) * kPersistShards * kVec;
                 u0[i] = k < 7 && ex[j] != 0;
                 u1[i] = k < 7 && ex[j + 8] != 0;
@@ -127,7 +127,7 @@ __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane) {
                 x1[i] = __hip_atomic_load(sp + (u1[i] ? (j + 8) * kVec + k : 0), AQE_RLX);
             }
 #pragma unroll
-            for (unsigned i = 0; i < 4; ++i) {
+            for (unsigned i = 0; i < 8; ++i) {
                 // shards in ascending order within a lane (j, then j + 8), then the fixed butterfly over j
                 const double tot = class_sum8((u0[i] ? x0[i] : 0.0) + (u1[i] ? x1[i] : 0.0));
                 double vec[kVec];
@@ -184,7 +184,7 @@ __device__ __forceinline__ void shard_reduce(const PersistLaunch& P, unsigned r,
 // abandoned after a stop) and draw the workgroup's ticket; the shard's last workgroup reduces the shard
 // and draws the shard's ticket; the last shard decides.
 __device__ __forceinline__ void block_publish(const PersistLaunch& P, unsigned r, int lane, bool with_partial,
-                                              double (*lds_part)[kWavesPerBlock][kVec]) {
+                                              double (*lds_part)[kWavesPerBlock][kVec], const uint16_t* lds_ex) {
     if (with_partial && lane < 7) {
         double s = lds_part[r][0][lane];
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ __forceinline__ void block_publish(const PersistLaunch& P, unsigned r
         __hip_atomic_store(P.partials + (static_cast<size_t>(r) * gridDim.x + blockIdx.x) * kVec + lane, s, AQE_RLX);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint16_t* ex = P.expected + static_cast<size_t>(r) * (kPersistShards + 1);
+    const uint16_t* ex = lds_ex + static_cast<size_t>(r) * (kPersistShards + 1);
     const unsigned sh = blockIdx.x % kPersistShards;
     unsigned shard_last = 0;
     if (lane == 0) {
@@ -213,13 +213,14 @@ __device__ __forceinline__ void block_publish(const PersistLaunch& P, unsigned r
             decider = 1;
         }
     }
-    if (__builtin_amdgcn_readfirstlane(decider)) decide_round(P, r, lane);
+    if (__builtin_amdgcn_readfirstlane(decider)) decide_round(P, r, lane, lds_ex);
 }
 
 // A wave leaves round r: hand its sums to the workgroup (LDS) and, if it is the workgroup's last wave in
 // that round, publish.  with_partial=false after a stop: tickets only.
 __device__ __forceinline__ void leave_round(const PersistLaunch& P, unsigned r, const Acc& acc, int lane, unsigned wave,
-                                            bool with_partial, double (*lds_part)[kWavesPerBlock][kVec], unsigned* lds_cnt) {
+                                            bool with_partial, double (*lds_part)[kWavesPerBlock][kVec], unsigned* lds_cnt,
+                                            const uint16_t* lds_ex) {
     if (with_partial) {
         double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
                        static_cast<double>(acc.nv)};
@@ -238,13 +239,15 @@ __device__ __forceinline__ void leave_round(const PersistLaunch& P, unsigned r, 
     unsigned old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(&lds_cnt[r], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
-    if (old + 1 == nw) block_publish(P, r, lane, with_partial, lds_part);
+    if (old + 1 == nw) block_publish(P, r, lane, with_partial, lds_part, lds_ex);
 }
 
 __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P) {
     __shared__ double lds_part[kMaxPersistRounds][kWavesPerBlock][kVec];
     __shared__ unsigned lds_cnt[kMaxPersistRounds];
     __shared__ DevFamily lds_fams[kMaxLdsFams];
+    __shared__ uint16_t lds_ex[kMaxPersistRounds * (kPersistShards + 1)];
+    for (unsigned i = threadIdx.x; i < P.rounds * (kPersistShards + 1); i += kBlockThreads) lds_ex[i] = P.expected[i];
     for (unsigned i = threadIdx.x; i < kMaxPersistRounds * kWavesPerBlock * kVec; i += kBlockThreads) (&lds_part[0][0][0])[i] = 0.0;
     if (threadIdx.x < kMaxPersistRounds) lds_cnt[threadIdx.x] = 0;
     const DevFamily* fams = stage_families(P.sw, lds_fams);
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P
     u64 t = w;
     for (; t < P.ntiles; t += W) {
         while (t >= P.round_begin[r + 1]) {  // tile t belongs to a later round: leave the ones in between
-            if (open) { leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt); acc = Acc{}; open = false; }
+            if (open) { leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt, lds_ex); acc = Acc{}; open = false; }
             ++r;
         }
         // should_stop (DB.cpp:930/987): one sc1 load issued beside the tile's own loads
@@ -276,15 +279,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P
     }
     if (!stopped) {
         stamp_wave(P, 2, lane);
-        if (open) leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt);
+        if (open) leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt, lds_ex);
         stamp_wave(P, 3, lane);
         return;
     }
     // A stop was published (necessarily for a round before r): hand in the tickets of round r and of every
     // later round this wave owns tiles in, sweeping nothing, so that all counters return to zero.
-    leave_round(P, r, acc, lane, wave, false, lds_part, lds_cnt);
+    leave_round(P, r, acc, lane, wave, false, lds_part, lds_cnt, lds_ex);
     for (unsigned q = r + 1; q < P.rounds; ++q)
-        if (wave_has_tile(w, W, P.round_begin[q], P.round_begin[q + 1])) leave_round(P, q, acc, lane, wave, false, lds_part, lds_cnt);
+        if (wave_has_tile(w, W, P.round_begin[q], P.round_begin[q + 1])) leave_round(P, q, acc, lane, wave, false, lds_part, lds_cnt, lds_ex);
     stamp_wave(P, 3, lane);
 }
 
