@@ -28,6 +28,43 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;  // valid in lane 0; fixed tree => bitwise reproducible
 }
 
+// Sum SEVEN per-lane values over the wave with 10 exchanges instead of 42: a butterfly that halves the
+// number of components a lane carries at each of the first three steps (xor 32, 16, 8) and then finishes
+// the one remaining component over the low three lane bits.  On return lane L holds the wave total of
+// component (L >> 3) for (L >> 3) < 7 — in all eight lanes of that class.  Fixed exchange pattern:
+// bitwise reproducible.
+__device__ __forceinline__ double wave_sum7(const double (&v)[7], int lane) {
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+    double a[4], t[4];
+    // 8 -> 4 components (component 7 is a zero pad)
+    const double v7 = 0.0;
+    t[0] = b5 ? v[0] : v[4]; t[1] = b5 ? v[1] : v[5]; t[2] = b5 ? v[2] : v[6]; t[3] = b5 ? v[3] : v7;
+    a[0] = b5 ? v[4] : v[0]; a[1] = b5 ? v[5] : v[1]; a[2] = b5 ? v[6] : v[2]; a[3] = b5 ? v7 : v[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] += __shfl_xor(t[i], 32, 64);
+    // 4 -> 2
+    double s0 = b4 ? a[0] : a[2], s1 = b4 ? a[1] : a[3];
+    double k0 = b4 ? a[2] : a[0], k1 = b4 ? a[3] : a[1];
+    k0 += __shfl_xor(s0, 16, 64);
+    k1 += __shfl_xor(s1, 16, 64);
+    // 2 -> 1
+    double s = b3 ? k0 : k1, k = b3 ? k1 : k0;
+    k += __shfl_xor(s, 8, 64);
+    // the remaining component over lanes that differ in bits 2..0
+    k += __shfl_xor(k, 4, 64);
+    k += __shfl_xor(k, 2, 64);
+    k += __shfl_xor(k, 1, 64);
+    return k;
+}
+
+// value of a wave-uniform source lane, through the scalar path (v_readlane) instead of an LDS permute
+__device__ __forceinline__ double read_lane_f64(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 struct Acc {
     double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
     unsigned na = 0, nb = 0, nv = 0;

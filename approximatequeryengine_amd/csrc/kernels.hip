@@ -17,16 +17,12 @@
 namespace aqe {
 namespace {
 
-// Sum 7 per-thread values over the workgroup in a fixed order: wave64 shuffle tree, then the four
-// wave results through LDS.  The totals are valid in thread 0.  `red` must be quiescent on entry.
+// Sum 7 per-thread values over the workgroup in a fixed order: wave64 butterfly (wave_sum7), then the
+// four wave results through LDS.  The totals are valid in thread 0.  `red` must be quiescent on entry.
 __device__ __forceinline__ void block_sum7(double (&v)[7], double (*red)[kVec]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) v[k] = wave_sum(v[k]);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) red[wave][k] = v[k];
-    }
+    const double mine = wave_sum7(v, lane);
+    if ((lane & 7) == 0 && lane < 56) red[wave][lane >> 3] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll

@@ -108,36 +108,38 @@ __device__ void decide_round(const PersistLaunch& P, unsigned r, int lane, const
     }
     if (abandoned) return;
     stamp_max(P, 8 + 8 * r + 4, lane);
-    // replay: lane -> value k = lane & 7 (k = 7 idle) of shards j and j + 8, j = lane >> 3
-    const int k = lane & 7, j = lane >> 3;
+    // replay: lane L sums the 16 shard partials (ascending shard) of component c = L & 7 of round
+    // q0 + (L >> 3); the folding then reads each round's seven totals through v_readlane.
     QueryState st{};
     bool stop = false;
     if (!timed_out) {
-        for (unsigned q0 = 0; q0 <= r && !stop; q0 += 8) {  // eight rounds of loads in flight at a time
-            double x0[8], x1[8];
-            bool u0[8], u1[8];
+        const int c = lane & 7;
+        for (unsigned q0 = 0; q0 <= r && !stop; q0 += 8) {
+            const unsigned q = q0 + static_cast<unsigned>(lane >> 3);
+            const bool act = c < 7 && q <= r;
+            const uint16_t* ex = lds_ex + static_cast<size_t>(act ? q : 0) * (kPersistShards + 1);
+            const double* sp = P.shard_partials + static_cast<size_t>(act ? q : 0) * kPersistShards * kVec;
+            double x[kPersistShards];
 #pragma unroll
-            for (unsigned i = 0; i < 8; ++i) {
-                const unsigned q = q0 + i <= r ? q0 + i : r;
-                const uint16_t* ex = lds_ex + static_cast<size_t>(q) * (kPersistShards + 1);
-                const double* sp = P.shard_partials + static_cast<size_t>(q) * kPersistShards * kVec;
-                u0[i] = k < 7 && ex[j] != 0;
-                u1[i] = k < 7 && ex[j + 8] != 0;
-                x0[i] = __hip_atomic_load(sp + (u0[i] ? j * kVec + k : 0), AQE_RLX);
-                x1[i] = __hip_atomic_load(sp + (u1[i] ? (j + 8) * kVec + k : 0), AQE_RLX);
+            for (int sh = 0; sh < kPersistShards; ++sh) {
+                const bool u = act && ex[sh] != 0;
+                x[sh] = __hip_atomic_load(sp + (u ? sh * kVec + c : 0), AQE_RLX);
+                if (!u) x[sh] = 0.0;
             }
+            double tot = 0.0;
 #pragma unroll
-            for (unsigned i = 0; i < 8; ++i) {
-                // shards in ascending order within a lane (j, then j + 8), then the fixed butterfly over j
-                const double tot = class_sum8((u0[i] ? x0[i] : 0.0) + (u1[i] ? x1[i] : 0.0));
+            for (int sh = 0; sh < kPersistShards; ++sh) tot += x[sh];
+#pragma unroll 1
+            for (int i = 0; i < 8 && q0 + i <= r; ++i) {  // wave-uniform trip count; source lanes live in SGPRs
                 double vec[kVec];
 #pragma unroll
-                for (int c = 0; c < 7; ++c) vec[c] = __shfl(tot, c, 64);
+                for (int cc = 0; cc < 7; ++cc) vec[cc] = read_lane_f64(tot, 8 * i + cc);
                 vec[7] = 0.0;
-                if (q0 + i <= r && !stop) {  // wave-uniform
-                    fold(st, vec, P.fold);
-                    stop = st.stop != 0;
-                    if (stop && q0 + i < r) return;  // an earlier round ends the query: its decider reports it
+                fold(st, vec, P.fold);
+                stop = st.stop != 0;
+                if (stop) {
+                    if (q0 + i < r) return;  // an earlier round ends the query: its decider reports it
+                    break;
                 }
             }
         }
@@ -222,14 +224,10 @@ __device__ __forceinline__ void leave_round(const PersistLaunch& P, unsigned r, 
                                             bool with_partial, double (*lds_part)[kWavesPerBlock][kVec], unsigned* lds_cnt,
                                             const uint16_t* lds_ex) {
     if (with_partial) {
-        double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
-                       static_cast<double>(acc.nv)};
-#pragma unroll
-        for (int k = 0; k < 7; ++k) v[k] = wave_sum(v[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) lds_part[r][wave][k] = v[k];
-        }
+        const double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
+                             static_cast<double>(acc.nv)};
+        const double mine = wave_sum7(v, lane);  // lane 8c holds component c
+        if ((lane & 7) == 0 && lane < 56) lds_part[r][wave][lane >> 3] = mine;
     }
     const u64 W = static_cast<u64>(gridDim.x) * kWavesPerBlock;
     const u64 b0 = P.round_begin[r], b1 = P.round_begin[r + 1];
@@ -242,7 +240,7 @@ __device__ __forceinline__ void leave_round(const PersistLaunch& P, unsigned r, 
     if (old + 1 == nw) block_publish(P, r, lane, with_partial, lds_part, lds_ex);
 }
 
-__global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P) {
+__global__ __launch_bounds__(kBlockThreads, 4) void k_sweep_persist(PersistLaunch P) {
     __shared__ double lds_part[kMaxPersistRounds][kWavesPerBlock][kVec];
     __shared__ unsigned lds_cnt[kMaxPersistRounds];
     __shared__ DevFamily lds_fams[kMaxLdsFams];
@@ -260,34 +258,45 @@ __global__ __launch_bounds__(kBlockThreads) void k_sweep_persist(PersistLaunch P
     const unsigned long long stop_tag = (P.epoch << 8) | 1ull;
     stamp_wave(P, 0, lane);
 
+    // One loop, one place where a round is left (the publish/decide code is large: a single call site
+    // keeps the sweep's registers for the loads).
     Acc acc;
     unsigned r = 0;
-    bool open = false;     // the wave has swept at least one tile of round r
-    bool stopped = false;
+    bool open = false;     // the wave has swept at least one tile of round r and not yet left it
+    bool stopped = false;  // a stop was observed: only tickets from here on
     u64 t = w;
-    for (; t < P.ntiles; t += W) {
-        while (t >= P.round_begin[r + 1]) {  // tile t belongs to a later round: leave the ones in between
-            if (open) { leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt, lds_ex); acc = Acc{}; open = false; }
-            ++r;
+    for (;;) {
+        bool leave = false, with_partial = true;
+        if (!stopped) {
+            const bool have = t < P.ntiles;
+            if (open && (!have || t >= P.round_begin[r + 1])) leave = true;  // round r is finished for this wave
+            else if (!have) break;
+            else while (t >= P.round_begin[r + 1]) ++r;                      // move to tile t's round
+        } else {
+            // A stop was published (necessarily for a round before r).  Hand in the tickets of round r and
+            // of every later round this wave owns tiles in, sweeping nothing, so all counters return to zero.
+            if (!open) {
+                do { ++r; } while (r < P.rounds && !wave_has_tile(w, W, P.round_begin[r], P.round_begin[r + 1]));
+                if (r >= P.rounds) break;
+            }
+            leave = true;
+            with_partial = false;
+        }
+        if (leave) {
+            leave_round(P, r, acc, lane, wave, with_partial, lds_part, lds_cnt, lds_ex);
+            acc = Acc{};
+            open = false;
+            continue;
         }
         // should_stop (DB.cpp:930/987): one sc1 load issued beside the tile's own loads
         const unsigned long long sw = __hip_atomic_load(&P.ctl->stop_word, AQE_RLX);
         sweep_tile(P.sw, fams, t, lane, ~0ull, acc);
         if (t == w) stamp_wave(P, 1, lane);
-        open = true;
-        if (sw == stop_tag) { stopped = true; break; }
-    }
-    if (!stopped) {
         stamp_wave(P, 2, lane);
-        if (open) leave_round(P, r, acc, lane, wave, true, lds_part, lds_cnt, lds_ex);
-        stamp_wave(P, 3, lane);
-        return;
+        open = true;
+        t += W;
+        if (sw == stop_tag) stopped = true;
     }
-    // A stop was published (necessarily for a round before r): hand in the tickets of round r and of every
-    // later round this wave owns tiles in, sweeping nothing, so that all counters return to zero.
-    leave_round(P, r, acc, lane, wave, false, lds_part, lds_cnt, lds_ex);
-    for (unsigned q = r + 1; q < P.rounds; ++q)
-        if (wave_has_tile(w, W, P.round_begin[q], P.round_begin[q + 1])) leave_round(P, q, acc, lane, wave, false, lds_part, lds_cnt, lds_ex);
     stamp_wave(P, 3, lane);
 }
 

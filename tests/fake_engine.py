@@ -1,0 +1,118 @@
+"""A CPU stand-in for engine.Plan built on the ORACLE (tests only): it lets the multi-process `gloo` tests
+drive approximatequeryengine_amd.distributed.ShardedQuery — the real orchestration code — without a GPU.
+The moment-vector layout and the fold are the ones of csrc/device_common.hpp, restated in numpy."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from oracle.pyoracle import Moments, Oracle
+
+VEC = 8
+
+
+class OracleShardPlan:
+    """Plan over rows [lo, hi) of a table of n_global rows for one of: ("stride", pct) or
+    ("clt", pct, conf, check_interval, T, e, R0, growth)."""
+
+    def __init__(self, oracle: Oracle, rows_shard: np.ndarray, lo: int, n_global: int, shift: float, spec):
+        self.o, self.rows, self.lo, self.hi, self.N, self.c, self.spec = oracle, rows_shard, lo, lo + len(rows_shard), n_global, shift, spec
+        self.kind = spec[0]
+        if self.kind == "clt":
+            _, pct, conf, ci, T, e, R0, g = spec
+            rc, self.plan = oracle.clt_plan(n_global, pct, conf, ci, T)
+            assert rc == 0
+            self.e, self.z, self.base = e, self.plan.z, self.plan.base
+            maxc = max(self.plan.w[i].count for i in range(T))
+            self.bounds, b, R = [], 0, R0
+            while b < maxc:
+                b1 = min(b + R, maxc)
+                self.bounds.append((b, b1))
+                b, R = b1, R * g
+            self.rounds, self.has_topup = len(self.bounds), self.base // 4 > 0
+        else:
+            self.rounds, self.has_topup = 1, False
+        self.reset()
+
+    def reset(self, stream=0):
+        self.st = dict(n_a=0.0, sd_a=0.0, qd_a=0.0, n_b=0.0, sd_b=0.0, qd_b=0.0, n_p=0.0, sd_p=0.0, qd_p=0.0, visited=0.0,
+                       topup=0.0, stop=0, converged=0, rounds=0)
+
+    @staticmethod
+    def _vec(ptr):
+        return np.ctypeslib.as_array((C.c_double * VEC).from_address(ptr))
+
+    def _shifted(self, x):
+        d = x - self.c
+        return float(len(x)), float(d.sum()), float((d * d).sum())
+
+    def enqueue_round(self, r, ptr, stream=0):
+        v = self._vec(ptr)
+        amt = self.rows["amount"]
+        if self.kind == "stride":
+            idx = self.o.idx_memory_stride(self.N, self.spec[1]).astype(np.int64)
+            idx = idx[(idx >= self.lo) & (idx < self.hi)] - self.lo
+            v[0:3] = self._shifted(amt[idx]); v[3:6] = 0; v[6] = len(idx); v[7] = 0
+            return
+        topup = r == self.rounds
+        if topup:
+            if not (self.st["n_p"] < self.base // 4):
+                return  # the device launch leaves without writing
+            step = max(1, self.N // (self.base // 4))
+            limit = int(self.base - self.st["n_p"])
+            idx = np.arange(0, self.N, step, dtype=np.int64)[:limit]
+            idx = idx[(idx >= self.lo) & (idx < self.hi)] - self.lo
+            v[0:3] = self._shifted(amt[idx]); v[3:6] = 0; v[6] = len(idx); v[7] = 0
+            return
+        if self.st["stop"]:
+            return
+        b0, b1 = self.bounds[r]
+        fa, sl = [], []
+        for i in range(self.plan.n_workers):
+            w = self.plan.w[i]
+            k = np.arange(min(b0, w.count), min(b1, w.count), dtype=np.int64)
+            idx = w.first + k * w.step
+            idx = idx[(idx >= self.lo) & (idx < self.hi)] - self.lo
+            (fa if w.is_fast else sl).append(amt[idx])
+        fa = np.concatenate(fa) if fa else np.zeros(0)
+        sl = np.concatenate(sl) if sl else np.zeros(0)
+        v[0:3] = self._shifted(fa); v[3:6] = self._shifted(sl); v[6] = len(fa) + len(sl); v[7] = 0
+
+    def enqueue_update(self, r, ptr, stream=0):
+        v, s = self._vec(ptr), self.st
+        if r == self.rounds and self.kind == "clt":
+            if not (s["n_p"] < self.base // 4):
+                return
+            s["n_p"] += v[0]; s["sd_p"] += v[1]; s["qd_p"] += v[2]; s["topup"] += v[0]; s["visited"] += v[6]
+            return
+        if s["stop"]:
+            return
+        for g, o in (("a", 0), ("b", 3)):
+            s["n_" + g] += v[o]; s["sd_" + g] += v[o + 1]; s["qd_" + g] += v[o + 2]
+        s["n_p"] += v[0] + v[3]; s["sd_p"] += v[1] + v[4]; s["qd_p"] += v[2] + v[5]
+        s["visited"] += v[6]; s["rounds"] += 1
+        if self.kind != "clt":
+            return
+        n = s["n_p"]
+        if n >= 30:
+            mean = self.c + s["sd_p"] / n
+            m2 = max(s["qd_p"] - s["sd_p"] ** 2 / n, 0.0)
+            if self.o.lib.aqo_clt_fast_rule(int(n), mean, m2 / (n - 1), self.z, self.e):
+                s["converged"], s["stop"] = 1, 1
+                return
+        if s["n_b"] >= 20 and s["n_a"] >= 30:
+            ma, mb = self.c + s["sd_a"] / s["n_a"], self.c + s["sd_b"] / s["n_b"]
+            if self.o.lib.aqo_clt_slow_rule(int(s["n_b"]), mb, int(s["n_a"]), ma, self.e, self.base):
+                s["converged"], s["stop"] = 2, 1
+
+    def enqueue_finalize(self, stream=0):
+        pass
+
+    def fetch(self, stream=0):
+        s = self.st
+        n = s["n_p"]
+        S = s["sd_p"] + n * self.c
+        mean = S / n if n else 0.0
+        m2 = max(s["qd_p"] - s["sd_p"] ** 2 / n, 0.0) if n else 0.0
+        return dict(n=int(n), sum=S, mean=mean, m2=m2, converged=s["converged"], rounds=s["rounds"], topup=int(s["topup"]),
+                    visited=int(s["visited"]))
