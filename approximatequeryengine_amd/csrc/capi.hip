@@ -48,14 +48,8 @@ struct aqe_ctx {
     double shift = 0.0;
     uint64_t hbm_bytes = 0;
     uint64_t table_epoch = 0;
-    // scratch shared by every launch of this context (one query in flight per context)
-    double* partials = nullptr;
-    unsigned* counter = nullptr;
-    // persistent sweep (persist.hip): fixed grid of 2 workgroups per CU, control block, per-round partials
+    // persistent sweep (persist.hip): fixed grid of 4 workgroups per CU (power of two)
     unsigned persist_grid = 0;
-    PersistCtl* d_ctl = nullptr;
-    double* d_ppart = nullptr;
-    double* d_spart = nullptr;
     unsigned long long* d_stamps = nullptr;  // diagnostics (env AQE_PERSIST_STAMPS)
     unsigned long long epoch = 1;
     // prepared plans of aqe_reduce / aqe_gather, keyed by the query bytes
@@ -77,6 +71,13 @@ struct aqe_plan {
     aqe_result* h_result = nullptr;  // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // Scratch of the hand-off protocols.  It belongs to the plan, not the context, so several plans can be
+    // in flight on different streams of one GPU (the tail of one query overlaps the sweep of the next).
+    double* partials = nullptr;   // [kMaxBlocks][kVec]   k_round / k_indexed
+    unsigned* counter = nullptr;  // sharded tickets, zero between launches
+    PersistCtl* d_ctl = nullptr;  // persistent sweep: decisions, stop word, tickets
+    double* d_ppart = nullptr;    // [rounds][persist_grid][kVec]
+    double* d_spart = nullptr;    // [rounds][kPersistShards][kVec]
     // single-launch form of the rounds (persist.hip), used by the fused single-GPU path when eligible
     bool persist = false;
     DevFamily* d_pfams = nullptr;
@@ -133,6 +134,11 @@ void destroy_plan(aqe_plan* p) {
     if (!p) return;
     if (p->d_fams) (void)hipFree(p->d_fams);
     if (p->d_idx) (void)hipFree(p->d_idx);
+    if (p->partials) (void)hipFree(p->partials);
+    if (p->counter) (void)hipFree(p->counter);
+    if (p->d_ctl) (void)hipFree(p->d_ctl);
+    if (p->d_ppart) (void)hipFree(p->d_ppart);
+    if (p->d_spart) (void)hipFree(p->d_spart);
     if (p->d_pfams) (void)hipFree(p->d_pfams);
     if (p->d_expected) (void)hipFree(p->d_expected);
     if (p->d_state) (void)hipFree(p->d_state);
@@ -240,12 +246,11 @@ SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam
 // folds into a zeroed state (no memset), later CLT launches test should_stop on entry, and in the fused
 // single-GPU form the last launch also writes the result.
 RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec) {
-    const aqe_ctx* c = p->ctx;
     RoundLaunch a{};
     a.sw = sweep_common(p, p->d_fams ? p->d_fams + L.fam_offset : nullptr, L.nfam);
     a.ntiles = L.ntiles;
-    a.partials = c->partials;
-    a.counter = c->counter;
+    a.partials = p->partials;
+    a.counter = p->counter;
     a.out_vec = out_vec;
     a.state = p->d_state;
     a.fused = fused ? 1 : 0;
@@ -351,9 +356,20 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             HIPCHK(c, hipMemcpy(p->d_pfams, pf.data(), pf.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_expected), ex.size() * sizeof(uint16_t)));
             HIPCHK(c, hipMemcpy(p->d_expected, ex.data(), ex.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            const size_t pp = sizeof(double) * kVec * c->persist_grid * R, sp = sizeof(double) * kVec * kPersistShards * R;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
+            HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ppart), pp));
+            HIPCHK(c, hipMemset(p->d_ppart, 0, pp));
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_spart), sp));
+            HIPCHK(c, hipMemset(p->d_spart, 0, sp));
             p->persist = true;
         }
     }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
+    HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
+    HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
     HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_result), sizeof(aqe_result)));
@@ -391,9 +407,9 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             for (size_t r = 0; r <= p->rounds.size(); ++r) a.round_begin[r] = p->round_begin[r];
             a.rounds = static_cast<uint32_t>(p->rounds.size());
             a.epoch = c->epoch++;
-            a.ctl = c->d_ctl;
-            a.partials = c->d_ppart;
-            a.shard_partials = c->d_spart;
+            a.ctl = p->d_ctl;
+            a.partials = p->d_ppart;
+            a.shard_partials = p->d_spart;
             a.expected = p->d_expected;
             a.state = p->d_state;
             a.fold = fold_params(p, false);
@@ -453,7 +469,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
         }
     }
     if (out->device_status != 0) {  // the round protocol gave up waiting: counters may be left mid-count
-        (void)hipMemset(c->d_ctl, 0, sizeof(PersistCtl));
+        if (p->d_ctl) (void)hipMemset(p->d_ctl, 0, sizeof(PersistCtl));
         return fail(c, AQE_ERR_HIP, "device-side round protocol timed out");
     }
     if (p->timed) {
@@ -576,20 +592,9 @@ int aqe_create(int device_id, aqe_ctx** out) {
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "hipSetDevice failed");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "stream creation failed");
-    if (hipMalloc(reinterpret_cast<void**>(&c->partials), sizeof(double) * kVec * kMaxBlocks) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->counter), sizeof(unsigned) * kCounterWords) != hipSuccess ||
-        hipMemset(c->counter, 0, sizeof(unsigned) * kCounterWords) != hipSuccess || hipMemset(c->partials, 0, sizeof(double) * kVec * kMaxBlocks) != hipSuccess)
-        return fail(nullptr, AQE_ERR_HIP, "scratch allocation failed");
     // 4 workgroups per CU, rounded down to a power of two (the wave->tile map uses masks), at most 1024
     c->persist_grid = 16;
     while (c->persist_grid * 2 <= static_cast<unsigned>(4 * prop.multiProcessorCount) && c->persist_grid < 1024) c->persist_grid *= 2;
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_ctl), sizeof(PersistCtl)) != hipSuccess ||
-        hipMemset(c->d_ctl, 0, sizeof(PersistCtl)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_ppart), sizeof(double) * kVec * c->persist_grid * kMaxPersistRounds) != hipSuccess ||
-        hipMemset(c->d_ppart, 0, sizeof(double) * kVec * c->persist_grid * kMaxPersistRounds) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_spart), sizeof(double) * kVec * kPersistShards * kMaxPersistRounds) != hipSuccess ||
-        hipMemset(c->d_spart, 0, sizeof(double) * kVec * kPersistShards * kMaxPersistRounds) != hipSuccess)
-        return fail(nullptr, AQE_ERR_HIP, "persistent-sweep scratch allocation failed");
     if (std::getenv("AQE_PERSIST_STAMPS") &&
         hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 8 * (8 * static_cast<size_t>(c->persist_grid) * kWavesPerBlock + 8 * kMaxPersistRounds)) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "stamp buffer allocation failed");
@@ -603,11 +608,6 @@ void aqe_destroy(aqe_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_cache(c);
     free_table(c);
-    if (c->partials) (void)hipFree(c->partials);
-    if (c->counter) (void)hipFree(c->counter);
-    if (c->d_ctl) (void)hipFree(c->d_ctl);
-    if (c->d_ppart) (void)hipFree(c->d_ppart);
-    if (c->d_spart) (void)hipFree(c->d_spart);
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--error-percent", type=float, default=0.01, help="--e of the reference CLI, in percent")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent queries in flight per GPU (one plan + one HIP stream each); 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     return ap.parse_args()
@@ -119,17 +121,27 @@ def main():
     eng.generate_synthetic(hi - lo, shard_lo=lo, n_global=n_global, seed=SEED, keep_aos=False)
     q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=0.95, check_interval=10,
                    num_threads=4 * world, max_error_percent=e, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
-    plan = eng.plan(q)
-    side = torch.cuda.Stream()
+    # S independent copies of the query, each with its own plan (hand-off scratch) and stream: the tail of
+    # one query (decision + top-up gate) overlaps the sweep of the next.  Multi-GPU keeps one in flight.
+    n_streams = max(1, args.streams) if world == 1 else 1
+    plans = [eng.plan(q) for _ in range(n_streams)]
+    sides = [torch.cuda.Stream() for _ in range(n_streams)]
+    plan, side = plans[0], sides[0]
     st = side.cuda_stream
+    turn = [0]
 
     with torch.cuda.stream(side):
         if world > 1:
             vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
             sq = ShardedQuery(plan, vec, torch_all_reduce(), stream=st)
             step = sq.enqueue
-        else:
+        elif n_streams == 1:
             step = lambda: plan.enqueue_all(st)  # noqa: E731
+        else:
+            def step():
+                i = turn[0] % n_streams
+                turn[0] += 1
+                plans[i].enqueue_all(sides[i].cuda_stream)
 
         def fence():
             torch.cuda.synchronize()
@@ -137,22 +149,27 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, n_streams)):
             step()
-        first = plan.fetch(st)
+        firsts = [p.fetch(s_.cuda_stream) for p, s_ in zip(plans, sides)]
+        first = firsts[0]
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         dt = time.perf_counter() - t0
-        last = plan.fetch(st)
+        lasts = [p.fetch(s_.cuda_stream) for p, s_ in zip(plans, sides)]
+        last = lasts[0]
+        assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
 
-        # ---- roofline of the dominant kernel (k_round): per-launch HIP events on the launch stream ----
+        # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, one query in flight ----
+        if world == 1:
+            step = lambda: plan.enqueue_all(st)  # noqa: E731
         plan.set_profiling(True)
         samples = plan.launch_samples()
         prof_steps = max(10, min(200, args.steps))
@@ -198,6 +215,7 @@ def main():
                 "rows_per_gpu": rows, "global_rows": n_global, "sample_percent": pct, "error_percent": e,
                 "pointers": 4 * world, "samples_per_query_per_gpu": int(last.visited if world == 1 else visited_local),
                 "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_query": len(samples),
+                "queries_in_flight": n_streams,
                 "collectives_per_query": (launches if world > 1 else 0),
                 "unit_definition": "one 10M-row region aggregate per GPU per query; a global query over N regions counts N",
             },
@@ -225,7 +243,8 @@ def main():
                                         "sample": f"failed: {ex!r}"}
         print(json.dumps(line), flush=True)
 
-    plan.close()
+    for p in plans:
+        p.close()
     eng.close()
     if world > 1:
         dist.barrier()
