@@ -48,7 +48,7 @@ struct aqe_ctx {
     double shift = 0.0;
     uint64_t hbm_bytes = 0;
     uint64_t table_epoch = 0;
-    // persistent sweep (persist.hip): fixed grid of 4 workgroups per CU (power of two)
+    // persistent sweep (persist.hip): fixed grid of one 16-wave workgroup per CU (power of two)
     unsigned persist_grid = 0;
     unsigned long long* d_stamps = nullptr;  // diagnostics (env AQE_PERSIST_STAMPS)
     unsigned long long epoch = 1;
@@ -77,10 +77,11 @@ struct aqe_plan {
     unsigned* counter = nullptr;  // sharded tickets, zero between launches
     PersistCtl* d_ctl = nullptr;  // persistent sweep: decisions, stop word, tickets
     double* d_ppart = nullptr;    // [rounds][persist_grid][kVec]
-    double* d_spart = nullptr;    // [rounds][kPersistShards][kVec]
+    double* d_rtot = nullptr;     // [rounds][kVec] round totals published by the deciders
     // single-launch form of the rounds (persist.hip), used by the fused single-GPU path when eligible
     bool persist = false;
     DevFamily* d_pfams = nullptr;
+    std::vector<DevFamily> h_pfams;
     uint32_t p_nfam = 0;
     uint16_t* d_expected = nullptr;
     uint64_t p_ntiles = 0;
@@ -138,7 +139,7 @@ void destroy_plan(aqe_plan* p) {
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_ppart) (void)hipFree(p->d_ppart);
-    if (p->d_spart) (void)hipFree(p->d_spart);
+    if (p->d_rtot) (void)hipFree(p->d_rtot);
     if (p->d_pfams) (void)hipFree(p->d_pfams);
     if (p->d_expected) (void)hipFree(p->d_expected);
     if (p->d_state) (void)hipFree(p->d_state);
@@ -340,29 +341,30 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             p->round_begin[R] = tiles;
             p->p_ntiles = tiles;
             p->p_nfam = static_cast<uint32_t>(pf.size());
-            const uint64_t G = c->persist_grid, W = G * kWavesPerBlock;
+            const uint64_t G = c->persist_grid, W = G * kPersistWaves;
             auto wave_has = [&](uint64_t w, uint64_t b0, uint64_t b1) { return b0 + ((w - b0) & (W - 1)) < b1; };
             std::vector<uint16_t> ex(R * (kPersistShards + 1), 0);
             for (size_t r = 0; r < R; ++r) {
                 uint16_t* e = &ex[r * (kPersistShards + 1)];
                 for (uint64_t b = 0; b < G; ++b) {
                     bool has = false;
-                    for (uint64_t j = 0; j < kWavesPerBlock; ++j) has = has || wave_has(b * kWavesPerBlock + j, p->round_begin[r], p->round_begin[r + 1]);
+                    for (uint64_t j = 0; j < kPersistWaves; ++j) has = has || wave_has(b * kPersistWaves + j, p->round_begin[r], p->round_begin[r + 1]);
                     if (has) e[b % kPersistShards]++;
                 }
                 for (int s = 0; s < kPersistShards; ++s) if (e[s]) e[kPersistShards]++;
             }
+            p->h_pfams = pf;
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_pfams), pf.size() * sizeof(DevFamily)));
             HIPCHK(c, hipMemcpy(p->d_pfams, pf.data(), pf.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_expected), ex.size() * sizeof(uint16_t)));
             HIPCHK(c, hipMemcpy(p->d_expected, ex.data(), ex.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            const size_t pp = sizeof(double) * kVec * c->persist_grid * R, sp = sizeof(double) * kVec * kPersistShards * R;
+            const size_t pp = sizeof(double) * kVec * c->persist_grid * R, sp = sizeof(double) * kVec * R;
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
             HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ppart), pp));
             HIPCHK(c, hipMemset(p->d_ppart, 0, pp));
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_spart), sp));
-            HIPCHK(c, hipMemset(p->d_spart, 0, sp));
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_rtot), sp));
+            HIPCHK(c, hipMemset(p->d_rtot, 0, sp));
             p->persist = true;
         }
     }
@@ -409,15 +411,17 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             a.epoch = c->epoch++;
             a.ctl = p->d_ctl;
             a.partials = p->d_ppart;
-            a.shard_partials = p->d_spart;
+            a.round_totals = p->d_rtot;
             a.expected = p->d_expected;
             a.state = p->d_state;
             a.fold = fold_params(p, false);
             a.fin = finalize_params(p);
             a.result = p->d_result;
             a.stamps = c->d_stamps;
+            a.inline_fams = p->p_nfam <= static_cast<uint32_t>(kPersistInlineFams) ? 1u : 0u;
+            if (a.inline_fams) std::copy(p->h_pfams.begin(), p->h_pfams.end(), a.fams);
             if (c->d_stamps) {
-                HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kWavesPerBlock + 8 * kMaxPersistRounds), s));
+                HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds), s));
                 HIPCHK(c, hipStreamSynchronize(s));
             }
             const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
@@ -446,7 +450,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     HIPCHK(c, hipStreamSynchronize(s));
     *out = *p->h_result;
     if (c->d_stamps && p->persist) {
-        const size_t W = static_cast<size_t>(c->persist_grid) * kWavesPerBlock;
+        const size_t W = static_cast<size_t>(c->persist_grid) * kPersistWaves;
         std::vector<unsigned long long> st(8 * W + 8 * kMaxPersistRounds);
         (void)hipMemcpy(st.data(), c->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* f = std::fopen(std::getenv("AQE_PERSIST_STAMPS"), "a")) {
@@ -462,7 +466,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
             std::fprintf(f, "starts ..%.2f first-tile %.2f..%.2f last-tile %.2f end %.2f |", us(s_hi), us(f_lo), us(f_hi), us(l_hi), us(e_hi));
             for (size_t r = 0; r < p->rounds.size(); ++r) {
                 const unsigned long long* q = &st[8 * W + 8 * r];
-                std::fprintf(f, " r%zu: shard %.2f chosen %.2f waited %.2f done %.2f |", r, us(q[2]), us(q[3]), us(q[4]), us(q[5]));
+                std::fprintf(f, " r%zu: chosen %.2f summed %.2f done %.2f |", r, us(q[3]), us(q[4]), us(q[5]));
             }
             std::fprintf(f, "\n");
             std::fclose(f);
@@ -592,11 +596,11 @@ int aqe_create(int device_id, aqe_ctx** out) {
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "hipSetDevice failed");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "stream creation failed");
-    // 4 workgroups per CU, rounded down to a power of two (the wave->tile map uses masks), at most 1024
+    // one 16-wave workgroup per CU, rounded down to a power of two (the wave->tile map uses masks)
     c->persist_grid = 16;
-    while (c->persist_grid * 2 <= static_cast<unsigned>(4 * prop.multiProcessorCount) && c->persist_grid < 1024) c->persist_grid *= 2;
+    while (c->persist_grid * 2 <= static_cast<unsigned>(prop.multiProcessorCount) && c->persist_grid * 2 <= kMaxPersistGrid) c->persist_grid *= 2;
     if (std::getenv("AQE_PERSIST_STAMPS") &&
-        hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 8 * (8 * static_cast<size_t>(c->persist_grid) * kWavesPerBlock + 8 * kMaxPersistRounds)) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds)) != hipSuccess)
         return fail(nullptr, AQE_ERR_HIP, "stamp buffer allocation failed");
     *out = c.release();
     return AQE_OK;

@@ -81,6 +81,30 @@ __device__ __forceinline__ void mean_m2(double n, double sd, double qd, double c
     if (m2 < 0.0) m2 = 0.0;
 }
 
+// The monitor's decision on the moments gathered so far (fast group a, slow group b, pooled a+b):
+// 1 = error rule (DB.cpp:936-961 on the pooled, all-reduced triple), 2 = cross-validation rule
+// (DB.cpp:993-1016), 0 = go on.
+__device__ __forceinline__ int clt_rules(double n_a, double sd_a, double qd_a, double n_b, double sd_b, double qd_b,
+                                         const FoldParams& p) {
+    const double n = n_a + n_b;
+    if (n >= 30.0) {
+        double mean, m2;
+        mean_m2(n, sd_a + sd_b, qd_a + qd_b, p.shift, mean, m2);
+        const double var = m2 / (n - 1.0);
+        const double se = sqrt(var / n);
+        const double err = (p.z * se / mean) * 100.0;
+        if (err <= p.e && n >= 50.0) return 1;
+    }
+    if (n_b >= 20.0 && n_a >= 30.0) {
+        const double mean_a = p.shift + sd_a / n_a, mean_b = p.shift + sd_b / n_b;
+        if (mean_a > 0.0) {
+            const double diff = fabs(mean_b - mean_a) / mean_a;
+            if (diff <= p.e / 100.0 && n_a >= static_cast<double>(p.base / 2)) return 2;
+        }
+    }
+    return 0;
+}
+
 // Fold one launch's reduced vector into the query state and take the CLT decision.
 __device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], const FoldParams& p) {
     if (p.is_topup) {  // DB.cpp:1031-1040: systematic rows appended to the sample
@@ -95,30 +119,10 @@ __device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], c
     s.visited += vec[6];
     s.rounds += 1;
     if (!p.is_clt) return;
-    // rule A, DB.cpp:936-961, on the pooled (all-reduced) moments
-    const double n = s.n_p;
-    if (n >= 30.0) {
-        double mean, m2;
-        mean_m2(n, s.sd_p, s.qd_p, p.shift, mean, m2);
-        double var = m2 / (n - 1.0);
-        double se = sqrt(var / n);
-        double err = (p.z * se / mean) * 100.0;
-        if (err <= p.e && n >= 50.0) {
-            s.converged = 1;
-            s.stop = 1;
-            return;
-        }
-    }
-    // rule B, DB.cpp:993-1016: slow pointers cross-validate the fast pointers' mean
-    if (s.n_b >= 20.0 && s.n_a >= 30.0) {
-        const double mean_a = p.shift + s.sd_a / s.n_a, mean_b = p.shift + s.sd_b / s.n_b;
-        if (mean_a > 0.0) {
-            double diff = fabs(mean_b - mean_a) / mean_a;
-            if (diff <= p.e / 100.0 && s.n_a >= static_cast<double>(p.base / 2)) {
-                s.converged = 2;
-                s.stop = 1;
-            }
-        }
+    const int code = clt_rules(s.n_a, s.sd_a, s.qd_a, s.n_b, s.sd_b, s.qd_b, p);
+    if (code) {
+        s.converged = code;
+        s.stop = 1;
     }
 }
 
@@ -215,13 +219,14 @@ __device__ __forceinline__ const DevFamily* stage_families(const SweepCommon& a,
 // Every load of the tile is issued before the first use; out-of-window lanes load row 0 of the shard
 // instead of branching around the load (a per-element branch would serialise the round trips:
 // cdna_hip_programming.md §5 item 4c).
-__device__ __forceinline__ void sweep_tile(const SweepCommon& a, const DevFamily* fams, u64 t, int lane, u64 ord_limit, Acc& acc) {
+template <typename FamPtr>
+__device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u64 t, int lane, u64 ord_limit, Acc& acc) {
     unsigned lo = 0, hi = a.nfam;
     while (hi - lo > 1) {
         unsigned mid = (lo + hi) >> 1;
         if (fams[mid].tile_begin <= t) lo = mid; else hi = mid;
     }
-    const DevFamily& F = fams[lo];
+    const auto& F = fams[lo];
     const u64 lt = t - F.tile_begin;
     u64 seg, j;
     if (F.tiles_per_seg == 0) { seg = F.seg_lo; j = F.j_lo + lt; }

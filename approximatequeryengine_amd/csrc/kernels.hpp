@@ -97,12 +97,16 @@ struct RoundLaunch {
 // ---- persistent single-launch sweep of a multi-round (CLT) query: persist.hip ------------------
 constexpr int kMaxPersistRounds = 32;
 constexpr int kPersistShards = 16;
-constexpr int kCtlStride = 32;  // u32 words between counters (128-byte lines)
+constexpr int kCtlStride = 32;         // u32 words between counters (128-byte lines)
+constexpr int kPersistThreads = 1024;  // one workgroup of 16 waves per CU
+constexpr int kPersistWaves = kPersistThreads / 64;
+constexpr int kMaxPersistGrid = 256;   // workgroups (a power of two <= CU count)
+constexpr int kPersistInlineFams = 16; // family tables up to this size travel in the kernel arguments
 
-// Control block in device memory (zeroed once per context; the protocol leaves every counter at zero).
+// Control block in device memory (zeroed once per plan; the protocol leaves every counter at zero).
 struct PersistCtl {
-    unsigned long long dec[kMaxPersistRounds];  // (epoch << 8) | code: 1 continue, 2 stop; one writer per round
-    unsigned long long stop_word;               // (epoch << 8) | 1 once a decider has stopped the query
+    unsigned long long dec[kMaxPersistRounds];  // (epoch << 8) | 1: round complete, its total published
+    unsigned long long stop_word;               // (epoch << 8) | 1 once a decider has ended the query
     unsigned long long pad[15];
     unsigned shard_cnt[kMaxPersistRounds][kPersistShards][kCtlStride];
     unsigned top_cnt[kMaxPersistRounds][kCtlStride];
@@ -113,17 +117,18 @@ struct PersistLaunch {
     uint64_t ntiles;
     uint64_t round_begin[kMaxPersistRounds + 1];  // first tile of each round; [rounds] == ntiles
     uint32_t rounds;
-    uint32_t pad;
-    unsigned long long epoch;  // distinguishes this launch's decisions from the previous launch's
+    uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
+    unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's
     PersistCtl* ctl;
-    double* partials;          // [rounds][gridDim.x][kVec]
-    double* shard_partials;    // [rounds][kPersistShards][kVec]
+    double* partials;          // [rounds][gridDim.x][kVec]  workgroup partials
+    double* round_totals;      // [rounds][kVec]             published by each round's decider
     const uint16_t* expected;  // [rounds][kPersistShards + 1]: participating workgroups per shard, then shards
     QueryState* state;
     FoldParams fold;
     FinalizeParams fin;
     aqe_result* result;
     unsigned long long* stamps;  // diagnostics only (AQE_PERSIST_STAMPS): s_memrealtime marks, else null
+    DevFamily fams[kPersistInlineFams];
 };
 
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s);
