@@ -199,6 +199,16 @@ def main():
                    "GBps": (8.0 * s / (m / prof_steps * 1e-3) / 1e9) if m > 0 else 0.0}
                   for s, m in zip(samples, sum_ms)]
 
+    # HBM-side traffic of the sweep kernel: a PMC measurement (FETCH_SIZE + WRITE_SIZE in their own rocprofv3
+    # passes, gfx950 correction calibrated on a known 80 MB scan) cannot be taken inside this process; the
+    # committed value in profiles/ is for this exact workload and kernel, and is only reported for it.
+    traffic = None
+    try:
+        if world == 1 and rows == ROWS_PER_GPU and e == 0.01:
+            traffic = json.loads((ROOT / "profiles" / "round1_pmc_raw.json").read_text())["k_sweep_persist_traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         line = {
             "metric": "aggregates/sec (10M-row region APPROX SUM/AVG/COUNT with 95% CI, CLT --e 0.01) + achieved HBM GB/s",
@@ -226,7 +236,8 @@ def main():
                        "same_as_first": bool(first.value == last.value)},
             "roofline": {
                 "bound": "hbm", "kernel": "k_sweep_persist" if world == 1 else "k_round", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": "profiles/round1_pmc_raw.json (rocprofv3 --pmc, bytes per launch)" if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms,
                 "launches_per_query": launches, "per_launch": per_launch,
                 "note": "8 B per sampled row (SoA f64 amount column) / mean sweep-kernel duration from per-launch HIP "
