@@ -87,6 +87,7 @@ struct aqe_plan {
     uint64_t p_ntiles = 0;
     uint64_t p_samples = 0;
     uint64_t round_begin[kMaxPersistRounds + 1] = {0};
+    uint32_t part_first[kMaxPersistRounds] = {0}, part_count[kMaxPersistRounds] = {0};
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
     bool profile = false;
     std::vector<hipEvent_t> lev;
@@ -352,6 +353,19 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                     if (has) e[b % kPersistShards]++;
                 }
                 for (int s = 0; s < kPersistShards; ++s) if (e[s]) e[kPersistShards]++;
+                // the same set as one cyclic run of workgroup ids (tiles are consecutive, waves cyclic)
+                const uint64_t b0 = p->round_begin[r], len = p->round_begin[r + 1] - b0;
+                uint64_t first = (b0 & (W - 1)) / kPersistWaves, count = G;
+                if (len < W) {
+                    const uint64_t last = ((b0 + len - 1) & (W - 1)) / kPersistWaves;
+                    count = ((last + G - first) & (G - 1)) + 1;
+                    if ((b0 & (W - 1)) > ((b0 + len - 1) & (W - 1)) && last >= first) count = G;  // wrapped onto its own first workgroup
+                }
+                uint64_t members = 0;
+                for (int s = 0; s < kPersistShards; ++s) members += e[s];
+                if (members != count) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation run mismatch");
+                p->part_first[r] = static_cast<uint32_t>(first);
+                p->part_count[r] = static_cast<uint32_t>(count);
             }
             p->h_pfams = pf;
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_pfams), pf.size() * sizeof(DevFamily)));
@@ -407,6 +421,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             a.sw = sweep_common(p, p->d_pfams, p->p_nfam);
             a.ntiles = p->p_ntiles;
             for (size_t r = 0; r <= p->rounds.size(); ++r) a.round_begin[r] = p->round_begin[r];
+            for (size_t r = 0; r < p->rounds.size(); ++r) { a.part_first[r] = p->part_first[r]; a.part_count[r] = p->part_count[r]; }
             a.rounds = static_cast<uint32_t>(p->rounds.size());
             a.epoch = c->epoch++;
             a.ctl = p->d_ctl;

@@ -116,6 +116,8 @@ struct PersistLaunch {
     SweepCommon sw;            // family table of ALL rounds, tile_begin numbered across the whole launch
     uint64_t ntiles;
     uint64_t round_begin[kMaxPersistRounds + 1];  // first tile of each round; [rounds] == ntiles
+    uint32_t part_first[kMaxPersistRounds];       // workgroups owning tiles of round r: the cyclic run
+    uint32_t part_count[kMaxPersistRounds];       //   [part_first, part_first + part_count) mod grid
     uint32_t rounds;
     uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
     unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's

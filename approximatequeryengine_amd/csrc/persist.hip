@@ -64,17 +64,6 @@ __device__ __forceinline__ bool wave_has_tile(u64 w, u64 W, u64 b0, u64 b1) {
     return first < b1;
 }
 
-// a workgroup's 16 waves are consecutive: it owns a tile of [b0,b1) iff some t in that range has
-// (t mod W) in [16 b, 16 b + 16)
-__device__ __forceinline__ bool block_has_tile(u64 b, u64 W, u64 b0, u64 b1) {
-    const u64 w0 = b * kPersistWaves;
-    const u64 first = b0 + ((w0 - b0) & (W - 1));       // first tile >= b0 owned by wave w0
-    if (first < b1) return true;
-    // otherwise the first tile at or after b0 owned by ANY of the 16 waves is b0 itself if b0's wave is in range
-    const u64 wb = b0 & (W - 1);
-    return b0 < b1 && wb >= w0 && wb < w0 + kPersistWaves;
-}
-
 __device__ __forceinline__ void state_store(QueryState* g, const QueryState& st) {
     static_assert(sizeof(QueryState) % 8 == 0, "state is moved as 8-byte words");
     const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&st);
@@ -97,7 +86,11 @@ constexpr int kDeciderLoads = kMaxPersistGrid / 8;  // workgroup partials per la
 // Not inlined on purpose: it runs once per round in the whole grid, and inlining lets hipcc hoist its address
 // arithmetic into every wave's prologue (and spill it).  It reads the launch descriptor through the kernarg
 // pointer only.
-__device__ __noinline__ void decide_round(KargPtr K, unsigned r) {
+__device__ __noinline__ void decide_round(KargPtr Kv, unsigned rv) {
+    // arguments arrive in vector registers: make them provably wave-uniform so the descriptor is read with
+    // scalar loads instead of a chain of dependent vector loads
+    const KargPtr K = (KargPtr)uniform64(reinterpret_cast<u64>(Kv));
+    const unsigned r = __builtin_amdgcn_readfirstlane(rv);
     const int lane = threadIdx.x & 63;
     PersistCtl* const ctl = K->ctl;
     const unsigned long long epoch = K->epoch;
@@ -109,8 +102,8 @@ __device__ __noinline__ void decide_round(KargPtr K, unsigned r) {
         if (lane == 0) __hip_atomic_store(&ctl->dec[r], tag | 1ull, AQE_RLX);
         return;
     }
-    const u64 W = static_cast<u64>(gridDim.x) * kPersistWaves;
-    const u64 b0 = K->round_begin[r], b1 = K->round_begin[r + 1];
+    // the workgroups that own tiles of round r form one cyclic run [first, first + count) of workgroup ids
+    const unsigned part_first = K->part_first[r], part_count = K->part_count[r], gmask = gridDim.x - 1;
     const int c = lane & 7, j = lane >> 3;
     const double* part = K->partials + static_cast<size_t>(r) * gridDim.x * kVec;
 
@@ -120,7 +113,7 @@ __device__ __noinline__ void decide_round(KargPtr K, unsigned r) {
 #pragma unroll
     for (int m = 0; m < kDeciderLoads; ++m) {  // lane (c, j) takes workgroups j, j + 8, j + 16, ...
         const unsigned b = static_cast<unsigned>(j + 8 * m);
-        use[m] = c < 7 && b < gridDim.x && block_has_tile(b, W, b0, b1);
+        use[m] = c < 7 && b < gridDim.x && ((b - part_first) & gmask) < part_count;
         x[m] = __hip_atomic_load(part + (use[m] ? static_cast<size_t>(b) * kVec + c : 0), AQE_RLX);
     }
     const bool watcher = static_cast<unsigned>(lane) < r;  // lane q < r watches round q
