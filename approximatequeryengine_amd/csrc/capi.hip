@@ -433,6 +433,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             a.fin = finalize_params(p);
             a.result = p->d_result;
             a.stamps = c->d_stamps;
+            a.finalize_here = p->host.has_topup ? 0u : 1u;
             a.inline_fams = p->p_nfam <= static_cast<uint32_t>(kPersistInlineFams) ? 1u : 0u;
             if (a.inline_fams) std::copy(p->h_pfams.begin(), p->h_pfams.end(), a.fams);
             if (c->d_stamps) {

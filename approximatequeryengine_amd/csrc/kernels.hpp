@@ -120,6 +120,8 @@ struct PersistLaunch {
     uint32_t part_count[kMaxPersistRounds];       //   [part_first, part_first + part_count) mod grid
     uint32_t rounds;
     uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
+    uint32_t finalize_here;    // 1: the ending decider also writes the result (no top-up launch follows)
+    uint32_t pad2;
     unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's
     PersistCtl* ctl;
     double* partials;          // [rounds][gridDim.x][kVec]  workgroup partials

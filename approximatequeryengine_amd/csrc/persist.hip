@@ -130,10 +130,12 @@ __device__ __noinline__ void decide_round(KargPtr Kv, unsigned rv) {
     s = class_sum8(s);  // lanes with (lane & 7) == c hold component c
     stamp_round(K->stamps, r, 4, lane);
 
-    // ---- publish the round total and the "complete" flag for later deciders ----
-    if (lane < 7) __hip_atomic_store(round_totals + static_cast<size_t>(r) * kVec + lane, s, AQE_RLX);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&ctl->dec[r], tag | 1ull, AQE_RLX);
+    // ---- publish the round total and the "complete" flag for later deciders (the last round has none) ----
+    if (r + 1 < rounds) {
+        if (lane < 7) __hip_atomic_store(round_totals + static_cast<size_t>(r) * kVec + lane, s, AQE_RLX);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&ctl->dec[r], tag | 1ull, AQE_RLX);
+    }
 
     // ---- earlier rounds must be complete; normally they are, otherwise wait (bounded) and re-read ----
     int timed_out = 0;
@@ -193,7 +195,7 @@ __device__ __noinline__ void decide_round(KargPtr Kv, unsigned rv) {
         fin.n_global = K->fin.n_global; fin.pct = K->fin.pct; fin.shift = K->fin.shift; fin.agg = K->fin.agg;
         fin.convention = K->fin.convention; fin.is_exact = K->fin.is_exact; fin.is_clt = K->fin.is_clt;
         state_store(K->state, st);
-        finalize(st, fin, K->result);  // the top-up launch, if it runs, rewrites the result
+        if (K->finalize_here) finalize(st, fin, K->result);  // else the top-up launch that follows writes the result  // the top-up launch, if it runs, rewrites the result
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // state and result are out before should_stop is
         __hip_atomic_store(&ctl->stop_word, tag | 1ull, AQE_RLX);
     }
@@ -266,7 +268,10 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
     // family table: from the kernel arguments when it fits (scalar loads, nothing to wait for), else LDS
     const DevFamily* lfams = P.inline_fams ? nullptr : stage_families(P.sw, lds_fams);
     const KargFams kfams = K->fams;
-    __syncthreads();
+    // The LDS tables above are first needed when a wave LEAVES a round, so with the family table in the
+    // kernel arguments the barrier that publishes them is taken after the wave's first tile is in flight.
+    bool synced = !P.inline_fams;
+    if (synced) __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const unsigned wave = threadIdx.x >> 6;
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
             with_partial = false;
         }
         if (leave) {
+            if (!synced) { __syncthreads(); synced = true; }
             leave_round(P, K, r, acc, lane, wave, with_partial, lds_part, lds_cnt, lds_ex);
             acc = Acc{};
             open = false;
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
         t += W;
         if (sw == stop_tag) stopped = true;
     }
+    if (!synced) __syncthreads();  // every wave of the workgroup takes the barrier exactly once
     stamp_wave(P, 3, lane);
 }
 
