@@ -120,6 +120,9 @@ def lib() -> C.CDLL:
         "aqe_plan_enqueue_update": (C.c_int, [vp, u32, vp, vp]),
         "aqe_plan_enqueue_finalize": (C.c_int, [vp, vp]),
         "aqe_plan_enqueue_all": (C.c_int, [vp, vp]),
+        "aqe_plan_totals_len": (C.c_int, [vp, P(u32)]),
+        "aqe_plan_enqueue_sweep_totals": (C.c_int, [vp, vp, vp]),
+        "aqe_plan_enqueue_replay": (C.c_int, [vp, vp, vp]),
         "aqe_plan_reset": (C.c_int, [vp, vp]),
         "aqe_plan_fetch": (C.c_int, [vp, P(Result), vp]),
         "aqe_plan_last_kernel_ms": (C.c_int, [vp, P(C.c_float)]),

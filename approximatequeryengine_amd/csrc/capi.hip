@@ -56,6 +56,20 @@ struct aqe_ctx {
     std::vector<std::pair<aqe_query, aqe_plan*>> cache;
 };
 
+// One persistent-sweep form of a plan's rounds (persist.hip): the tile list of all slots, who owns tiles
+// of which slot, and the workgroup-partial buffer.
+struct SweepForm {
+    bool ok = false;
+    uint32_t slots = 0;       // rounds (+ the top-up as an extra slot in the totals form)
+    std::vector<DevFamily> h_fams;
+    DevFamily* d_fams = nullptr;
+    uint16_t* d_expected = nullptr;
+    double* d_ppart = nullptr;  // [slots][persist_grid][kVec]
+    uint64_t round_begin[kMaxPersistRounds + 1] = {0};
+    uint32_t part_first[kMaxPersistRounds] = {0}, part_count[kMaxPersistRounds] = {0};
+    uint64_t ntiles = 0, samples = 0;
+};
+
 struct aqe_plan {
     aqe_ctx* ctx = nullptr;
     aqe_query q{};
@@ -76,18 +90,13 @@ struct aqe_plan {
     double* partials = nullptr;   // [kMaxBlocks][kVec]   k_round / k_indexed
     unsigned* counter = nullptr;  // sharded tickets, zero between launches
     PersistCtl* d_ctl = nullptr;  // persistent sweep: decisions, stop word, tickets
-    double* d_ppart = nullptr;    // [rounds][persist_grid][kVec]
     double* d_rtot = nullptr;     // [rounds][kVec] round totals published by the deciders
-    // single-launch form of the rounds (persist.hip), used by the fused single-GPU path when eligible
+    // Persistent single-launch forms (persist.hip).  `decide`: whole table on this GPU, decisions taken in the
+    // kernel (should_stop).  `totals`: any shard, every round plus the top-up swept speculatively, one total per
+    // slot written out — the multi-GPU form: ONE all-reduce of the slot totals, then k_replay decides.
     bool persist = false;
-    DevFamily* d_pfams = nullptr;
-    std::vector<DevFamily> h_pfams;
-    uint32_t p_nfam = 0;
-    uint16_t* d_expected = nullptr;
-    uint64_t p_ntiles = 0;
-    uint64_t p_samples = 0;
-    uint64_t round_begin[kMaxPersistRounds + 1] = {0};
-    uint32_t part_first[kMaxPersistRounds] = {0}, part_count[kMaxPersistRounds] = {0};
+    SweepForm decide, totals;
+    int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
     bool profile = false;
     std::vector<hipEvent_t> lev;
@@ -139,10 +148,12 @@ void destroy_plan(aqe_plan* p) {
     if (p->partials) (void)hipFree(p->partials);
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
-    if (p->d_ppart) (void)hipFree(p->d_ppart);
     if (p->d_rtot) (void)hipFree(p->d_rtot);
-    if (p->d_pfams) (void)hipFree(p->d_pfams);
-    if (p->d_expected) (void)hipFree(p->d_expected);
+    for (SweepForm* f : {&p->decide, &p->totals}) {
+        if (f->d_fams) (void)hipFree(f->d_fams);
+        if (f->d_expected) (void)hipFree(f->d_expected);
+        if (f->d_ppart) (void)hipFree(f->d_ppart);
+    }
     if (p->d_state) (void)hipFree(p->d_state);
     if (p->d_result) (void)hipFree(p->d_result);
     if (p->h_result) (void)hipHostFree(p->h_result);
@@ -277,12 +288,77 @@ hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStr
 
 int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, hipStream_t s) {
     aqe_ctx* c = p->ctx;
+    if (!topup && index == 0) p->last_exec = 0;
     RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec);
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
     if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
     if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s));
     else HIPCHK(c, launch_round(a, s));
     if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
+    return AQE_OK;
+}
+
+// Lay the plan's rounds (and, for the totals form, the top-up as one more slot) out as ONE tile list and work
+// out which workgroups own tiles of which slot.
+int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
+    aqe_ctx* c = p->ctx;
+    std::vector<const LaunchDesc*> slots;
+    for (const auto& L : p->rounds) slots.push_back(&L);
+    if (with_topup_slot && p->host.has_topup) slots.push_back(&p->topup);
+    const size_t S = slots.size();
+    uint64_t tiles = 0;
+    for (size_t r = 0; r < S; ++r) {
+        const LaunchDesc& L = *slots[r];
+        F.round_begin[r] = tiles;
+        for (uint32_t i = 0; i < L.nfam; ++i) {
+            DevFamily d = p->h_fams[L.fam_offset + i];
+            d.tile_begin += tiles;
+            d.flags &= ~AQE_F_TOPUP;  // swept whole: the replay decides whether the top-up counts
+            F.h_fams.push_back(d);
+        }
+        tiles += L.ntiles;
+        F.samples += L.samples;
+    }
+    F.round_begin[S] = tiles;
+    F.ntiles = tiles;
+    F.slots = static_cast<uint32_t>(S);
+    const uint64_t G = c->persist_grid, W = G * kPersistWaves;
+    auto wave_has = [&](uint64_t w, uint64_t b0, uint64_t b1) { return b0 + ((w - b0) & (W - 1)) < b1; };
+    std::vector<uint16_t> ex(S * (kPersistShards + 1), 0);
+    for (size_t r = 0; r < S; ++r) {
+        uint16_t* e = &ex[r * (kPersistShards + 1)];
+        for (uint64_t b = 0; b < G; ++b) {
+            bool has = false;
+            for (uint64_t j = 0; j < kPersistWaves; ++j) has = has || wave_has(b * kPersistWaves + j, F.round_begin[r], F.round_begin[r + 1]);
+            if (has) e[b % kPersistShards]++;
+        }
+        for (int s = 0; s < kPersistShards; ++s) if (e[s]) e[kPersistShards]++;
+        // the same set as one cyclic run of workgroup ids (tiles are consecutive, waves cyclic)
+        const uint64_t b0 = F.round_begin[r], len = F.round_begin[r + 1] - b0;
+        uint64_t first = (b0 & (W - 1)) / kPersistWaves, count = G;
+        if (len == 0) {
+            count = 0;
+        } else if (len < W) {
+            const uint64_t last = ((b0 + len - 1) & (W - 1)) / kPersistWaves;
+            count = ((last + G - first) & (G - 1)) + 1;
+            if ((b0 & (W - 1)) > ((b0 + len - 1) & (W - 1)) && last >= first) count = G;  // wrapped onto its own first workgroup
+        }
+        uint64_t members = 0;
+        for (int s = 0; s < kPersistShards; ++s) members += e[s];
+        if (members != count) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation run mismatch");
+        F.part_first[r] = static_cast<uint32_t>(first);
+        F.part_count[r] = static_cast<uint32_t>(count);
+    }
+    if (!F.h_fams.empty()) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_fams), F.h_fams.size() * sizeof(DevFamily)));
+        HIPCHK(c, hipMemcpy(F.d_fams, F.h_fams.data(), F.h_fams.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_expected), std::max<size_t>(ex.size(), 1) * sizeof(uint16_t)));
+    HIPCHK(c, hipMemcpy(F.d_expected, ex.data(), ex.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    const size_t pp = sizeof(double) * kVec * c->persist_grid * std::max<size_t>(S, 1);
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), pp));
+    HIPCHK(c, hipMemset(F.d_ppart, 0, pp));
+    F.ok = true;
     return AQE_OK;
 }
 
@@ -320,66 +396,26 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         HIPCHK(c, hipMemcpy(p->d_idx, p->host.random_idx.data(), p->host.random_idx.size() * sizeof(uint64_t),
                             hipMemcpyHostToDevice));
     }
-    {   // persistent single-launch form of the rounds
+    {   // persistent single-launch forms of the rounds
         const size_t R = p->rounds.size();
-        bool ok = !(q->flags & AQE_Q_NO_PERSIST) && !p->host.is_random && R >= 2 && R <= static_cast<size_t>(kMaxPersistRounds) &&
-                  c->persist_grid > 0 && c->shard_lo == 0 && c->n_local == c->n_global;
-        for (size_t r = 0; ok && r < R; ++r) ok = p->rounds[r].ntiles > 0;
-        if (ok) {
-            std::vector<DevFamily> pf;
-            uint64_t tiles = 0;
-            for (size_t r = 0; r < R; ++r) {
-                const LaunchDesc& L = p->rounds[r];
-                p->round_begin[r] = tiles;
-                for (uint32_t i = 0; i < L.nfam; ++i) {
-                    DevFamily d = p->h_fams[L.fam_offset + i];
-                    d.tile_begin += tiles;
-                    pf.push_back(d);
-                }
-                tiles += L.ntiles;
-                p->p_samples += L.samples;
-            }
-            p->round_begin[R] = tiles;
-            p->p_ntiles = tiles;
-            p->p_nfam = static_cast<uint32_t>(pf.size());
-            const uint64_t G = c->persist_grid, W = G * kPersistWaves;
-            auto wave_has = [&](uint64_t w, uint64_t b0, uint64_t b1) { return b0 + ((w - b0) & (W - 1)) < b1; };
-            std::vector<uint16_t> ex(R * (kPersistShards + 1), 0);
-            for (size_t r = 0; r < R; ++r) {
-                uint16_t* e = &ex[r * (kPersistShards + 1)];
-                for (uint64_t b = 0; b < G; ++b) {
-                    bool has = false;
-                    for (uint64_t j = 0; j < kPersistWaves; ++j) has = has || wave_has(b * kPersistWaves + j, p->round_begin[r], p->round_begin[r + 1]);
-                    if (has) e[b % kPersistShards]++;
-                }
-                for (int s = 0; s < kPersistShards; ++s) if (e[s]) e[kPersistShards]++;
-                // the same set as one cyclic run of workgroup ids (tiles are consecutive, waves cyclic)
-                const uint64_t b0 = p->round_begin[r], len = p->round_begin[r + 1] - b0;
-                uint64_t first = (b0 & (W - 1)) / kPersistWaves, count = G;
-                if (len < W) {
-                    const uint64_t last = ((b0 + len - 1) & (W - 1)) / kPersistWaves;
-                    count = ((last + G - first) & (G - 1)) + 1;
-                    if ((b0 & (W - 1)) > ((b0 + len - 1) & (W - 1)) && last >= first) count = G;  // wrapped onto its own first workgroup
-                }
-                uint64_t members = 0;
-                for (int s = 0; s < kPersistShards; ++s) members += e[s];
-                if (members != count) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation run mismatch");
-                p->part_first[r] = static_cast<uint32_t>(first);
-                p->part_count[r] = static_cast<uint32_t>(count);
-            }
-            p->h_pfams = pf;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_pfams), pf.size() * sizeof(DevFamily)));
-            HIPCHK(c, hipMemcpy(p->d_pfams, pf.data(), pf.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_expected), ex.size() * sizeof(uint16_t)));
-            HIPCHK(c, hipMemcpy(p->d_expected, ex.data(), ex.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            const size_t pp = sizeof(double) * kVec * c->persist_grid * R, sp = sizeof(double) * kVec * R;
+        const bool multi = !p->host.is_random && R >= 2 && c->persist_grid > 0;
+        const bool whole = c->shard_lo == 0 && c->n_local == c->n_global;
+        bool every_round_has_tiles = true;
+        for (size_t r = 0; r < R; ++r) every_round_has_tiles = every_round_has_tiles && p->rounds[r].ntiles > 0;
+        if (multi && whole && every_round_has_tiles && R <= static_cast<size_t>(kMaxPersistRounds) && !(q->flags & AQE_Q_NO_PERSIST)) {
+            int rc2 = build_sweep_form(p.get(), false, p->decide);
+            if (rc2 != AQE_OK) return rc2;
+            p->persist = true;
+        }
+        if (multi && R + (p->host.has_topup ? 1 : 0) <= static_cast<size_t>(kMaxPersistRounds)) {
+            int rc2 = build_sweep_form(p.get(), true, p->totals);
+            if (rc2 != AQE_OK) return rc2;
+        }
+        if (p->decide.ok || p->totals.ok) {
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
             HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ppart), pp));
-            HIPCHK(c, hipMemset(p->d_ppart, 0, pp));
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_rtot), sp));
-            HIPCHK(c, hipMemset(p->d_rtot, 0, sp));
-            p->persist = true;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_rtot), sizeof(double) * kVec * kMaxPersistRounds));
+            HIPCHK(c, hipMemset(p->d_rtot, 0, sizeof(double) * kVec * kMaxPersistRounds));
         }
     }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
@@ -408,6 +444,41 @@ int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     return AQE_OK;
 }
 
+int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_totals, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    PersistLaunch a{};
+    a.sw = sweep_common(p, F.d_fams, static_cast<uint32_t>(F.h_fams.size()));
+    a.ntiles = F.ntiles;
+    for (uint32_t r = 0; r <= F.slots; ++r) a.round_begin[r] = F.round_begin[r];
+    for (uint32_t r = 0; r < F.slots; ++r) { a.part_first[r] = F.part_first[r]; a.part_count[r] = F.part_count[r]; }
+    a.rounds = F.slots;
+    a.epoch = c->epoch++;
+    a.ctl = p->d_ctl;
+    a.partials = F.d_ppart;
+    a.round_totals = p->d_rtot;
+    a.expected = F.d_expected;
+    a.state = p->d_state;
+    a.fold = fold_params(p, false);
+    a.fin = finalize_params(p);
+    a.result = p->d_result;
+    a.stamps = c->d_stamps;
+    a.finalize_here = p->host.has_topup ? 0u : 1u;
+    a.totals_only = totals_only ? 1u : 0u;
+    p->last_exec = totals_only ? 2 : 1;
+    a.out_totals = out_totals;
+    a.inline_fams = F.h_fams.size() <= static_cast<size_t>(kPersistInlineFams) ? 1u : 0u;
+    if (a.inline_fams) std::copy(F.h_fams.begin(), F.h_fams.end(), a.fams);
+    if (c->d_stamps) {
+        HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds), s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
+    if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
+    HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s));
+    if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
+    return AQE_OK;
+}
+
 int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
     aqe_ctx* c = p->ctx;
     if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
@@ -417,33 +488,8 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
         HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
     } else {
         if (p->persist) {
-            PersistLaunch a{};
-            a.sw = sweep_common(p, p->d_pfams, p->p_nfam);
-            a.ntiles = p->p_ntiles;
-            for (size_t r = 0; r <= p->rounds.size(); ++r) a.round_begin[r] = p->round_begin[r];
-            for (size_t r = 0; r < p->rounds.size(); ++r) { a.part_first[r] = p->part_first[r]; a.part_count[r] = p->part_count[r]; }
-            a.rounds = static_cast<uint32_t>(p->rounds.size());
-            a.epoch = c->epoch++;
-            a.ctl = p->d_ctl;
-            a.partials = p->d_ppart;
-            a.round_totals = p->d_rtot;
-            a.expected = p->d_expected;
-            a.state = p->d_state;
-            a.fold = fold_params(p, false);
-            a.fin = finalize_params(p);
-            a.result = p->d_result;
-            a.stamps = c->d_stamps;
-            a.finalize_here = p->host.has_topup ? 0u : 1u;
-            a.inline_fams = p->p_nfam <= static_cast<uint32_t>(kPersistInlineFams) ? 1u : 0u;
-            if (a.inline_fams) std::copy(p->h_pfams.begin(), p->h_pfams.end(), a.fams);
-            if (c->d_stamps) {
-                HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds), s));
-                HIPCHK(c, hipStreamSynchronize(s));
-            }
-            const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
-            if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
-            HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s));
-            if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
+            int rc = launch_form(p, p->decide, false, nullptr, s);
+            if (rc != AQE_OK) return rc;
         } else {
             for (uint32_t i = 0; i < p->rounds.size(); ++i) {
                 int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
@@ -888,6 +934,34 @@ int aqe_plan_enqueue_finalize(aqe_plan* p, void* stream) {
     return AQE_OK;
 }
 
+int aqe_plan_totals_len(const aqe_plan* p, uint32_t* n_doubles) {
+    if (!p || !n_doubles) return AQE_ERR_INVALID;
+    *n_doubles = p->totals.ok ? p->totals.slots * kVec : 0;
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_sweep_totals(aqe_plan* p, double* dev_totals, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!p->totals.ok) return fail(p->ctx, AQE_ERR_UNSUPPORTED, "this plan has no batched (totals) form; use the per-round calls");
+    if (!dev_totals) return fail(p->ctx, AQE_ERR_INVALID, "dev_totals is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    p->lev_used = 0;
+    return launch_form(p, p->totals, true, dev_totals, pick(p, stream));
+}
+
+int aqe_plan_enqueue_replay(aqe_plan* p, const double* dev_totals, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!p->totals.ok) return fail(p->ctx, AQE_ERR_UNSUPPORTED, "this plan has no batched (totals) form");
+    if (!dev_totals) return fail(p->ctx, AQE_ERR_INVALID, "dev_totals is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    const uint32_t R = static_cast<uint32_t>(p->rounds.size());
+    HIPCHK(p->ctx, launch_replay(dev_totals, R, p->totals.slots > R ? 1u : 0u, fold_params(p, false), finalize_params(p),
+                                 p->d_state, p->d_result, pick(p, stream)));
+    return AQE_OK;
+}
+
 int aqe_plan_enqueue_all(aqe_plan* p, void* stream) {
     int rc = plan_is_current(p);
     if (rc != AQE_OK) return rc;
@@ -940,13 +1014,21 @@ int aqe_plan_launch_ms(aqe_plan* p, float* ms, uint32_t cap, uint32_t* n_out) {
 
 int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, uint32_t* n_out) {
     if (!p || !n_out) return AQE_ERR_INVALID;
-    // the fused single-GPU path runs every round in ONE launch when the plan has a persistent form
-    const uint32_t sweeps = p->persist ? 1u : static_cast<uint32_t>(p->rounds.size());
+    // reports the launches of the form the plan last executed with (or will: the fused path by default)
+    const int form = p->last_exec ? p->last_exec : (p->persist ? 1 : 0);
+    if (form == 2) {  // batched multi-GPU form: one launch sweeps every slot, top-up included
+        *n_out = 1;
+        if (!samples) return AQE_OK;
+        if (cap < 1) return AQE_ERR_CAPACITY;
+        samples[0] = p->totals.samples;
+        return AQE_OK;
+    }
+    const uint32_t sweeps = form == 1 ? 1u : static_cast<uint32_t>(p->rounds.size());
     const uint32_t n = sweeps + (p->host.has_topup ? 1u : 0u);
     *n_out = n;
     if (!samples) return AQE_OK;
     if (cap < n) return AQE_ERR_CAPACITY;
-    if (p->persist) samples[0] = p->p_samples;
+    if (form == 1) samples[0] = p->decide.samples;
     else for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
     if (p->host.has_topup) samples[sweeps] = p->topup.samples;
     return AQE_OK;

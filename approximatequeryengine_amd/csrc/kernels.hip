@@ -179,6 +179,53 @@ __global__ void k_update(QueryState* s, const double* vec, FoldParams p, int res
     *s = st;
 }
 
+// Multi-GPU form: `totals` holds the all-reduced total of every slot (rounds in order, then the top-up).
+// Replays the folds in round order — lane q keeps the state after round q and judges that round's stop rule,
+// all rounds at once — takes the first stopping round (or the last), applies the top-up gate
+// (DB.cpp:1031-1040) and writes state + result.  Every rank runs it on identical input.
+__global__ void k_replay(const double* __restrict__ totals, unsigned rounds, unsigned has_topup_slot, FoldParams fp,
+                         FinalizeParams fin, QueryState* state, aqe_result* result) {
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const bool have = static_cast<unsigned>(lane) < rounds;
+    double tot_q[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) tot_q[c] = have ? totals[static_cast<size_t>(lane) * kVec + c] : 0.0;
+    double run[7] = {0, 0, 0, 0, 0, 0, 0}, mine[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (unsigned q = 0; q < rounds; ++q) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            run[c] += read_lane_f64(tot_q[c], static_cast<int>(q));
+            if (static_cast<unsigned>(lane) == q) mine[c] = run[c];
+        }
+    }
+    int code = 0;
+    if (fp.is_clt && have) code = clt_rules(mine[0], mine[1], mine[2], mine[3], mine[4], mine[5], fp);
+    const unsigned long long stops = __ballot(code != 0);
+    unsigned last = rounds ? rounds - 1 : 0;
+    if (stops) last = static_cast<unsigned>(__builtin_ctzll(stops));
+    if (static_cast<unsigned>(lane) != last) return;
+    QueryState st{};
+    if (rounds) {
+        st.n_a = mine[0]; st.sd_a = mine[1]; st.qd_a = mine[2];
+        st.n_b = mine[3]; st.sd_b = mine[4]; st.qd_b = mine[5];
+        st.n_p = mine[0] + mine[3]; st.sd_p = mine[1] + mine[4]; st.qd_p = mine[2] + mine[5];
+        st.visited = mine[6];
+        st.rounds = static_cast<int32_t>(last + 1);
+        st.converged = code;
+        st.stop = code != 0;
+    }
+    if (has_topup_slot && st.n_p < static_cast<double>(fp.base / 4)) {  // DB.cpp:1032
+        const double* t = totals + static_cast<size_t>(rounds) * kVec;
+        st.n_p += t[0]; st.sd_p += t[1]; st.qd_p += t[2];
+        st.topup += t[0];
+        st.visited += t[6];
+    }
+    *state = st;
+    finalize(st, fin, result);
+}
+
 __global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     QueryState st = *s;
@@ -305,6 +352,12 @@ hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_
 
 hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, int reset_state, hipStream_t s) {
     hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, s, state, vec, p, reset_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup_slot, const FoldParams& fp,
+                         const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s) {
+    hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, s, totals, rounds, has_topup_slot, fp, fin, state, result);
     return hipGetLastError();
 }
 

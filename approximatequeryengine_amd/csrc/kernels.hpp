@@ -121,11 +121,12 @@ struct PersistLaunch {
     uint32_t rounds;
     uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
     uint32_t finalize_here;    // 1: the ending decider also writes the result (no top-up launch follows)
-    uint32_t pad2;
+    uint32_t totals_only;      // 1: no decisions in the kernel; every slot's total is written to out_totals
     unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's
     PersistCtl* ctl;
     double* partials;          // [rounds][gridDim.x][kVec]  workgroup partials
     double* round_totals;      // [rounds][kVec]             published by each round's decider
+    double* out_totals;        // totals_only: [rounds][kVec] (this shard's slot totals, for the all-reduce)
     const uint16_t* expected;  // [rounds][kPersistShards + 1]: participating workgroups per shard, then shards
     QueryState* state;
     FoldParams fold;
@@ -136,6 +137,8 @@ struct PersistLaunch {
 };
 
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s);
+hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup_slot, const FoldParams& fp,
+                         const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);
 
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s);
 hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s);

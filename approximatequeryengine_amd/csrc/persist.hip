@@ -97,8 +97,9 @@ __device__ __noinline__ void decide_round(KargPtr Kv, unsigned rv) {
     const unsigned rounds = K->rounds;
     double* const round_totals = K->round_totals;
     const unsigned long long tag = epoch << 8;
+    const bool totals_only = K->totals_only != 0;
     stamp_round(K->stamps, r, 3, lane);
-    if (__hip_atomic_load(&ctl->stop_word, AQE_RLX) == (tag | 1ull)) {  // an earlier round already ended the query
+    if (!totals_only && __hip_atomic_load(&ctl->stop_word, AQE_RLX) == (tag | 1ull)) {  // an earlier round already ended the query
         if (lane == 0) __hip_atomic_store(&ctl->dec[r], tag | 1ull, AQE_RLX);
         return;
     }
@@ -116,7 +117,7 @@ __device__ __noinline__ void decide_round(KargPtr Kv, unsigned rv) {
         use[m] = c < 7 && b < gridDim.x && ((b - part_first) & gmask) < part_count;
         x[m] = __hip_atomic_load(part + (use[m] ? static_cast<size_t>(b) * kVec + c : 0), AQE_RLX);
     }
-    const bool watcher = static_cast<unsigned>(lane) < r;  // lane q < r watches round q
+    const bool watcher = !totals_only && static_cast<unsigned>(lane) < r;  // lane q < r watches round q
     unsigned long long flag = __hip_atomic_load(&ctl->dec[watcher ? lane : 0], AQE_RLX);
     double tot_q[7];  // lane q: the published totals of round q
 #pragma unroll
@@ -129,6 +130,10 @@ __device__ __noinline__ void decide_round(KargPtr Kv, unsigned rv) {
     for (int m = 0; m < kDeciderLoads; ++m) s += use[m] ? x[m] : 0.0;
     s = class_sum8(s);  // lanes with (lane & 7) == c hold component c
     stamp_round(K->stamps, r, 4, lane);
+    if (totals_only) {  // multi-GPU form: hand the slot total out; the decision is taken after the all-reduce
+        if (lane < kVec) K->out_totals[static_cast<size_t>(r) * kVec + lane] = lane < 7 ? s : 0.0;
+        return;
+    }
 
     // ---- publish the round total and the "complete" flag for later deciders (the last round has none) ----
     if (r + 1 < rounds) {
@@ -265,6 +270,10 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
     for (unsigned i = threadIdx.x; i < P.rounds * (kPersistShards + 1); i += kPersistThreads) lds_ex[i] = P.expected[i];
     if (threadIdx.x < kMaxPersistRounds) lds_cnt[threadIdx.x] = 0;
     const KargPtr K = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    if (P.totals_only && blockIdx.x == 0 && threadIdx.x < P.rounds * kVec) {  // slots with no tile on this shard
+        const unsigned r0 = threadIdx.x / kVec;
+        if (K->round_begin[r0 + 1] == K->round_begin[r0]) P.out_totals[threadIdx.x] = 0.0;
+    }
     // family table: from the kernel arguments when it fits (scalar loads, nothing to wait for), else LDS
     const DevFamily* lfams = P.inline_fams ? nullptr : stage_families(P.sw, lds_fams);
     const KargFams kfams = K->fams;

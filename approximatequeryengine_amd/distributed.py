@@ -30,33 +30,74 @@ class ShardedQuery:
     """Runs one planned query across the ranks of a process group.
 
     plan        an object with the ``engine.Plan`` interface, planned over THIS rank's shard
-    vec         a tensor of MOMENT_VEC float64 on the plan's device (reused every round)
+    vec         a float64 tensor on the plan's device, at least max(MOMENT_VEC, plan.totals_len) long
     all_reduce  callable(tensor) -> None performing an in-place SUM over the group
     stream      raw stream handle passed through to the plan (0 = the plan's own stream)
-    sync_every  fetch the device stop flag every this many rounds to stop enqueueing early
-                (0 = never look: rounds after the stop are cheap device-side no-ops)
+    batched     True: ONE collective per query — every round and the top-up are swept speculatively in one
+                launch, the per-slot totals are all-reduced once, and the stop rules are replayed on the
+                reduced totals (identical answer; the rounds after the stop are swept for nothing, which on a
+                10 M-row shard costs less than a single extra collective).  False: one collective per
+                convergence step, nothing swept past the stop.  None: batched when the plan offers it.
     """
 
-    def __init__(self, plan, vec, all_reduce: Callable, stream: int = 0):
+    def __init__(self, plan, vec, all_reduce: Callable, stream: int = 0, batched: Optional[bool] = None):
         self.plan = plan
         self.vec = vec
         self.all_reduce = all_reduce
         self.stream = stream
+        can = getattr(plan, "totals_len", 0) > 0
+        self.batched = can if batched is None else (batched and can)
+        need = plan.totals_len if self.batched else MOMENT_VEC
+        if vec.numel() < need:
+            raise ValueError(f"moment buffer holds {vec.numel()} doubles, the plan needs {need}")
 
     def enqueue(self) -> None:
         p, v, s = self.plan, self.vec, self.stream
+        if self.batched:
+            t = v[: p.totals_len]
+            p.enqueue_sweep_totals(t.data_ptr(), s)  # this shard's total of every slot, one launch
+            self.all_reduce(t)                       # ONE collective per query
+            p.enqueue_replay(t.data_ptr(), s)        # stop rules + top-up gate + estimate, on the device
+            return
         p.reset(s)
         steps = p.rounds + (1 if p.has_topup else 0)
+        t = v[:MOMENT_VEC]
         for r in range(steps):
-            v.zero_()                            # a launch that leaves early writes nothing
-            p.enqueue_round(r, v.data_ptr(), s)  # this shard's partial (n, Σd, Σd²)
-            self.all_reduce(v)                   # ONE collective per convergence step
-            p.enqueue_update(r, v.data_ptr(), s) # fold + CLT rules + should_stop, on the device
+            t.zero_()                            # a launch that leaves early writes nothing
+            p.enqueue_round(r, t.data_ptr(), s)  # this shard's partial (n, Σd, Σd²)
+            self.all_reduce(t)                   # ONE collective per convergence step
+            p.enqueue_update(r, t.data_ptr(), s) # fold + CLT rules + should_stop, on the device
         p.enqueue_finalize(s)
 
     def run(self):
         self.enqueue()
         return self.plan.fetch(self.stream)
+
+
+class ShardedBatch:
+    """B independent queries per collective: each query's slot totals land in its own row of one buffer and a
+    single all-reduce serves them all (xGMI collectives are latency-bound at this size: 8 queries x 7 slots x 64 B
+    cost the same ~tens of microseconds as one).  All plans must offer the batched form."""
+
+    def __init__(self, plans, buf, all_reduce: Callable, stream: int = 0):
+        if any(getattr(p, "totals_len", 0) == 0 for p in plans):
+            raise ValueError("every plan of a ShardedBatch needs a batched (totals) form")
+        self.plans, self.buf, self.all_reduce, self.stream = list(plans), buf, all_reduce, stream
+        self.width = max(p.totals_len for p in plans)
+        if buf.dim() != 2 or buf.shape[0] < len(self.plans) or buf.shape[1] < self.width:
+            raise ValueError("buffer must be [len(plans), >= totals_len] float64")
+
+    def enqueue(self) -> None:
+        s = self.stream
+        for i, p in enumerate(self.plans):
+            p.enqueue_sweep_totals(self.buf[i].data_ptr(), s)
+        self.all_reduce(self.buf)
+        for i, p in enumerate(self.plans):
+            p.enqueue_replay(self.buf[i].data_ptr(), s)
+
+    def run(self):
+        self.enqueue()
+        return [p.fetch(self.stream) for p in self.plans]
 
 
 def torch_all_reduce(group=None) -> Callable:

@@ -31,6 +31,9 @@ class Plan:
         r, t = C.c_uint32(), C.c_int32()
         nat.check(nat.lib().aqe_plan_rounds(self._h, C.byref(r), C.byref(t)), engine._h)
         self.rounds, self.has_topup = r.value, bool(t.value)
+        n = C.c_uint32()
+        nat.check(nat.lib().aqe_plan_totals_len(self._h, C.byref(n)), engine._h)
+        self.totals_len = n.value  # 0: no batched (one-collective) form
 
     def close(self):
         if self._h:
@@ -57,6 +60,12 @@ class Plan:
 
     def enqueue_finalize(self, stream: int = 0):
         self._chk(nat.lib().aqe_plan_enqueue_finalize(self._h, C.c_void_p(stream)))
+
+    def enqueue_sweep_totals(self, dev_totals_ptr: int, stream: int = 0):
+        self._chk(nat.lib().aqe_plan_enqueue_sweep_totals(self._h, C.c_void_p(dev_totals_ptr), C.c_void_p(stream)))
+
+    def enqueue_replay(self, dev_totals_ptr: int, stream: int = 0):
+        self._chk(nat.lib().aqe_plan_enqueue_replay(self._h, C.c_void_p(dev_totals_ptr), C.c_void_p(stream)))
 
     def enqueue_all(self, stream: int = 0):
         self._chk(nat.lib().aqe_plan_enqueue_all(self._h, C.c_void_p(stream)))

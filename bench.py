@@ -40,12 +40,13 @@ CLT_GROWTH = 4      # ... times 4 every round: 5 launches cover the 1 M-sample p
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--error-percent", type=float, default=0.01, help="--e of the reference CLI, in percent")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="independent queries in flight per GPU (one plan + one HIP stream each); 1 = strictly serial")
+    ap.add_argument("--batch", "--streams", dest="batch", type=int, default=8,
+                    help="independent queries per step.  1 GPU: each has its own plan and HIP stream (the decision tail of "
+                         "one overlaps the sweep of the next).  N GPUs: one all-reduce serves the whole batch.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     return ap.parse_args()
@@ -97,7 +98,7 @@ def main():
     import torch
     import torch.distributed as dist
     from approximatequeryengine_amd import _native as nat
-    from approximatequeryengine_amd.distributed import ShardedQuery, shard_bounds, torch_all_reduce
+    from approximatequeryengine_amd.distributed import ShardedBatch, ShardedQuery, shard_bounds, torch_all_reduce
     from approximatequeryengine_amd.engine import Engine, make_query
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,10 +107,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # AQE_BENCH_REHEARSAL=1: several ranks share ONE GPU over gloo (to exercise the N>1 code path on a one-GPU
+    # box); never used for reported numbers.
+    rehearsal = os.environ.get("AQE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     rows = args.rows_per_gpu
     n_global = rows * world
@@ -121,27 +130,34 @@ def main():
     eng.generate_synthetic(hi - lo, shard_lo=lo, n_global=n_global, seed=SEED, keep_aos=False)
     q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=0.95, check_interval=10,
                    num_threads=4 * world, max_error_percent=e, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
-    # S independent copies of the query, each with its own plan (hand-off scratch) and stream: the tail of
-    # one query (decision + top-up gate) overlaps the sweep of the next.  Multi-GPU keeps one in flight.
-    n_streams = max(1, args.streams) if world == 1 else 1
-    plans = [eng.plan(q) for _ in range(n_streams)]
-    sides = [torch.cuda.Stream() for _ in range(n_streams)]
+    # One step = a batch of B independent copies of the query, each with its own plan (hand-off scratch).
+    # 1 GPU: one HIP stream per query, in-kernel decisions (k_sweep_persist).  N GPUs: every query's slot totals
+    # go into one [B, totals] buffer, ONE RCCL all-reduce per step, then k_replay decides each query.
+    B = max(1, args.batch)
+    plans = [eng.plan(q) for _ in range(B)]
+    sides = [torch.cuda.Stream() for _ in range(B if world == 1 else 1)]
     plan, side = plans[0], sides[0]
     st = side.cuda_stream
-    turn = [0]
+    n_streams = len(sides)
 
     with torch.cuda.stream(side):
         if world > 1:
-            vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
-            sq = ShardedQuery(plan, vec, torch_all_reduce(), stream=st)
-            step = sq.enqueue
-        elif n_streams == 1:
-            step = lambda: plan.enqueue_all(st)  # noqa: E731
+            if plan.totals_len:
+                buf = torch.zeros(B, plan.totals_len, dtype=torch.float64, device="cuda")
+                sb = ShardedBatch(plans, buf, torch_all_reduce(), stream=st)
+                step = sb.enqueue
+                collectives_per_step = 1
+            else:  # plans without a batched form: one collective per convergence step and query
+                vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
+                sqs = [ShardedQuery(p, vec, torch_all_reduce(), stream=st) for p in plans]
+                step = lambda: [x.enqueue() for x in sqs]  # noqa: E731
+                collectives_per_step = B * (plan.rounds + (1 if plan.has_topup else 0))
         else:
+            collectives_per_step = 0
+
             def step():
-                i = turn[0] % n_streams
-                turn[0] += 1
-                plans[i].enqueue_all(sides[i].cuda_stream)
+                for p, s_ in zip(plans, sides):
+                    p.enqueue_all(s_.cuda_stream)
 
         def fence():
             torch.cuda.synchronize()
@@ -149,9 +165,9 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(max(args.warmup, n_streams)):
+        for _ in range(max(args.warmup, 1)):
             step()
-        firsts = [p.fetch(s_.cuda_stream) for p, s_ in zip(plans, sides)]
+        firsts = [p.fetch(sides[i % n_streams].cuda_stream) for i, p in enumerate(plans)]
         first = firsts[0]
         fence()
         t0 = time.perf_counter()
@@ -159,7 +175,7 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
-        lasts = [p.fetch(s_.cuda_stream) for p, s_ in zip(plans, sides)]
+        lasts = [p.fetch(sides[i % n_streams].cuda_stream) for i, p in enumerate(plans)]
         last = lasts[0]
         assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
         if world > 1:
@@ -169,13 +185,20 @@ def main():
 
         # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, one query in flight ----
         if world == 1:
-            step = lambda: plan.enqueue_all(st)  # noqa: E731
+            one = lambda: plan.enqueue_all(st)  # noqa: E731
+        elif plan.totals_len:
+            one_buf = torch.zeros(plan.totals_len, dtype=torch.float64, device="cuda")
+            one = ShardedQuery(plan, one_buf, torch_all_reduce(), stream=st).enqueue
+        else:
+            one = sqs[0].enqueue
         plan.set_profiling(True)
-        samples = plan.launch_samples()
+        one()
+        torch.cuda.synchronize()
+        samples = plan.launch_samples()  # launches of the form just executed
         prof_steps = max(10, min(200, args.steps))
         sum_ms = [0.0] * len(samples)
         for _ in range(prof_steps):
-            step()
+            one()
             torch.cuda.synchronize()
             for i, ms in enumerate(plan.launch_ms()):
                 sum_ms[i] += ms
@@ -184,12 +207,13 @@ def main():
         lat = []
         for _ in range(50):
             t1 = time.perf_counter()
-            step()
+            one()
             plan.fetch(st)
             lat.append(time.perf_counter() - t1)
         lat.sort()
 
-    sweeps = len(samples) - (1 if plan.has_topup else 0)  # the top-up launch never fires here: not a sweep
+    # the separate top-up launch never fires in this workload: not a sweep (the batched form has no such launch)
+    sweeps = len(samples) - (1 if (plan.has_topup and len(samples) > 1) else 0)
     launches = sweeps
     avg_launch_ms = sum(sum_ms[:sweeps]) / prof_steps / launches
     visited_local = sum(samples[:sweeps])
@@ -212,7 +236,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "aggregates/sec (10M-row region APPROX SUM/AVG/COUNT with 95% CI, CLT --e 0.01) + achieved HBM GB/s",
-            "value": world * args.steps / dt,
+            "value": world * B * args.steps / dt,
             "unit": "aggregates/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
@@ -225,11 +249,11 @@ def main():
                 "rows_per_gpu": rows, "global_rows": n_global, "sample_percent": pct, "error_percent": e,
                 "pointers": 4 * world, "samples_per_query_per_gpu": int(last.visited if world == 1 else visited_local),
                 "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_query": len(samples),
-                "queries_in_flight": n_streams,
-                "collectives_per_query": (launches if world > 1 else 0),
+                "queries_per_step": B, "streams": n_streams,
+                "collectives_per_step": collectives_per_step,
                 "unit_definition": "one 10M-row region aggregate per GPU per query; a global query over N regions counts N",
             },
-            "global_queries_per_sec": args.steps / dt,
+            "global_queries_per_sec": B * args.steps / dt,
             "closed_loop_latency_us": {"p50": 1e6 * lat[len(lat) // 2], "min": 1e6 * lat[0]},
             "result": {"avg": last.value, "ci": [last.ci_lower, last.ci_upper], "n": int(last.n),
                        "converged": int(last.converged), "rounds": int(last.rounds),

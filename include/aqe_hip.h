@@ -229,6 +229,16 @@ AQE_API int aqe_plan_rounds(const aqe_plan* plan, uint32_t* rounds, int32_t* has
 AQE_API int aqe_plan_enqueue_round(aqe_plan* plan, uint32_t round, double* dev_vec, void* stream);
 AQE_API int aqe_plan_enqueue_update(aqe_plan* plan, uint32_t round, const double* dev_vec, void* stream);
 AQE_API int aqe_plan_enqueue_finalize(aqe_plan* plan, void* stream);
+/* Batched multi-GPU form (plans of 2..31 rounds): ONE launch sweeps every round and the top-up
+ * speculatively and writes this shard's total per slot (aqe_plan_totals_len doubles: AQE_MOMENT_VEC per
+ * slot, rounds in order then the top-up); ONE all-reduce SUM of that vector; aqe_plan_enqueue_replay then
+ * replays the stop rules on the reduced totals, applies the top-up gate and writes the result.  One
+ * collective per query instead of one per convergence step — the stop decision is a pure function of the
+ * reduced per-round totals, so the answer is identical; what is given up is not sweeping the rounds after
+ * the stop.  totals_len == 0: the plan has no batched form (single-round or > 31 rounds). */
+AQE_API int aqe_plan_totals_len(const aqe_plan* plan, uint32_t* n_doubles);
+AQE_API int aqe_plan_enqueue_sweep_totals(aqe_plan* plan, double* dev_totals, void* stream);
+AQE_API int aqe_plan_enqueue_replay(aqe_plan* plan, const double* dev_totals, void* stream);
 /* fused single-GPU form: round + update in one launch (the last workgroup to arrive folds) */
 AQE_API int aqe_plan_enqueue_all(aqe_plan* plan, void* stream);
 AQE_API int aqe_plan_reset(aqe_plan* plan, void* stream); /* re-arm a plan for another execution */

@@ -32,6 +32,9 @@ class OracleShardPlan:
             self.rounds, self.has_topup = len(self.bounds), self.base // 4 > 0
         else:
             self.rounds, self.has_topup = 1, False
+        # batched form: rounds in order then the top-up, VEC doubles per slot (plans of 2..31 rounds)
+        slots = self.rounds + (1 if self.has_topup else 0)
+        self.totals_len = slots * VEC if (self.kind == "clt" and 2 <= self.rounds and slots <= 32) else 0
         self.reset()
 
     def reset(self, stream=0):
@@ -107,6 +110,33 @@ class OracleShardPlan:
 
     def enqueue_finalize(self, stream=0):
         pass
+
+    # ---- batched form: everything swept speculatively, decisions replayed on the reduced totals ----
+    def enqueue_sweep_totals(self, ptr, stream=0):
+        t = np.ctypeslib.as_array((C.c_double * self.totals_len).from_address(ptr)).reshape(-1, VEC)
+        saved = self.st
+        for r in range(self.rounds):
+            self.reset()  # no stop, no gate: every slot is swept
+            self.enqueue_round(r, t[r].ctypes.data)
+        if self.has_topup:
+            self.reset()
+            amt = self.rows["amount"]
+            step = max(1, self.N // (self.base // 4))
+            idx = np.arange(0, self.N, step, dtype=np.int64)[: self.base]
+            idx = idx[(idx >= self.lo) & (idx < self.hi)] - self.lo
+            t[self.rounds, 0:3] = self._shifted(amt[idx]); t[self.rounds, 3:6] = 0
+            t[self.rounds, 6] = len(idx); t[self.rounds, 7] = 0
+        self.st = saved
+
+    def enqueue_replay(self, ptr, stream=0):
+        t = np.ctypeslib.as_array((C.c_double * self.totals_len).from_address(ptr)).reshape(-1, VEC).copy()
+        self.reset()
+        for r in range(self.rounds):
+            if self.st["stop"]:
+                break
+            self.enqueue_update(r, t[r].ctypes.data)
+        if self.has_topup:
+            self.enqueue_update(self.rounds, t[self.rounds].ctypes.data)
 
     def fetch(self, stream=0):
         s = self.st

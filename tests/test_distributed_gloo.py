@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, specs, out_dir):
+def _worker(rank, world, port, n, specs, out_dir, batched=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -39,10 +39,11 @@ def _worker(rank, world, port, n, specs, out_dir):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
         plan = OracleShardPlan(o, rows, lo, n, shift, spec)
-        vec = torch.zeros(8, dtype=torch.float64)
-        res = ShardedQuery(plan, vec, all_reduce).run()
+        vec = torch.zeros(max(8, plan.totals_len), dtype=torch.float64)
+        sq = ShardedQuery(plan, vec, all_reduce, batched=batched)
+        res = sq.run()
         res["collectives"] = calls[0]
-        res["steps"] = plan.rounds + (1 if plan.has_topup else 0)
+        res["steps"] = 1 if sq.batched else plan.rounds + (1 if plan.has_topup else 0)
         results.append(res)
     torch.save(results, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
@@ -57,11 +58,11 @@ SPECS = [
 ]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_query_over_gloo_matches_single_process_oracle(oracle, table, tmp_path, world):
+@pytest.mark.parametrize("world,batched", [(2, False), (3, False), (2, True)])
+def test_sharded_query_over_gloo_matches_single_process_oracle(oracle, table, tmp_path, world, batched):
     n = 200_003
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, SPECS, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, SPECS, str(tmp_path), batched), nprocs=world, join=True)
     per_rank = [torch.load(tmp_path / f"r{r}.pt", weights_only=False) for r in range(world)]
     rows = table(n)
     for i, spec in enumerate(SPECS):
@@ -69,7 +70,7 @@ def test_sharded_query_over_gloo_matches_single_process_oracle(oracle, table, tm
         for g in got[1:]:  # every rank folds the same reduced vector -> identical answers
             assert g == got[0]
         g = got[0]
-        assert g["collectives"] == g["steps"]  # exactly one all-reduce per convergence step (+ top-up)
+        assert g["collectives"] == g["steps"]  # one all-reduce per convergence step (+ top-up), or one per query when batched
         if spec[0] == "stride":
             idx = oracle.idx_memory_stride(n, spec[1])
             m = oracle.moments_idx(rows, idx)

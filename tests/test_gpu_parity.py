@@ -406,6 +406,24 @@ def test_sharded_plan_api_single_gpu_virtual_shards(nat, oracle, table):
                 assert (o_.n, o_.visited, o_.converged, o_.rounds, o_.topup) == (want.n, want.visited, want.converged, want.rounds, want.topup)
                 assert rel(o_.sum, want.sum) <= SUM_TOL and rel(o_.value, want.value) <= EST_TOL
                 assert rel(o_.ci_lower, want.ci_lower) <= EST_TOL
+            # batched form: every slot swept in one launch per shard, ONE reduction, decisions replayed
+            if plans[0].totals_len:
+                assert all(p.totals_len == plans[0].totals_len for p in plans)
+                with torch.cuda.stream(side):
+                    tot = torch.full((G, plans[0].totals_len), float("nan"), dtype=torch.float64, device="cuda")
+                    for g, p in enumerate(plans):
+                        p.enqueue_sweep_totals(tot[g].data_ptr(), st)
+                    red = tot.sum(0)
+                    outs = []
+                    for p in plans:
+                        p.enqueue_replay(red.data_ptr(), st)
+                        outs.append(p.fetch(st))
+                for o_ in outs:
+                    assert (o_.n, o_.visited, o_.converged, o_.rounds, o_.topup) == (want.n, want.visited, want.converged, want.rounds, want.topup)
+                    assert rel(o_.sum, want.sum) <= SUM_TOL and rel(o_.value, want.value) <= EST_TOL
+                    assert rel(o_.ci_lower, want.ci_lower) <= EST_TOL and o_.device_status == 0
+            else:
+                assert q.method != nat.M_CLT_DUAL_POINTER
             for p in plans:
                 p.close()
         for e in engs:
