@@ -44,6 +44,7 @@ struct aqe_ctx {
     aqe_record* aos = nullptr;
     bool owns_table = true;
     bool staged = false;
+    bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
     uint64_t n_global = 0, shard_lo = 0, n_local = 0;
     double shift = 0.0;
     uint64_t hbm_bytes = 0;
@@ -172,8 +173,10 @@ int alloc_table(aqe_ctx* c, uint64_t n_local, bool keep_aos) {
     free_table(c);
     drop_cache(c);
     if (n_local == 0) return AQE_OK;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->amount), n_local * sizeof(double)));
-    c->hbm_bytes = n_local * sizeof(double);
+    // one spare double behind the column: the 16-byte dense loads park masked lanes on rows 0..1
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->amount), (n_local + 1) * sizeof(double)));
+    c->hbm_bytes = (n_local + 1) * sizeof(double);
+    c->dense16 = true;
     if (keep_aos) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->aos), n_local * sizeof(aqe_record)));
         c->hbm_bytes += n_local * sizeof(aqe_record);
@@ -182,7 +185,7 @@ int alloc_table(aqe_ctx* c, uint64_t n_local, bool keep_aos) {
 }
 
 // Tile decomposition of one family window (kernels.hpp: one wave folds kTileOrdinals per tile).
-void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f, uint64_t& out_pos) {
+void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f, uint64_t& out_pos, bool dense16) {
     if (f.ord_hi <= f.ord_lo) return;
     DevFamily d{};
     d.row0 = f.row0; d.pitch = f.pitch; d.seg_len = f.seg_len; d.step = f.step;
@@ -195,15 +198,16 @@ void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f,
         win_hi = std::max(win_hi, f.ord_hi_b);
         size_b = f.ord_hi_b - f.ord_lo_b;
     }
+    const uint64_t tile = dense16 ? tile_ordinals(f.step, f.flags) : kTileOrdinals;
     const uint64_t s_lo = win_lo / f.seg_len, s_hi = (win_hi - 1) / f.seg_len;
     uint64_t ntiles;
     d.seg_lo = s_lo;
     if (s_lo == s_hi) {
         d.tiles_per_seg = 0;
-        d.j_lo = (win_lo % f.seg_len) / kTileOrdinals;
-        ntiles = ((win_hi - 1) % f.seg_len) / kTileOrdinals + 1 - d.j_lo;
+        d.j_lo = (win_lo % f.seg_len) / tile;
+        ntiles = ((win_hi - 1) % f.seg_len) / tile + 1 - d.j_lo;
     } else {
-        d.tiles_per_seg = (f.seg_len + kTileOrdinals - 1) / kTileOrdinals;
+        d.tiles_per_seg = (f.seg_len + tile - 1) / tile;
         d.j_lo = 0;
         ntiles = (s_hi - s_lo + 1) * d.tiles_per_seg;
     }
@@ -252,6 +256,7 @@ SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam
     s.wmin = p->q.where_min;
     s.wmax = p->q.where_max;
     s.shift = c->shift;
+    s.dense16 = c->dense16 ? 1 : 0;
     return s;
 }
 
@@ -375,7 +380,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     for (const auto& rf : p->host.round_fams) {
         LaunchDesc L;
         L.fam_offset = p->h_fams.size();
-        for (const auto& f : rf) add_family(p->h_fams, L, f, out_pos);
+        for (const auto& f : rf) add_family(p->h_fams, L, f, out_pos, c->dense16);
         p->rounds.push_back(L);
     }
     if (p->host.is_random) {
@@ -385,7 +390,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     }
     if (p->host.has_topup) {
         p->topup.fam_offset = p->h_fams.size();
-        for (const auto& f : p->host.topup_fams) add_family(p->h_fams, p->topup, f, out_pos);
+        for (const auto& f : p->host.topup_fams) add_family(p->h_fams, p->topup, f, out_pos, c->dense16);
     }
     if (!p->h_fams.empty()) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams), p->h_fams.size() * sizeof(DevFamily)));
@@ -770,6 +775,7 @@ int aqe_attach_device(aqe_ctx* c, const double* dev_amount, const void* dev_aos3
     free_table(c);
     drop_cache(c);
     c->owns_table = false;
+    c->dense16 = n_local >= 2;  // caller-owned memory has no spare row
     c->staged = true;
     c->amount = const_cast<double*>(dev_amount);
     c->aos = static_cast<aqe_record*>(const_cast<void*>(dev_aos32));
@@ -1084,7 +1090,7 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
     } else {
         for (uint32_t r = 0; r < rounds_used && e == hipSuccess; ++r) {
             const LaunchDesc& L = p->rounds[r];
-            if (L.nfam) e = launch_gather(c->aos, c->shard_lo, p->d_fams + L.fam_offset, L.nfam, L.ntiles, d_out, c->stream);
+            if (L.nfam) e = launch_gather(c->aos, c->shard_lo, p->d_fams + L.fam_offset, L.nfam, L.ntiles, d_out, c->dense16, c->stream);
         }
         if (e == hipSuccess && topup_rows) {
             // the top-up is one strided family from row 0; keep its first `topup_rows` ordinals and place
@@ -1100,7 +1106,7 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
             DevFamily* d_tf = nullptr;
             e = hipMalloc(reinterpret_cast<void**>(&d_tf), tf.size() * sizeof(DevFamily));
             if (e == hipSuccess) e = hipMemcpy(d_tf, tf.data(), tf.size() * sizeof(DevFamily), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = launch_gather(c->aos, c->shard_lo, d_tf, static_cast<uint32_t>(tf.size()), p->topup.ntiles, d_out, c->stream);
+            if (e == hipSuccess) e = launch_gather(c->aos, c->shard_lo, d_tf, static_cast<uint32_t>(tf.size()), p->topup.ntiles, d_out, c->dense16, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (d_tf) (void)hipFree(d_tf);
         }

@@ -236,6 +236,37 @@ __device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u6
     const u64 ord_lo = F.ord_lo;
     const u64 ord_hi = (F.flags & AQE_F_TOPUP) ? (F.ord_hi < ord_limit ? F.ord_hi : ord_limit) : F.ord_hi;
     const double* base = a.amount + (F.row0 + seg * F.pitch - a.shard_lo);
+
+    if (a.dense16 && step == 1 && !(F.flags & AQE_F_PAIR)) {
+        // Dense segment (blocks, pages, exact scans): two consecutive rows per lane per 16-byte load, eight loads in
+        // flight — 1 KiB per wave instruction, the widest coalesced access.  Rows are only 8-byte aligned, which
+        // global loads allow.  An ordinal pair never straddles the segment end unless masked.
+        struct __attribute__((packed, aligned(8))) Row2 { double x, y; };
+        const u64 oi0d = j * kDenseTileOrdinals + 2 * static_cast<u64>(lane);
+        const bool group_bd = F.group != 0;
+        Row2 v2[kTileUnroll];
+        bool ok0[kTileUnroll], ok1[kTileUnroll];
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) {
+            const u64 oi = oi0d + static_cast<u64>(k) * 128;
+            const u64 o = seg_ord0 + oi;
+            ok0[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
+            ok1[k] = oi + 1 < seg_len && o + 1 >= ord_lo && o + 1 < ord_hi;
+            // both rows must be readable: fall back to row 0/1 of the shard when the pair leaves the window
+            const bool both = ok0[k] && ok1[k];
+            const Row2* p = reinterpret_cast<const Row2*>(both ? base + oi : a.amount);
+            v2[k] = *p;
+            if (!both) {  // window edge (at most one lane per tile side): single 8-byte reads
+                v2[k].x = ok0[k] ? base[oi] : 0.0;
+                v2[k].y = ok1[k] ? base[oi + 1] : 0.0;
+            }
+        }
+        TileAcc ta;
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) { accumulate(ta, v2[k].x, ok0[k], a); accumulate(ta, v2[k].y, ok1[k], a); }
+        merge_tile(acc, ta, group_bd);
+        return;
+    }
     const u64 oi0 = j * kTileOrdinals + lane;
 
     if (F.flags & AQE_F_PAIR) {

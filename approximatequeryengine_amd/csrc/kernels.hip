@@ -235,7 +235,7 @@ __global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* ou
 // ---- record-returning samplers: gather 32-byte rows ---------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __restrict__ aos, u64 shard_lo,
                                                           const DevFamily* __restrict__ fams, unsigned nfam,
-                                                          u64 ntiles, aqe_record* __restrict__ out) {
+                                                          u64 ntiles, aqe_record* __restrict__ out, int dense16) {
     const int lane = threadIdx.x & 63;
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
     const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
@@ -255,9 +255,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __re
         const u64 seg_ord0 = seg * F.seg_len;
         const u64 row_base = F.row0 + seg * F.pitch - shard_lo;
         const bool pair = (F.flags & AQE_F_PAIR) != 0;
+        const u64 tile = (dense16 && F.step == 1 && !pair) ? kDenseTileOrdinals : kTileOrdinals;
+        for (u64 half = 0; half * kTileOrdinals < tile; ++half)
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) {
-            const u64 oi = j * kTileOrdinals + lane + static_cast<u64>(k) * 64;
+            const u64 oi = j * tile + half * kTileOrdinals + lane + static_cast<u64>(k) * 64;
             const u64 o = seg_ord0 + oi;
             if (oi < F.seg_len && o >= F.ord_lo && o < F.ord_hi) {
                 const u64 row = row_base + oi * F.step;
@@ -367,11 +369,11 @@ hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe
 }
 
 hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFamily* fams, uint32_t nfam,
-                         uint64_t ntiles, aqe_record* out, hipStream_t s) {
+                         uint64_t ntiles, aqe_record* out, int dense16, hipStream_t s) {
     if (ntiles == 0) return hipSuccess;
     unsigned grid = grid_for(ntiles, kWavesPerBlock);
     hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlockThreads), 0, s, aos, static_cast<u64>(shard_lo), fams, nfam,
-                       static_cast<u64>(ntiles), out);
+                       static_cast<u64>(ntiles), out, dense16);
     return hipGetLastError();
 }
 

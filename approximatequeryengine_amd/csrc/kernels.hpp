@@ -13,6 +13,10 @@ constexpr int kBlockThreads = 256;          // 4 wave64 per workgroup
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr int kTileUnroll = 8;              // loads in flight per lane
 constexpr int kTileOrdinals = 64 * kTileUnroll;  // ordinals one wave folds per tile
+// Dense families (step 1, single pointer: blocks, pages, exact scans) are swept with 16-byte loads, two
+// rows per lane per load: their tiles are twice as long.
+constexpr int kDenseTileOrdinals = 2 * kTileOrdinals;
+inline uint64_t tile_ordinals(uint64_t step, uint32_t flags) { return (step == 1 && !(flags & AQE_F_PAIR)) ? kDenseTileOrdinals : kTileOrdinals; }
 constexpr int kMaxBlocks = 2048;            // 8 workgroups per CU on 256 CUs
 constexpr int kVec = AQE_MOMENT_VEC;
 // Arrival tickets are sharded: a same-address device atomic costs ~20 ns and serialises, so 2048
@@ -76,6 +80,8 @@ struct SweepCommon {
     int32_t has_where;
     double wmin, wmax;
     double shift;           // c of the shifted sums
+    int32_t dense16;        // 16-byte loads allowed on dense families (rows 0..1 of the column are readable)
+    int32_t pad;
 };
 
 struct RoundLaunch {
@@ -146,7 +152,7 @@ hipError_t launch_update(QueryState* state, const double* vec, const FoldParams&
 hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe_result* out, hipStream_t s);
 
 hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFamily* fams, uint32_t nfam,
-                         uint64_t ntiles, aqe_record* out, hipStream_t s);
+                         uint64_t ntiles, aqe_record* out, int dense16, hipStream_t s);
 hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const uint64_t* idx, uint64_t n,
                                  aqe_record* out, hipStream_t s);
 
