@@ -13,7 +13,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_TABLE, ERR_IO, ERR_CAPACITY, ERR
 
 M_EXACT, M_MEMORY_STRIDE, M_ADDRESS_ARITHMETIC, M_RANDOM_POINTER, M_BLOCK, M_PAGE, M_PARALLEL_BLOCK = range(7)
 M_OPTIMIZED_CLT, M_CLT_DUAL_POINTER, M_FAST_POINTER, M_SLOW_POINTER, M_DUAL_POINTER = 7, 8, 9, 10, 11
-M_PARALLEL_POINTER, M_REGION_STRIDE = 12, 13
+M_PARALLEL_POINTER, M_REGION_STRIDE, M_RANDOM_START_STRIDE = 12, 13, 14
 
 SUM, AVG, COUNT = 0, 1, 2
 EST_CLI, EST_CPP, EST_RAW = 0, 1, 2
@@ -33,7 +33,7 @@ class Query(C.Structure):
         ("confidence_level", C.c_double), ("max_error_percent", C.c_double), ("has_where", C.c_int32),
         ("reserved0", C.c_int32), ("where_min", C.c_double), ("where_max", C.c_double),
         ("clt_round0", C.c_uint64), ("clt_growth", C.c_uint32), ("flags", C.c_uint32),
-        ("visible_rows", C.c_uint64),
+        ("visible_rows", C.c_uint64), ("row_lo", C.c_uint64), ("row_hi", C.c_uint64),
     ]
 
 
@@ -104,6 +104,7 @@ def lib() -> C.CDLL:
         "aqe_attach_device": (C.c_int, [vp, vp, vp, u64, u64, u64, dbl]),
         "aqe_set_shift": (C.c_int, [vp, dbl]),
         "aqe_table_info_get": (C.c_int, [vp, P(TableInfo)]),
+        "aqe_key_range_rows": (C.c_int, [vp, C.c_int64, C.c_int64, P(u64), P(u64)]),
         "aqe_release_table": (C.c_int, [vp]),
         "aqe_query_defaults": (None, [P(Query)]),
         "aqe_plan_families": (C.c_int, [P(Query), u64, u64, u64, u32, P(Family), u32, P(u32), P(u32), P(u64)]),

@@ -101,7 +101,7 @@ _AGG = {"SUM": nat.SUM, "AVG": nat.AVG, "COUNT": nat.COUNT}
 _OUT_OF_SCOPE = (
     "optimized_sequential_sample", "index_based_sample", "node_skip_sample", "balanced_tree_sample",
     "direct_access_sample", "byte_offset_sample", "random_start_nth_sample", "address_arithmetic_sample",
-    "random_start_memory_stride_sample", "signal_based_clt_sample", "adaptive_block_sample", "stratified_block_sample",
+    "signal_based_clt_sample", "adaptive_block_sample", "stratified_block_sample",
 )
 
 
@@ -283,6 +283,11 @@ class CustomBPlusDB:
     def memory_stride_sample(self, sample_percent, stride_bytes=0, *, as_array=False):
         return self._gather(make_query(nat.M_MEMORY_STRIDE, sample_percent, stride_bytes=int(stride_bytes)), as_array)
 
+    def random_start_memory_stride_sample(self, sample_percent, stride_bytes=0, *, seed=None, as_array=False):
+        """custom_bplus_db.cpp:1838-1878; the reference draws the start from std::random_device, here it is seeded."""
+        seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
+        return self._gather(make_query(nat.M_RANDOM_START_STRIDE, sample_percent, stride_bytes=int(stride_bytes), seed=seed), as_array)
+
     def optimized_address_arithmetic_sample(self, sample_percent, *, as_array=False):
         return self._gather(make_query(nat.M_ADDRESS_ARITHMETIC, sample_percent), as_array)
 
@@ -366,7 +371,7 @@ class CustomBPlusDB:
     def approx(self, agg: str, method: str = "stride", sample_percent: float = 10.0, error_percent: Optional[float] = None,
                where: Optional[Tuple[float, float]] = None, seed: int = 42, num_threads: int = 4, block_size: int = 1000,
                confidence_level: float = 0.95, check_interval: int = 10, round0: int = 4096, growth: int = 4,
-               convention: str = "cli") -> ApproxResult:
+               convention: str = "cli", id_between: Optional[Tuple[int, int]] = None) -> ApproxResult:
         """APPROX <agg>(amount): method in {"stride","random","block","page","parallel_block","region","clt","exact"}.
         ``error_percent`` (CLT) is in percent, as the reference CLI's --e (enhanced_aqe_cli.py:414-415); the
         sample percentage then follows enhanced_aqe_cli.py:243-250."""
@@ -374,16 +379,23 @@ class CustomBPlusDB:
         conv = {"cli": nat.EST_CLI, "cpp": nat.EST_CPP, "raw": nat.EST_RAW}[convention]
         if self._n == 0:
             raise RuntimeError("No samples collected")  # enhanced_aqe_cli.py:226-228
+        rows = None
+        if id_between is not None:  # B+-tree key bounds -> row window (the pruning search_range never got, DB.hpp:45)
+            rows = self._eng().key_range_rows(int(id_between[0]), int(id_between[1]))
+            if rows[1] <= rows[0]:
+                raise RuntimeError("No samples collected")
         if method == "clt":
             e = 2.0 if error_percent is None else float(error_percent)
             pct = nat.lib().aqe_error_to_sample_percent(e)
             q = self._clt_query(pct, confidence_level, check_interval, num_threads, e, round0, growth, a)
+            if rows:
+                q.row_lo, q.row_hi = rows
         else:
             m = {"stride": nat.M_MEMORY_STRIDE, "random": nat.M_RANDOM_POINTER, "block": nat.M_BLOCK, "page": nat.M_PAGE,
                  "parallel_block": nat.M_PARALLEL_BLOCK, "region": nat.M_REGION_STRIDE, "exact": nat.M_EXACT}[method]
             bs = 4096 if (method == "page" and block_size == 1000) else block_size
             q = make_query(m, sample_percent, agg=a, convention=conv, where=where, seed=int(seed),
-                           num_threads=int(num_threads), block_size=int(bs))
+                           num_threads=int(num_threads), block_size=int(bs), rows=rows)
         res = self._reduce(q)
         if res.visited == 0:
             raise RuntimeError("No samples collected")

@@ -44,6 +44,8 @@ struct aqe_ctx {
     aqe_record* aos = nullptr;
     bool owns_table = true;
     bool staged = false;
+    bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
+    int64_t first_id = 0;
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
     uint64_t n_global = 0, shard_lo = 0, n_local = 0;
     double shift = 0.0;
@@ -137,6 +139,8 @@ void free_table(aqe_ctx* c) {
     c->aos = nullptr;
     c->owns_table = true;
     c->staged = false;
+    c->ids_dense = false;
+    c->first_id = 0;
     c->n_global = c->shard_lo = c->n_local = 0;
     c->hbm_bytes = 0;
     c->table_epoch++;
@@ -198,7 +202,7 @@ void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f,
         win_hi = std::max(win_hi, f.ord_hi_b);
         size_b = f.ord_hi_b - f.ord_lo_b;
     }
-    const uint64_t tile = dense16 ? tile_ordinals(f.step, f.flags) : kTileOrdinals;
+    const uint64_t tile = dense16 ? tile_ordinals(f.step, f.flags, f.seg_len) : kTileOrdinals;
     const uint64_t s_lo = win_lo / f.seg_len, s_hi = (win_hi - 1) / f.seg_len;
     uint64_t ntiles;
     d.seg_lo = s_lo;
@@ -235,7 +239,7 @@ FoldParams fold_params(const aqe_plan* p, bool topup) {
 
 FinalizeParams finalize_params(const aqe_plan* p) {
     FinalizeParams f{};
-    f.n_global = p->ctx->n_global;
+    f.n_global = p->q.row_hi > p->q.row_lo ? p->q.row_hi - p->q.row_lo : p->ctx->n_global;  // a row window is the table
     f.pct = p->q.sample_percent;
     f.shift = p->ctx->shift;
     f.agg = p->q.agg;
@@ -573,11 +577,14 @@ int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64
         HIPCHK(c, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
     }
     int status = AQE_OK;
+    bool dense_ids = true;
+    const int64_t id0 = rows[0].id;
     for (uint64_t off = 0, k = 0; off < n_local && status == AQE_OK; off += kStageChunkRows, ++k) {
         const int b = static_cast<int>(k & 1);
         const uint64_t m = std::min<uint64_t>(kStageChunkRows, n_local - off);
         if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) { status = fail(c, AQE_ERR_HIP, "event sync"); break; }
         hipError_t e;
+        for (uint64_t i = 0; dense_ids && i < m; ++i) dense_ids = rows[off + i].id == id0 + static_cast<int64_t>(off + i);
         if (keep) {
             std::memcpy(pinned[b], rows + off, m * sizeof(aqe_record));
             e = hipMemcpyAsync(c->aos + off, pinned[b], m * sizeof(aqe_record), hipMemcpyHostToDevice, c->stream);
@@ -596,7 +603,9 @@ int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64
         if (pinned[b]) (void)hipHostFree(pinned[b]);
         if (done[b]) (void)hipEventDestroy(done[b]);
     }
-    if (status != AQE_OK) free_table(c);
+    if (status != AQE_OK) { free_table(c); return status; }
+    c->ids_dense = dense_ids;
+    c->first_id = id0 - static_cast<int64_t>(shard_lo);  // id of global row 0 when the ids are dense
     return status;
 }
 
@@ -762,6 +771,8 @@ int aqe_generate_synthetic(aqe_ctx* c, uint64_t n_local, uint64_t shard_lo, uint
         }
         c->shift = m ? acc / static_cast<double>(m) : 0.0;
     }
+    c->ids_dense = true;  // id = row + 1
+    c->first_id = 1;
     HIPCHK(c, launch_synth(c->aos, c->amount, n_local, shard_lo, seed, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AQE_OK;
@@ -802,6 +813,34 @@ int aqe_table_info_get(const aqe_ctx* c, aqe_table_info* out) {
     out->has_aos = c->aos != nullptr;
     out->device_id = c->device;
     out->hbm_bytes = c->hbm_bytes;
+    return AQE_OK;
+}
+
+int aqe_key_range_rows(aqe_ctx* c, int64_t id_min, int64_t id_max, uint64_t* row_lo, uint64_t* row_hi) {
+    if (!c || !row_lo || !row_hi) return AQE_ERR_INVALID;
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    HIPCHK(c, hipSetDevice(c->device));
+    *row_lo = *row_hi = 0;
+    if (id_max < id_min || c->n_global == 0) return AQE_OK;
+    if (c->ids_dense) {  // id = first_id + row
+        const int64_t last = c->first_id + static_cast<int64_t>(c->n_global) - 1;
+        if (id_max < c->first_id || id_min > last) return AQE_OK;
+        *row_lo = static_cast<uint64_t>(std::max(id_min, c->first_id) - c->first_id);
+        *row_hi = static_cast<uint64_t>(std::min(id_max, last) - c->first_id) + 1;
+        return AQE_OK;
+    }
+    if (c->shard_lo != 0 || c->n_local != c->n_global) return fail(c, AQE_ERR_UNSUPPORTED, "key bounds on a shard need dense ids");
+    if (!c->aos) return fail(c, AQE_ERR_UNSUPPORTED, "key bounds on non-dense ids need the rows resident (AQE_STAGE_KEEP_AOS)");
+    uint64_t* d_out = nullptr;
+    uint64_t h_out[2] = {0, 0};
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof h_out));
+    hipError_t e = launch_id_bounds(c->aos, c->n_local, id_min, id_max, d_out, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("key bounds: ") + hipGetErrorString(e));
+    *row_lo = h_out[0];
+    *row_hi = std::max(h_out[0], h_out[1]);
     return AQE_OK;
 }
 

@@ -237,7 +237,7 @@ __device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u6
     const u64 ord_hi = (F.flags & AQE_F_TOPUP) ? (F.ord_hi < ord_limit ? F.ord_hi : ord_limit) : F.ord_hi;
     const double* base = a.amount + (F.row0 + seg * F.pitch - a.shard_lo);
 
-    if (a.dense16 && step == 1 && !(F.flags & AQE_F_PAIR)) {
+    if (a.dense16 && is_dense16(step, F.flags, seg_len)) {
         // Dense segment (blocks, pages, exact scans): two consecutive rows per lane per 16-byte load, eight loads in
         // flight — 1 KiB per wave instruction, the widest coalesced access.  Rows are only 8-byte aligned, which
         // global loads allow.  An ordinal pair never straddles the segment end unless masked.

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __re
         const u64 seg_ord0 = seg * F.seg_len;
         const u64 row_base = F.row0 + seg * F.pitch - shard_lo;
         const bool pair = (F.flags & AQE_F_PAIR) != 0;
-        const u64 tile = (dense16 && F.step == 1 && !pair) ? kDenseTileOrdinals : kTileOrdinals;
+        const u64 tile = (dense16 && is_dense16(F.step, F.flags, F.seg_len)) ? kDenseTileOrdinals : kTileOrdinals;
         for (u64 half = 0; half * kTileOrdinals < tile; ++half)
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) {
@@ -291,6 +291,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather_indexed(const aqe_reco
         dst[2 * i] = a;
         dst[2 * i + 1] = b;
     }
+}
+
+// B+-tree key bounds: first row whose id is >= key[0] and first row whose id is > key[1] (ids ascend in leaf
+// order).  Two independent bisections, one lane each.
+__global__ void k_id_bounds(const aqe_record* __restrict__ aos, u64 n, long long id_min, long long id_max, u64* out) {
+    if (blockIdx.x != 0 || threadIdx.x > 1) return;
+    const bool upper = threadIdx.x == 1;
+    u64 a = 0, b = n;
+    while (a < b) {
+        const u64 mid = a + (b - a) / 2;
+        const long long id = aos[mid].id;
+        const bool go_right = upper ? id <= id_max : id < id_min;
+        if (go_right) a = mid + 1; else b = mid;
+    }
+    out[threadIdx.x] = a;
 }
 
 // ---- staging ------------------------------------------------------------------------------------
@@ -383,6 +398,12 @@ hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const
     unsigned grid = grid_for(n, kBlockThreads);
     hipLaunchKernelGGL(k_gather_indexed, dim3(grid), dim3(kBlockThreads), 0, s, aos, static_cast<u64>(shard_lo), idx,
                        static_cast<u64>(n), out);
+    return hipGetLastError();
+}
+
+hipError_t launch_id_bounds(const aqe_record* aos, uint64_t n, int64_t id_min, int64_t id_max, uint64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_id_bounds, dim3(1), dim3(64), 0, s, aos, static_cast<u64>(n), static_cast<long long>(id_min),
+                       static_cast<long long>(id_max), reinterpret_cast<u64*>(out));
     return hipGetLastError();
 }
 

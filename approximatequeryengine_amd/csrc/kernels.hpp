@@ -16,7 +16,9 @@ constexpr int kTileOrdinals = 64 * kTileUnroll;  // ordinals one wave folds per 
 // Dense families (step 1, single pointer: blocks, pages, exact scans) are swept with 16-byte loads, two
 // rows per lane per load: their tiles are twice as long.
 constexpr int kDenseTileOrdinals = 2 * kTileOrdinals;
-inline uint64_t tile_ordinals(uint64_t step, uint32_t flags) { return (step == 1 && !(flags & AQE_F_PAIR)) ? kDenseTileOrdinals : kTileOrdinals; }
+// (short segments — pages of 128 rows — keep the 512-ordinal tile: a long tile would idle most of the wave)
+__host__ __device__ inline bool is_dense16(uint64_t step, uint32_t flags, uint64_t seg_len) { return step == 1 && !(flags & AQE_F_PAIR) && seg_len >= static_cast<uint64_t>(kTileOrdinals); }
+inline uint64_t tile_ordinals(uint64_t step, uint32_t flags, uint64_t seg_len) { return is_dense16(step, flags, seg_len) ? kDenseTileOrdinals : kTileOrdinals; }
 constexpr int kMaxBlocks = 2048;            // 8 workgroups per CU on 256 CUs
 constexpr int kVec = AQE_MOMENT_VEC;
 // Arrival tickets are sharded: a same-address device atomic costs ~20 ns and serialises, so 2048
@@ -156,6 +158,7 @@ hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFami
 hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const uint64_t* idx, uint64_t n,
                                  aqe_record* out, hipStream_t s);
 
+hipError_t launch_id_bounds(const aqe_record* aos, uint64_t n, int64_t id_min, int64_t id_max, uint64_t* out, hipStream_t s);
 hipError_t launch_split_amount(const aqe_record* aos, double* amount, uint64_t n, hipStream_t s);
 hipError_t launch_synth(aqe_record* aos_or_null, double* amount, uint64_t n, uint64_t first_row, uint64_t seed,
                         hipStream_t s);

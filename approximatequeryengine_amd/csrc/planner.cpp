@@ -167,7 +167,25 @@ int random_pointer_indices(u64 N, double pct, uint32_t seed, ClipWindow shard, s
     return AQE_OK;
 }
 
+static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err);
+
+// Row window (key-range pruning): plan over the window as if it were the whole table, then shift.
 int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err) {
+    if (q.row_hi <= q.row_lo) return build_plan_whole(q, N, shard, P, err);
+    if (q.row_hi > N) AQE_FAIL("row window exceeds the table");
+    const u64 lo = q.row_lo, n = q.row_hi - q.row_lo;
+    auto rebase = [&](u64 x) { return x <= lo ? 0 : std::min(x - lo, n); };
+    aqe_query inner = q;
+    inner.row_lo = inner.row_hi = 0;
+    int rc = build_plan_whole(inner, n, ClipWindow{rebase(shard.lo), rebase(shard.hi)}, P, err);
+    if (rc != AQE_OK) return rc;
+    for (auto& rf : P.round_fams) for (auto& f : rf) { f.row0 += lo; if (f.flags & AQE_F_PAIR) f.row0_b += lo; }
+    for (auto& f : P.topup_fams) f.row0 += lo;
+    for (auto& i : P.random_idx) i += lo;
+    return AQE_OK;
+}
+
+static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err) {
     P = HostPlan{};
     P.pct = q.sample_percent;
     shard.lo = std::min(shard.lo, N);
@@ -200,6 +218,16 @@ int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::st
             u64 stride = q.stride_bytes == 0 ? std::max<u64>(1, M / static_cast<u64>(target))
                                              : std::max<u64>(1, q.stride_bytes / sizeof(aqe_record));
             fams.push_back(strided(0, stride, std::min<u64>(static_cast<u64>(target), ceil_div(M, stride))));
+            return finish_single();
+        }
+        case AQE_M_RANDOM_START_STRIDE: {  // DB.cpp:1838-1878: the stride sampler from a random row in [0, stride)
+            if (M == 0) return finish_single();
+            int target = target_of(M, pct);
+            if (target <= 0) return finish_single();
+            u64 stride = q.stride_bytes == 0 ? std::max<u64>(1, M / static_cast<u64>(target))
+                                             : std::max<u64>(1, q.stride_bytes / sizeof(aqe_record));
+            u64 start = splitmix64_at(q.seed, 0) % stride;  // uniform_int_distribution(0, stride-1), seeded
+            fams.push_back(strided(start, stride, std::min<u64>(static_cast<u64>(target), prog_count(start, M, stride))));
             return finish_single();
         }
         case AQE_M_ADDRESS_ARITHMETIC: {  // DB.cpp:1667-1703

@@ -167,6 +167,12 @@ class Engine:
         self._chk(nat.lib().aqe_table_info_get(self._h, C.byref(t)))
         return t
 
+    def key_range_rows(self, id_min: int, id_max: int) -> Tuple[int, int]:
+        """Row window [lo, hi) of `id BETWEEN id_min AND id_max` (rows are in ascending-id leaf order)."""
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._chk(nat.lib().aqe_key_range_rows(self._h, id_min, id_max, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
     # -- hot path --
     def reduce(self, query: Query) -> Result:
         res = Result()
@@ -191,7 +197,10 @@ class Engine:
 def make_query(method: int, sample_percent: float = 10.0, agg: int = nat.SUM, convention: int = nat.EST_CLI,
                where: Optional[Tuple[float, float]] = None, **kw) -> Query:
     """aqe_query with the reference's defaults (bindings.cpp:56-101) plus overrides."""
+    rows = kw.pop("rows", None)
     q = nat.default_query(method=method, sample_percent=float(sample_percent), agg=agg, convention=convention, **kw)
+    if rows is not None:
+        q.row_lo, q.row_hi = int(rows[0]), int(rows[1])
     if where is not None:
         q.has_where, q.where_min, q.where_max = 1, float(where[0]), float(where[1])
     return q

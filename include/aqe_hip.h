@@ -72,8 +72,9 @@ typedef enum aqe_method {
     AQE_M_SLOW_POINTER = 10,      /* slow_pointer_sample                    DB.cpp:760-780   */
     AQE_M_DUAL_POINTER = 11,      /* dual_pointer_sample                    DB.cpp:782-813   */
     AQE_M_PARALLEL_POINTER = 12,  /* parallel_pointer_sample                DB.cpp:815-854   */
-    AQE_M_REGION_STRIDE = 13      /* multithreaded_memory_stride_sample / fast_aggregated_memory_stride_sum,
+    AQE_M_REGION_STRIDE = 13,     /* multithreaded_memory_stride_sample / fast_aggregated_memory_stride_sum,
                                      DB.cpp:1880-2048, with a seeded counter-based start per region */
+    AQE_M_RANDOM_START_STRIDE = 14 /* random_start_memory_stride_sample, DB.cpp:1838-1878, seeded start in [0, stride) */
 } aqe_method;
 
 typedef enum aqe_agg { AQE_SUM = 0, AQE_AVG = 1, AQE_COUNT = 2 } aqe_agg;
@@ -106,6 +107,9 @@ typedef struct aqe_query {
     uint32_t flags;           /* AQE_Q_*                                                         */
     uint64_t visible_rows;    /* M of the cached samplers; 0 = global_rows (the
                                  reference's stale-cache quirk DB.cpp:188-191 is not reproduced)  */
+    uint64_t row_lo, row_hi;  /* row_hi > row_lo: the sampler runs over rows [row_lo, row_hi) only, as if they
+                                 were the whole table (key-range pruning: see aqe_key_range_rows); N in the
+                                 estimators is then row_hi - row_lo                                */
 } aqe_query;
 
 #define AQE_Q_NO_TOPUP 1u   /* CLT: skip the systematic top-up of DB.cpp:1031-1040 */
@@ -184,6 +188,11 @@ AQE_API int aqe_attach_device(aqe_ctx* ctx, const double* dev_amount, const void
                               uint64_t n_local, uint64_t shard_lo, uint64_t n_global, double shift);
 AQE_API int aqe_set_shift(aqe_ctx* ctx, double shift); /* all shards of one table must agree */
 AQE_API int aqe_table_info_get(const aqe_ctx* ctx, aqe_table_info* out);
+/* B+-tree key bounds -> row interval.  Rows are in ascending-id leaf order (DB.cpp:715-735), so
+ * `WHERE id BETWEEN id_min AND id_max` is the row window [*row_lo, *row_hi) — what the reference's declared but
+ * never defined BPlusTreeNode::search_range (DB.hpp:45) would have pruned to.  Needs the whole table in this
+ * context, and either dense ids (id = first_id + row, detected at staging) or the rows resident (KEEP_AOS). */
+AQE_API int aqe_key_range_rows(aqe_ctx* ctx, int64_t id_min, int64_t id_max, uint64_t* row_lo, uint64_t* row_hi);
 AQE_API int aqe_release_table(aqe_ctx* ctx);
 
 /* ---- host-side planning (no GPU needed) ------------------------------------------------------ */

@@ -76,6 +76,22 @@ int64_t aqo_idx_memory_stride(uint64_t M, double pct, uint64_t stride_bytes, uin
     return s.n;
 }
 
+/* DB.cpp:1838-1878: memory_stride_sample from a random first row in [0, stride).  The reference draws the
+ * start from mt19937(random_device); start_override replays a recorded draw, otherwise the start is the
+ * product's seeded one, splitmix64_at(seed, 0) % stride. */
+int64_t aqo_idx_random_start_stride(uint64_t M, double pct, uint64_t stride_bytes, uint64_t seed,
+                                    const uint64_t* start_override, uint64_t* out, int64_t cap) {
+    sink s = {out, cap, 0};
+    if (M == 0) return 0;
+    int target = target_of(M, pct);
+    if (target <= 0) return 0;
+    uint64_t stride = stride_bytes == 0 ? umax(1, M / (uint64_t)target)
+                                        : umax(1, stride_bytes / sizeof(aqo_record));
+    uint64_t start = start_override ? *start_override : aqo_splitmix64_at(seed, 0) % stride;
+    for (uint64_t off = start; (uint64_t)s.n < (uint64_t)target && off < M; off += stride) emit(&s, off);
+    return s.n;
+}
+
 /* DB.cpp:1667-1703: indices i*stride, i < target, kept when < M. */
 int64_t aqo_idx_address_arithmetic(uint64_t M, double pct, uint64_t* out, int64_t cap) {
     sink s = {out, cap, 0};

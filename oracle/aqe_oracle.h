@@ -49,6 +49,8 @@ void aqo_synth_fill(aqo_record* rows, uint64_t first_row, uint64_t n, uint64_t s
  *      reference would return, or -1 where the reference itself divides by zero / loops forever. */
 int64_t aqo_idx_memory_stride(uint64_t M, double pct, uint64_t stride_bytes, uint64_t* out, int64_t cap);
 int64_t aqo_idx_address_arithmetic(uint64_t M, double pct, uint64_t* out, int64_t cap);
+int64_t aqo_idx_random_start_stride(uint64_t M, double pct, uint64_t stride_bytes, uint64_t seed,
+                                    const uint64_t* start_override, uint64_t* out, int64_t cap);
 int64_t aqo_idx_random_pointer(uint64_t N, double pct, uint32_t seed, uint64_t* out, int64_t cap);
 int64_t aqo_idx_block(uint64_t N, double pct, uint64_t block_rows, uint64_t* out, int64_t cap);
 int64_t aqo_idx_page(uint64_t N, double pct, uint64_t page_bytes, uint64_t* out, int64_t cap);

@@ -184,6 +184,14 @@ def main():
                 dist["parallel_sum_where_250_750_pct1_T4"].append(r.parallel_sum_where_sample(250, 750, 1.0, 4))
                 dist["parallel_count_pct1_T4"].append(r.parallel_count_sample(1.0, 4))
             T["distributions"] = dist
+            # random_start_memory_stride_sample (DB.cpp:1838-1878): the draw is visible as the first row
+            rs = []
+            for pct_, sb in ((1.0, 0), (5.0, 0), (1.0, 4096)):
+                for _ in range(3):
+                    ids = r.sample("random_start_memory_stride_sample", pct_, sb)
+                    idx = (ids - 1).astype(np.uint64)
+                    rs.append({"pct": pct_, "stride_bytes": sb, "start": int(idx[0]), "idx": digest(idx)})
+            T["random_start_stride"] = rs
         r.close()
         G["tables"][str(N)] = T
         print(f"N={N}: {len(T['calls'])} calls", flush=True)

@@ -101,6 +101,8 @@ class Oracle:
             f = getattr(L, name)
             f.restype = C.c_int64
             f.argtypes = [C.c_uint64, C.c_double] + extra + [_u64p, C.c_int64]
+        L.aqo_idx_random_start_stride.restype = C.c_int64
+        L.aqo_idx_random_start_stride.argtypes = [C.c_uint64, C.c_double, C.c_uint64, C.c_uint64, _u64p, _u64p, C.c_int64]
         L.aqo_idx_region_stride.restype = C.c_int64
         L.aqo_idx_region_stride.argtypes = [C.c_uint64, C.c_double, C.c_int, C.c_uint64, _u64p, C.c_int,
                                             _u64p, C.c_int64]
@@ -178,6 +180,17 @@ class Oracle:
     def idx_slow_pointer(self, N, pct): return self._idx("aqo_idx_fast_pointer", N, pct, 1)
     def idx_dual_pointer(self, N, pct): return self._idx("aqo_idx_dual_pointer", N, pct)
     def idx_parallel_pointer(self, N, pct, T=4): return self._idx("aqo_idx_parallel_pointer", N, pct, T)
+
+    def idx_random_start_stride(self, M, pct, stride_bytes=0, seed=42, start=None):
+        sp = None
+        if start is not None:
+            st = np.array([start], dtype=np.uint64)
+            sp = _ptr(st, _u64p)
+        f = self.lib.aqo_idx_random_start_stride
+        cnt = f(M, pct, stride_bytes, seed, sp, None, 0)
+        out = np.zeros(max(cnt, 1), dtype=np.uint64)
+        f(M, pct, stride_bytes, seed, sp, _ptr(out, _u64p), cnt)
+        return out[:cnt]
 
     def idx_region_stride(self, M, pct, T=4, seed=42, starts=None, reference_partition=False):
         sp = None

@@ -28,7 +28,8 @@ def test_record_and_result_types_have_the_reference_fields():
                  "fast_pointer_sample", "slow_pointer_sample", "dual_pointer_sample", "parallel_pointer_sample",
                  "random_pointer_sample", "clt_validated_dual_pointer_sample", "optimized_clt_sample", "block_sample",
                  "page_sample", "parallel_block_sample", "memory_stride_sample", "optimized_address_arithmetic_sample",
-                 "multithreaded_memory_stride_sample", "fast_aggregated_memory_stride_sum"):  # bindings.cpp:44-101
+                 "multithreaded_memory_stride_sample", "fast_aggregated_memory_stride_sum",
+                 "random_start_memory_stride_sample"):  # bindings.cpp:44-101
         assert callable(getattr(db, name)), name
     for name in ("index_based_sample", "node_skip_sample", "stratified_block_sample", "adaptive_block_sample",
                  "signal_based_clt_sample", "direct_access_sample"):
@@ -168,6 +169,13 @@ def test_fused_approx_entry_points(db100k, oracle, table):
         mod.CustomBPlusDB().approx_sum(method="stride", sample_percent=1.0)
     with pytest.raises(RuntimeError, match="No samples collected"):
         db100k.approx_sum(method="stride", sample_percent=0.00001)
+    # WHERE id BETWEEN 20001 AND 70000: key bounds prune the sampled index space
+    r = db100k.approx_sum(method="stride", sample_percent=1.0, id_between=(20_001, 70_000))
+    sub = rows[20_000:70_000]
+    m = oracle.moments_idx(sub, oracle.idx_memory_stride(len(sub), 1.0))
+    assert r.n == m.n and rel(r.value, m.sum * (len(sub) / m.n)) <= 1e-12
+    got = db100k.random_start_memory_stride_sample(1.0, 0, seed=5, as_array=True)
+    assert np.array_equal(got["id"] - 1, oracle.idx_random_start_stride(100_000, 1.0, 0, seed=5).astype(np.int64))
 
 
 @pytest.mark.gpu

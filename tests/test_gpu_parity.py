@@ -244,6 +244,46 @@ def test_conventions_and_where_composition(nat, oracle, table, engines):
         assert r.n == len(idx) and rel(r.value, oracle.moments_idx(rows, idx).sum) <= SUM_TOL
 
 
+def test_key_range_windows(nat, oracle, table):
+    """`WHERE id BETWEEN a AND b`: B+-tree key bounds -> row window -> the sampler runs on the window."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 100_000
+    rows = table(n)
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)             # dense ids (id = row + 1): arithmetic bounds
+        assert eng.key_range_rows(1, n) == (0, n)
+        assert eng.key_range_rows(5001, 25_000) == (5000, 25_000)
+        assert eng.key_range_rows(-50, 10) == (0, 10) and eng.key_range_rows(n + 5, n + 9) == (0, 0)
+        lo, hi = eng.key_range_rows(20_001, 70_000)
+        sub = rows[lo:hi]
+        for q, idx in (
+            (make_query(nat.M_MEMORY_STRIDE, 1.0, rows=(lo, hi)), oracle.idx_memory_stride(len(sub), 1.0)),
+            (make_query(nat.M_BLOCK, 10.0, rows=(lo, hi), where=(250.0, 750.0)), oracle.idx_block(len(sub), 10.0, 1000)),
+            (make_query(nat.M_RANDOM_POINTER, 2.0, seed=3, rows=(lo, hi)), oracle.idx_random_pointer(len(sub), 2.0, 3)),
+            (make_query(nat.M_RANDOM_START_STRIDE, 1.0, seed=11, rows=(lo, hi)), oracle.idx_random_start_stride(len(sub), 1.0, 0, seed=11)),
+            (make_query(nat.M_EXACT, 100.0, rows=(lo, hi)), np.arange(len(sub), dtype=np.uint64)),
+        ):
+            r = eng.reduce(q)
+            m = oracle.moments_idx(sub, idx, where=(250.0, 750.0) if q.has_where else None)
+            assert (r.visited, r.n) == (len(idx), m.n) and rel(r.sum, m.sum) <= SUM_TOL
+            if not q.has_where and q.method != nat.M_EXACT:  # SUM scales to the WINDOW's row count
+                assert rel(r.value, m.sum * (len(sub) / m.n)) <= EST_TOL
+        rc, want, _ = oracle.clt_run(sub, 20.0, 0.95, 10, 4, 1.0, R0=64, growth=2)
+        r = eng.reduce(make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=1.0, clt_round0=64, clt_growth=2, rows=(lo, hi)))
+        assert (r.n, r.converged, r.rounds, r.topup) == (want.final.n, want.converged, want.rounds, want.topup)
+        assert rel(r.sum, want.final.sum) <= SUM_TOL
+        # sparse ids: bounds come from a bisection over the resident rows
+        sparse = rows.copy()
+        sparse["id"] = 7 + 3 * np.arange(n)
+        eng.stage_records(sparse, keep_aos=True)
+        ids = sparse["id"]
+        for a, b in ((7, 7), (8, 9), (100, 1000), (0, 10**9), (ids[-1], ids[-1] + 5), (ids[500] + 1, ids[900] - 1)):
+            assert eng.key_range_rows(int(a), int(b)) == (int(np.searchsorted(ids, a, "left")), int(np.searchsorted(ids, b, "right")))
+        eng.stage_records(sparse, keep_aos=False)
+        with pytest.raises(nat.AqeError):
+            eng.key_range_rows(10, 20)
+
+
 def test_edge_shapes(nat, oracle, table):
     """Empty and tiny tables, 100 % samples, ragged tails, block sizes that do not divide N."""
     from approximatequeryengine_amd.engine import Engine, make_query

@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol(nat):
     for n in names:
         assert hasattr(L, n), f"libaqe_hip.so does not export {n}"
     assert L.aqe_abi_version() == 1
-    assert C.sizeof(nat.Query) == 120 and C.sizeof(nat.Family) == 80 and C.sizeof(nat.Result) == 120
+    assert C.sizeof(nat.Query) == 136 and C.sizeof(nat.Family) == 80 and C.sizeof(nat.Result) == 120
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback(nat):
@@ -109,6 +109,37 @@ def test_planner_index_sets_equal_oracle_whole_and_sharded(nat, oracle, table, n
             q = __import__("approximatequeryengine_amd.engine", fromlist=["make_query"]).make_query(
                 nat.M_REGION_STRIDE, pct, num_threads=4, seed=seed)
             assert np.array_equal(expand(nat.plan_families(q, n)[0]), oracle.idx_region_stride(n, pct, 4, seed))
+
+
+def test_random_start_stride_and_row_windows(nat, oracle):
+    from approximatequeryengine_amd.engine import make_query
+    n = 100_007
+    for seed in (0, 5, 42):
+        q = make_query(nat.M_RANDOM_START_STRIDE, 1.0, seed=seed)
+        assert np.array_equal(expand(nat.plan_families(q, n)[0]), oracle.idx_random_start_stride(n, 1.0, 0, seed=seed))
+    # a row window is the table: the sampler's arithmetic runs on [lo, hi) as if it were everything
+    lo, hi = 12_345, 77_001
+    m = hi - lo
+    for q, want in (
+        (make_query(nat.M_MEMORY_STRIDE, 1.0, rows=(lo, hi)), oracle.idx_memory_stride(m, 1.0)),
+        (make_query(nat.M_BLOCK, 5.0, block_size=1000, rows=(lo, hi)), oracle.idx_block(m, 5.0, 1000)),
+        (make_query(nat.M_PARALLEL_BLOCK, 5.0, block_size=300, num_threads=3, rows=(lo, hi)), oracle.idx_parallel_block(m, 5.0, 300, 3)),
+        (make_query(nat.M_EXACT, 100.0, rows=(lo, hi)), np.arange(m, dtype=np.uint64)),
+    ):
+        fams, _, samples = nat.plan_families(q, n)
+        assert np.array_equal(expand(fams), want + np.uint64(lo)) and samples == len(want)
+        parts = [expand(nat.plan_families(q, n, (g * n) // 3, ((g + 1) * n) // 3)[0]) for g in range(3)]
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.sort(want + np.uint64(lo)))
+    q = make_query(nat.M_RANDOM_POINTER, 2.0, seed=9, rows=(lo, hi))
+    L = nat.lib()
+    # (random sampler: families are empty, the index list carries the window)
+    assert nat.plan_families(q, n)[0] == []
+    with pytest.raises(nat.AqeError):
+        nat.plan_families(make_query(nat.M_MEMORY_STRIDE, 1.0, rows=(5, n + 1)), n)
+    q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, clt_round0=64, clt_growth=2, rows=(lo, hi))
+    rc, plan = oracle.clt_plan(m, 20.0, 0.95, 10, 4)
+    f0 = nat.plan_families(q, n, round=0)[0]
+    assert sorted(f.row0 for f in f0) == sorted(plan.w[i].first + lo for i in range(2))
 
 
 def test_planner_matches_reference_golden(nat, golden, table):

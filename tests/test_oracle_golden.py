@@ -181,6 +181,19 @@ def test_random_device_reducers_are_statistically_consistent(oracle, golden, tab
     assert abs(ours - ref.mean()) <= 4 * max(ref.std(), 288.4 * math.sqrt(2500))
 
 
+def test_random_start_stride_replays_reference_draws(oracle, golden):
+    """random_start_memory_stride_sample (DB.cpp:1838-1878): given the start the reference drew (its first
+    row), the oracle reproduces the reference's whole index set; the start is always inside [0, stride)."""
+    N = 1_000_000
+    for g in golden["tables"][str(N)]["random_start_stride"]:
+        idx = oracle.idx_random_start_stride(N, g["pct"], g["stride_bytes"], start=g["start"])
+        assert digest(idx) == g["idx"], g
+        stride = int(idx[1] - idx[0])
+        assert 0 <= g["start"] < stride
+    a = oracle.idx_random_start_stride(N, 1.0, 0, seed=5)
+    assert np.array_equal(a, oracle.idx_random_start_stride(N, 1.0, 0, seed=5)) and a[0] < 100 and len(a) == 10_000
+
+
 def test_small_n_quirks_of_the_real_tree(oracle, golden):
     """memory_stride_sample's fallback reads root->subtree_record_count, which only a leaf root
     maintains (DB.cpp:1569-1571): 255 <= N < 1000 returns nothing.  The oracle takes the visible row
