@@ -22,12 +22,6 @@ __device__ __forceinline__ u64 uniform64(u64 x) {
     return (static_cast<u64>(hi) << 32) | lo;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;  // valid in lane 0; fixed tree => bitwise reproducible
-}
-
 // Sum SEVEN per-lane values over the wave with 10 exchanges instead of 42: a butterfly that halves the
 // number of components a lane carries at each of the first three steps (xor 32, 16, 8) and then finishes
 // the one remaining component over the low three lane bits.  On return lane L holds the wave total of

@@ -1,17 +1,19 @@
 // kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the sampled-reduce path.
 //
 // The path is a bandwidth/latency-bound f64 reduction (3 flops per 8 bytes): no MFMA.  What matters is
-// coalesced loads of the SoA `amount` column, many loads in flight per lane, a wave64 shuffle tree, an
-// LDS cross-wave step, and ONE hand-off per workgroup to the last-arriving workgroup, which folds the
-// launch into the query's running Welford state and evaluates the CLT rules on the device.
+// coalesced loads of the SoA `amount` column, many loads in flight per lane, a wave64 butterfly, an LDS
+// cross-wave step, and ONE hand-off per workgroup to the last-arriving workgroup, which folds the launch
+// into the query's running moments and evaluates the CLT rules on the device.
 //
-// Reference lines restated here (DB.cpp = /root/reference/src/aqe_backend/core/custom_bplus_db.cpp):
-//   reducer loops       DB.cpp:285-294, 324-335, 2024-2036  -> k_round / k_indexed
-//   CLT error rule      DB.cpp:936-961                      -> fold(), rule A on the pooled triple
-//   CLT cross-check     DB.cpp:993-1016                     -> fold(), rule B
-//   should_stop polling DB.cpp:930, 987                     -> QueryState::stop tested on kernel entry
-//   top-up              DB.cpp:1031-1040                    -> k_round with FoldParams::is_topup
-//   estimators + CI     enhanced_aqe_cli.py:189-200, 277-291; DB.cpp:303-315 -> k_finalize
+//   k_round / k_indexed   one launch = one round, one single-round sampler, or the top-up
+//                         (reducer loops DB.cpp:285-294, 324-335, 2024-2036; should_stop DB.cpp:930, 987 is
+//                         QueryState::stop tested on kernel entry; top-up DB.cpp:1031-1040)
+//   k_update / k_replay   fold all-reduced vectors on every rank (multi-GPU forms)
+//   k_finalize            estimators + interval (enhanced_aqe_cli.py:189-200, 277-291; DB.cpp:303-315)
+//   k_gather*             record-returning samplers; k_id_bounds key range -> row window
+//   k_split_amount, k_synth   staging
+// (DB.cpp = /root/reference/src/aqe_backend/core/custom_bplus_db.cpp; the shared device code with the
+// rule and estimator restatements is device_common.hpp; the single-launch multi-round sweep is persist.hip.)
 #include "device_common.hpp"
 
 namespace aqe {
