@@ -349,6 +349,38 @@ def test_persistent_sweep_stress_alternating_queries(nat, oracle, table, engines
     assert eng.reduce(qs[0]).sum == first[0].sum
 
 
+def test_concurrent_plans_on_separate_streams(nat, engines):
+    """Several plans in flight at once (what bench.py does): each plan owns its hand-off scratch, so queries on
+    different HIP streams may overlap — unevenly loaded, back to back — and every one must still return exactly
+    what it returns alone."""
+    import torch
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(1_000_000)
+    qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.0, clt_round0=4096, clt_growth=4),
+          make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=1.0, clt_round0=64, clt_growth=2),
+          make_query(nat.M_EXACT, 100.0),
+          make_query(nat.M_BLOCK, 20.0, where=(250.0, 750.0)),
+          make_query(nat.M_CLT_DUAL_POINTER, 10.0, agg=nat.SUM, max_error_percent=0.2, clt_round0=16, clt_growth=2, num_threads=8),
+          make_query(nat.M_MEMORY_STRIDE, 1.0)]
+    alone = [eng.reduce(q) for q in qs]
+    plans = [eng.plan(q) for q in qs]
+    streams = [torch.cuda.Stream() for _ in qs]
+    for rep in range(25):
+        order = list(range(len(qs)))
+        if rep % 2:
+            order.reverse()
+        for i in order:
+            for _ in range(1 + (i + rep) % 3):  # uneven: some streams get several executions per turn
+                plans[i].enqueue_all(streams[i].cuda_stream)
+        for i, (p, a) in enumerate(zip(plans, alone)):
+            r = p.fetch(streams[i].cuda_stream)
+            assert r.device_status == 0
+            assert (r.n, r.visited, r.sum, r.sumsq, r.value, r.ci_lower, r.converged, r.rounds, r.topup) == \
+                (a.n, a.visited, a.sum, a.sumsq, a.value, a.ci_lower, a.converged, a.rounds, a.topup), (rep, i)
+    for p in plans:
+        p.close()
+
+
 def test_run_to_run_bitwise_reproducible(nat, engines):
     from approximatequeryengine_amd.engine import make_query
     eng = engines(1_000_000)
