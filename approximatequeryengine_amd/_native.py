@@ -13,7 +13,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_TABLE, ERR_IO, ERR_CAPACITY, ERR
 
 M_EXACT, M_MEMORY_STRIDE, M_ADDRESS_ARITHMETIC, M_RANDOM_POINTER, M_BLOCK, M_PAGE, M_PARALLEL_BLOCK = range(7)
 M_OPTIMIZED_CLT, M_CLT_DUAL_POINTER, M_FAST_POINTER, M_SLOW_POINTER, M_DUAL_POINTER = 7, 8, 9, 10, 11
-M_PARALLEL_POINTER, M_REGION_STRIDE, M_RANDOM_START_STRIDE = 12, 13, 14
+M_PARALLEL_POINTER, M_REGION_STRIDE, M_RANDOM_START_STRIDE, M_ADAPTIVE_BLOCK, M_STRATIFIED_BLOCK = 12, 13, 14, 15, 16
 
 SUM, AVG, COUNT = 0, 1, 2
 EST_CLI, EST_CPP, EST_RAW = 0, 1, 2
@@ -33,7 +33,7 @@ class Query(C.Structure):
         ("confidence_level", C.c_double), ("max_error_percent", C.c_double), ("has_where", C.c_int32),
         ("reserved0", C.c_int32), ("where_min", C.c_double), ("where_max", C.c_double),
         ("clt_round0", C.c_uint64), ("clt_growth", C.c_uint32), ("flags", C.c_uint32),
-        ("visible_rows", C.c_uint64), ("row_lo", C.c_uint64), ("row_hi", C.c_uint64),
+        ("visible_rows", C.c_uint64), ("block_size_max", C.c_uint64), ("row_lo", C.c_uint64), ("row_hi", C.c_uint64),
     ]
 
 
@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
         "aqe_query_defaults": (None, [P(Query)]),
         "aqe_plan_families": (C.c_int, [P(Query), u64, u64, u64, u32, P(Family), u32, P(u32), P(u32), P(u64)]),
         "aqe_plan_random_indices": (C.c_int, [u64, dbl, u32, u64, u64, P(u64), u64, P(u64)]),
+        "aqe_plan_adaptive_families": (C.c_int, [P(Query), u64, P(dbl), P(Family), u32, P(u32), P(u64)]),
         "aqe_parse_where": (C.c_int, [C.c_char_p, P(dbl), P(dbl)]),
         "aqe_confidence_heuristic": (dbl, [dbl, u64]),
         "aqe_error_to_sample_percent": (dbl, [dbl]),
@@ -167,6 +168,17 @@ def plan_families(q: Query, n_global: int, lo: int = 0, hi: int | None = None, r
     fams = (Family * max(n.value, 1))()
     check(L.aqe_plan_families(C.byref(q), n_global, lo, hi, round, fams, n.value, C.byref(n), C.byref(rounds), C.byref(samples)))
     return list(fams[: n.value]), rounds.value, samples.value
+
+
+def plan_adaptive_families(q: Query, n_global: int, zone_var):
+    """Host-side plan of adaptive_block_sample from the ten zone variances: (families, global_samples)."""
+    L = lib()
+    zv = (C.c_double * 10)(*[float(v) for v in zone_var])
+    n, samples = C.c_uint32(), C.c_uint64()
+    check(L.aqe_plan_adaptive_families(C.byref(q), n_global, zv, None, 0, C.byref(n), C.byref(samples)))
+    fams = (Family * max(n.value, 1))()
+    check(L.aqe_plan_adaptive_families(C.byref(q), n_global, zv, fams, n.value, C.byref(n), C.byref(samples)))
+    return list(fams[: n.value]), samples.value
 
 
 def plan_random_indices(n_global: int, pct: float, seed: int, lo: int = 0, hi: int | None = None):

@@ -101,7 +101,7 @@ _AGG = {"SUM": nat.SUM, "AVG": nat.AVG, "COUNT": nat.COUNT}
 _OUT_OF_SCOPE = (
     "optimized_sequential_sample", "index_based_sample", "node_skip_sample", "balanced_tree_sample",
     "direct_access_sample", "byte_offset_sample", "random_start_nth_sample", "address_arithmetic_sample",
-    "signal_based_clt_sample", "adaptive_block_sample", "stratified_block_sample",
+    "signal_based_clt_sample",
 )
 
 
@@ -312,6 +312,16 @@ class CustomBPlusDB:
         return self._gather(make_query(nat.M_PARALLEL_BLOCK, sample_percent, block_size=int(block_size),
                                        num_threads=int(num_threads)), as_array)
 
+    def adaptive_block_sample(self, sample_percent, min_block_size=500, max_block_size=2000, *, as_array=False):
+        """custom_bplus_db.cpp:1273-1329 (the ten zone variances come from a device pre-pass, cached per table)."""
+        return self._gather(make_query(nat.M_ADAPTIVE_BLOCK, sample_percent, block_size=int(min_block_size),
+                                       block_size_max=int(max_block_size)), as_array)
+
+    def stratified_block_sample(self, sample_percent, block_size=1000, strata_count=4, *, as_array=False):
+        """custom_bplus_db.cpp:1331-1379 (the amount column is sorted once on the device, cached per table)."""
+        return self._gather(make_query(nat.M_STRATIFIED_BLOCK, sample_percent, block_size=int(block_size),
+                                       num_threads=int(strata_count)), as_array)
+
     def optimized_clt_sample(self, sample_percent, confidence_level=0.95, check_interval=20, num_threads=4,
                              max_error_percent=2.0, *, as_array=False):
         return self._gather(make_query(nat.M_OPTIMIZED_CLT, sample_percent, confidence_level=confidence_level,
@@ -372,7 +382,8 @@ class CustomBPlusDB:
                where: Optional[Tuple[float, float]] = None, seed: int = 42, num_threads: int = 4, block_size: int = 1000,
                confidence_level: float = 0.95, check_interval: int = 10, round0: int = 4096, growth: int = 4,
                convention: str = "cli", id_between: Optional[Tuple[int, int]] = None) -> ApproxResult:
-        """APPROX <agg>(amount): method in {"stride","random","block","page","parallel_block","region","clt","exact"}.
+        """APPROX <agg>(amount): method in {"stride","random","block","page","parallel_block","region","clt","exact",
+        "adaptive_block","stratified_block"}.
         ``error_percent`` (CLT) is in percent, as the reference CLI's --e (enhanced_aqe_cli.py:414-415); the
         sample percentage then follows enhanced_aqe_cli.py:243-250."""
         a = _AGG[agg.upper()]
@@ -392,7 +403,10 @@ class CustomBPlusDB:
                 q.row_lo, q.row_hi = rows
         else:
             m = {"stride": nat.M_MEMORY_STRIDE, "random": nat.M_RANDOM_POINTER, "block": nat.M_BLOCK, "page": nat.M_PAGE,
-                 "parallel_block": nat.M_PARALLEL_BLOCK, "region": nat.M_REGION_STRIDE, "exact": nat.M_EXACT}[method]
+                 "parallel_block": nat.M_PARALLEL_BLOCK, "region": nat.M_REGION_STRIDE, "exact": nat.M_EXACT,
+                 "adaptive_block": nat.M_ADAPTIVE_BLOCK, "stratified_block": nat.M_STRATIFIED_BLOCK}[method]
+            if method == "adaptive_block" and block_size == 1000:
+                block_size = 500  # the reference's min_block_size default (bindings.cpp:79-80)
             bs = 4096 if (method == "page" and block_size == 1000) else block_size
             q = make_query(m, sample_percent, agg=a, convention=conv, where=where, seed=int(seed),
                            num_threads=int(num_threads), block_size=int(bs), rows=rows)

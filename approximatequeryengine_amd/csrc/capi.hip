@@ -44,6 +44,11 @@ struct aqe_ctx {
     aqe_record* aos = nullptr;
     bool owns_table = true;
     bool staged = false;
+    // lazily built, per table: zone variances of adaptive_block_sample, amount-sorted column of stratified_block_sample
+    bool zone_var_valid = false;
+    double zone_var[10] = {0};
+    double* sorted_amount = nullptr;
+    uint32_t* sorted_row = nullptr;
     bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
     int64_t first_id = 0;
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
@@ -135,6 +140,11 @@ void free_table(aqe_ctx* c) {
         if (c->amount) (void)hipFree(c->amount);
         if (c->aos) (void)hipFree(c->aos);
     }
+    if (c->sorted_amount) (void)hipFree(c->sorted_amount);
+    if (c->sorted_row) (void)hipFree(c->sorted_row);
+    c->sorted_amount = nullptr;
+    c->sorted_row = nullptr;
+    c->zone_var_valid = false;
     c->amount = nullptr;
     c->aos = nullptr;
     c->owns_table = true;
@@ -252,7 +262,7 @@ FinalizeParams finalize_params(const aqe_plan* p) {
 SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam) {
     const aqe_ctx* c = p->ctx;
     SweepCommon s{};
-    s.amount = c->amount;
+    s.amount = p->host.on_sorted ? c->sorted_amount : c->amount;
     s.shard_lo = c->shard_lo;
     s.fams = fams;
     s.nfam = nfam;
@@ -371,6 +381,51 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
     return AQE_OK;
 }
 
+int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
+int enqueue_all(aqe_plan* p, hipStream_t s, bool timed);
+int fetch(aqe_plan* p, aqe_result* out, hipStream_t s);
+
+// adaptive_block_sample's pre-pass (DB.cpp:1291-1308): population variance of each of the ten zones from raw
+// moments, var = Q/n - (S/n)^2 — ten exact window scans on the device, kept until the table changes.
+int ensure_zone_variances(aqe_ctx* c) {
+    if (c->zone_var_valid) return AQE_OK;
+    const uint64_t zone_size = c->n_global / 10;
+    if (zone_size == 0) return fail(c, AQE_ERR_INVALID, "adaptive_block_sample: needs at least 10 rows");
+    for (uint64_t z = 0; z < 10; ++z) {
+        aqe_query q;
+        aqe_query_defaults(&q);
+        q.method = AQE_M_EXACT;
+        q.sample_percent = 100.0;
+        q.row_lo = z * zone_size;
+        q.row_hi = std::min(q.row_lo + zone_size, c->n_global);
+        aqe_plan* p = nullptr;
+        aqe_result r;
+        int rc = cached_plan(c, &q, &p);
+        if (rc == AQE_OK) rc = enqueue_all(p, c->stream, false);
+        if (rc == AQE_OK) rc = fetch(p, &r, c->stream);
+        if (rc != AQE_OK) return rc;
+        const double cnt = static_cast<double>(q.row_hi - q.row_lo), mean = r.sum / cnt;
+        c->zone_var[z] = (r.sumsq / cnt) - (mean * mean);
+    }
+    c->zone_var_valid = true;
+    return AQE_OK;
+}
+
+// stratified_block_sample's pre-pass (DB.cpp:1342-1345): the amount column sorted ascending + its row permutation.
+int ensure_sorted(aqe_ctx* c) {
+    if (c->sorted_amount || c->n_local == 0) return AQE_OK;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->sorted_amount), (c->n_local + 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->sorted_row), c->n_local * sizeof(uint32_t)));
+    hipError_t e = sort_amounts(c->amount, c->n_local, c->sorted_amount, c->sorted_row, c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(c->sorted_amount); (void)hipFree(c->sorted_row);
+        c->sorted_amount = nullptr; c->sorted_row = nullptr;
+        return fail(c, AQE_ERR_HIP, std::string("sorting the amount column: ") + hipGetErrorString(e));
+    }
+    c->hbm_bytes += (c->n_local + 1) * sizeof(double) + c->n_local * sizeof(uint32_t);
+    return AQE_OK;
+}
+
 int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
     std::unique_ptr<aqe_plan, void (*)(aqe_plan*)> p(new aqe_plan(), destroy_plan);
@@ -378,7 +433,15 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     p->q = *q;
     p->table_epoch = c->table_epoch;
     std::string err;
-    int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err);
+    const double* zone_var = nullptr;
+    if (q->method == AQE_M_ADAPTIVE_BLOCK || q->method == AQE_M_STRATIFIED_BLOCK) {
+        if (c->shard_lo != 0 || c->n_local != c->n_global)
+            return fail(c, AQE_ERR_UNSUPPORTED, "adaptive/stratified block samplers need the whole table in this context (they need a global variance pass / sort)");
+        int rc0 = q->method == AQE_M_ADAPTIVE_BLOCK ? ensure_zone_variances(c) : ensure_sorted(c);
+        if (rc0 != AQE_OK) return rc0;
+        zone_var = q->method == AQE_M_ADAPTIVE_BLOCK ? c->zone_var : nullptr;
+    }
+    int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err, zone_var);
     if (rc != AQE_OK) return fail(c, rc, err);
     uint64_t out_pos = 0;
     for (const auto& rf : p->host.round_fams) {
@@ -869,6 +932,7 @@ void aqe_query_defaults(aqe_query* q) {
     q->confidence_level = 0.95;
     q->max_error_percent = 2.0;
     q->clt_growth = 1;
+    q->block_size_max = 2000;  // adaptive_block_sample's max_block_size (BIND:79-80); its min is 500
 }
 
 int aqe_plan_families(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, uint64_t shard_hi, uint32_t round,
@@ -890,6 +954,24 @@ int aqe_plan_families(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, 
     if (fams) {
         if (cap < src->size()) return fail(nullptr, AQE_ERR_CAPACITY, "family buffer too small");
         std::copy(src->begin(), src->end(), fams);
+    }
+    return AQE_OK;
+}
+
+int aqe_plan_adaptive_families(const aqe_query* q, uint64_t n_global, const double* zone_var10, aqe_family* fams,
+                               uint32_t cap, uint32_t* n_out, uint64_t* samples_out) {
+    if (!q || !zone_var10) return AQE_ERR_INVALID;
+    if (q->method != AQE_M_ADAPTIVE_BLOCK) return fail(nullptr, AQE_ERR_INVALID, "not an adaptive_block_sample query");
+    HostPlan P;
+    std::string err;
+    int rc = build_plan(*q, n_global, ClipWindow{0, n_global}, P, err, zone_var10);
+    if (rc != AQE_OK) return fail(nullptr, rc, err);
+    const auto& src = P.round_fams.at(0);
+    if (n_out) *n_out = static_cast<uint32_t>(src.size());
+    if (samples_out) *samples_out = P.global_samples;
+    if (fams) {
+        if (cap < src.size()) return fail(nullptr, AQE_ERR_CAPACITY, "family buffer too small");
+        std::copy(src.begin(), src.end(), fams);
     }
     return AQE_OK;
 }
@@ -1129,7 +1211,8 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
     } else {
         for (uint32_t r = 0; r < rounds_used && e == hipSuccess; ++r) {
             const LaunchDesc& L = p->rounds[r];
-            if (L.nfam) e = launch_gather(c->aos, c->shard_lo, p->d_fams + L.fam_offset, L.nfam, L.ntiles, d_out, c->dense16, c->stream);
+            if (L.nfam) e = launch_gather(c->aos, c->shard_lo, p->d_fams + L.fam_offset, L.nfam, L.ntiles, d_out, c->dense16,
+                                          p->host.on_sorted ? c->sorted_row : nullptr, c->stream);
         }
         if (e == hipSuccess && topup_rows) {
             // the top-up is one strided family from row 0; keep its first `topup_rows` ordinals and place
@@ -1145,7 +1228,7 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
             DevFamily* d_tf = nullptr;
             e = hipMalloc(reinterpret_cast<void**>(&d_tf), tf.size() * sizeof(DevFamily));
             if (e == hipSuccess) e = hipMemcpy(d_tf, tf.data(), tf.size() * sizeof(DevFamily), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = launch_gather(c->aos, c->shard_lo, d_tf, static_cast<uint32_t>(tf.size()), p->topup.ntiles, d_out, c->dense16, c->stream);
+            if (e == hipSuccess) e = launch_gather(c->aos, c->shard_lo, d_tf, static_cast<uint32_t>(tf.size()), p->topup.ntiles, d_out, c->dense16, nullptr, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (d_tf) (void)hipFree(d_tf);
         }

@@ -237,7 +237,8 @@ __global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* ou
 // ---- record-returning samplers: gather 32-byte rows ---------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __restrict__ aos, u64 shard_lo,
                                                           const DevFamily* __restrict__ fams, unsigned nfam,
-                                                          u64 ntiles, aqe_record* __restrict__ out, int dense16) {
+                                                          u64 ntiles, aqe_record* __restrict__ out, int dense16,
+                                                          const uint32_t* __restrict__ perm) {
     const int lane = threadIdx.x & 63;
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
     const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const aqe_record* __re
             const u64 oi = j * tile + half * kTileOrdinals + lane + static_cast<u64>(k) * 64;
             const u64 o = seg_ord0 + oi;
             if (oi < F.seg_len && o >= F.ord_lo && o < F.ord_hi) {
-                const u64 row = row_base + oi * F.step;
+                u64 row = row_base + oi * F.step;
+                if (perm) row = perm[row];  // position in the amount-sorted table -> row
                 const u64 pos = F.out_begin + (o - F.ord_lo);
                 uint4 a = src[2 * row], b = src[2 * row + 1];
                 dst[2 * pos] = a;
@@ -386,11 +388,11 @@ hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe
 }
 
 hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFamily* fams, uint32_t nfam,
-                         uint64_t ntiles, aqe_record* out, int dense16, hipStream_t s) {
+                         uint64_t ntiles, aqe_record* out, int dense16, const uint32_t* perm, hipStream_t s) {
     if (ntiles == 0) return hipSuccess;
     unsigned grid = grid_for(ntiles, kWavesPerBlock);
     hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlockThreads), 0, s, aos, static_cast<u64>(shard_lo), fams, nfam,
-                       static_cast<u64>(ntiles), out, dense16);
+                       static_cast<u64>(ntiles), out, dense16, perm);
     return hipGetLastError();
 }
 

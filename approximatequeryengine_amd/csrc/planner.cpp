@@ -167,17 +167,19 @@ int random_pointer_indices(u64 N, double pct, uint32_t seed, ClipWindow shard, s
     return AQE_OK;
 }
 
-static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err);
+static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err, const double* zone_var);
 
 // Row window (key-range pruning): plan over the window as if it were the whole table, then shift.
-int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err) {
-    if (q.row_hi <= q.row_lo) return build_plan_whole(q, N, shard, P, err);
+int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err, const double* zone_var) {
+    if (q.row_hi <= q.row_lo) return build_plan_whole(q, N, shard, P, err, zone_var);
+    if (q.method == AQE_M_ADAPTIVE_BLOCK || q.method == AQE_M_STRATIFIED_BLOCK)
+        AQE_FAIL("adaptive/stratified block samplers work on the whole table (no row window)");
     if (q.row_hi > N) AQE_FAIL("row window exceeds the table");
     const u64 lo = q.row_lo, n = q.row_hi - q.row_lo;
     auto rebase = [&](u64 x) { return x <= lo ? 0 : std::min(x - lo, n); };
     aqe_query inner = q;
     inner.row_lo = inner.row_hi = 0;
-    int rc = build_plan_whole(inner, n, ClipWindow{rebase(shard.lo), rebase(shard.hi)}, P, err);
+    int rc = build_plan_whole(inner, n, ClipWindow{rebase(shard.lo), rebase(shard.hi)}, P, err, nullptr);
     if (rc != AQE_OK) return rc;
     for (auto& rf : P.round_fams) for (auto& f : rf) { f.row0 += lo; if (f.flags & AQE_F_PAIR) f.row0_b += lo; }
     for (auto& f : P.topup_fams) f.row0 += lo;
@@ -185,7 +187,7 @@ int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::st
     return AQE_OK;
 }
 
-static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err) {
+static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err, const double* zone_var) {
     P = HostPlan{};
     P.pct = q.sample_percent;
     shard.lo = std::min(shard.lo, N);
@@ -295,6 +297,65 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
             u64 last_len = std::min(B, N - last_row0);            // only the table's tail block is short
             u64 avail = (nseg - 1) * B + last_len;
             fams.push_back(blocks(0, interval * B, B, std::min<u64>(static_cast<u64>(target), avail)));
+            return finish_single();
+        }
+        case AQE_M_ADAPTIVE_BLOCK: {  // DB.cpp:1273-1329
+            if (N == 0) return finish_single();
+            int target = target_of(N, pct);
+            if (target <= 0) return finish_single();
+            const u64 min_b = q.block_size, max_b = q.block_size_max;
+            const u64 zones = 10, zone_size = N / zones;
+            if (zone_size == 0 || min_b == 0 || max_b < min_b) AQE_FAIL("adaptive_block_sample: needs N >= 10 and 0 < min_block_size <= max_block_size");
+            if (!zone_var) AQE_FAIL("adaptive_block_sample: zone variances missing (planned by aqe_reduce after its device pre-pass, or aqe_plan_adaptive_families)");
+            double vmax = zone_var[0];
+            for (u64 z = 1; z < zones; ++z) vmax = std::max(vmax, zone_var[z]);
+            if (!(vmax > 0.0)) AQE_FAIL("adaptive_block_sample: all zone variances are zero (the reference divides 0/0)");
+            u64 budget = static_cast<u64>(target);
+            for (u64 z = 0; z < zones && budget; ++z) {
+                const u64 a = z * zone_size, b = std::min(a + zone_size, N);
+                const double ratio = zone_var[z] / vmax;
+                const u64 abs_ = min_b + static_cast<u64>(static_cast<double>(max_b - min_b) * (1.0 - ratio));
+                const u64 nblk = ceil_div(b - a, abs_), nfull = (b - a) / abs_;
+                if (nfull) {  // whole blocks: the first max(1, abs*pct/100) rows of each
+                    const u64 cnt = std::min(abs_, std::max<u64>(1, static_cast<u64>(static_cast<double>(abs_) * pct / 100.0)));
+                    const u64 total = std::min(budget, nfull * cnt);
+                    fams.push_back(blocks(a, abs_, cnt, total));
+                    budget -= total;
+                }
+                if (nblk > nfull && budget) {  // the zone's short last block
+                    const u64 i = a + nfull * abs_, len = b - i;
+                    const u64 cnt = std::min(len, std::max<u64>(1, static_cast<u64>(static_cast<double>(len) * pct / 100.0)));
+                    const u64 total = std::min(budget, cnt);
+                    fams.push_back(blocks(i, len, cnt, total));
+                    budget -= total;
+                }
+            }
+            return finish_single();
+        }
+        case AQE_M_STRATIFIED_BLOCK: {  // DB.cpp:1331-1379; rows are positions in the amount-sorted table
+            P.on_sorted = true;
+            if (N == 0) return finish_single();
+            int target = target_of(N, pct);
+            if (target <= 0) return finish_single();
+            const u64 B = q.block_size;
+            const int strata = T;
+            if (B == 0 || strata <= 0) AQE_FAIL("stratified_block_sample: block_size and strata_count must be positive");
+            const u64 stratum_size = N / static_cast<u64>(strata), per_stratum = static_cast<u64>(target / strata);
+            u64 budget = static_cast<u64>(target);
+            for (int st = 0; st < strata && budget; ++st) {
+                const u64 a = static_cast<u64>(st) * stratum_size, b = (st == strata - 1) ? N : a + stratum_size;
+                const u64 recs = b - a, nblocks = ceil_div(recs, B);
+                if (nblocks == 0 || per_stratum == 0) continue;  // remaining_samples == 0: nothing is taken
+                const u64 to_sample = std::max<u64>(1, static_cast<u64>(static_cast<double>(nblocks) * pct / 100.0));
+                const u64 interval = std::max<u64>(1, nblocks / to_sample);
+                const u64 nsel = ceil_div(nblocks, interval);
+                const u64 take_full = std::min(per_stratum, B);
+                const u64 last_len = std::min(B, recs - (nsel - 1) * interval * B);
+                const u64 avail = (nsel - 1) * take_full + std::min(per_stratum, last_len);
+                const u64 total = std::min(budget, avail);
+                fams.push_back(blocks(a, interval * B, take_full, total));
+                budget -= total;
+            }
             return finish_single();
         }
         case AQE_M_PARALLEL_BLOCK: {  // DB.cpp:1218-1271

@@ -28,6 +28,7 @@ struct HostPlan {
     bool is_random = false;   // RANDOM_POINTER: explicit index list instead of families
     bool is_clt = false;
     bool has_topup = false;
+    bool on_sorted = false;   // STRATIFIED_BLOCK: families index the amount-sorted table
     uint32_t rounds = 1;
     CltShape clt;
     std::vector<std::vector<aqe_family>> round_fams;  // [round] -> families clipped to the shard
@@ -39,7 +40,9 @@ struct HostPlan {
 };
 
 // Returns AQE_OK or AQE_ERR_INVALID (err gets the reason).  shard = [lo, hi) global rows.
-int build_plan(const aqe_query& q, uint64_t n_global, ClipWindow shard, HostPlan& out, std::string& err);
+// zone_var: the ten zone variances ADAPTIVE_BLOCK needs (nullptr for every other method).
+int build_plan(const aqe_query& q, uint64_t n_global, ClipWindow shard, HostPlan& out, std::string& err,
+               const double* zone_var = nullptr);
 
 // random_pointer_sample index set (DB.cpp:856-882), ascending, restricted to the shard.
 int random_pointer_indices(uint64_t n_global, double pct, uint32_t seed, ClipWindow shard,

@@ -74,7 +74,11 @@ typedef enum aqe_method {
     AQE_M_PARALLEL_POINTER = 12,  /* parallel_pointer_sample                DB.cpp:815-854   */
     AQE_M_REGION_STRIDE = 13,     /* multithreaded_memory_stride_sample / fast_aggregated_memory_stride_sum,
                                      DB.cpp:1880-2048, with a seeded counter-based start per region */
-    AQE_M_RANDOM_START_STRIDE = 14 /* random_start_memory_stride_sample, DB.cpp:1838-1878, seeded start in [0, stride) */
+    AQE_M_RANDOM_START_STRIDE = 14, /* random_start_memory_stride_sample, DB.cpp:1838-1878, seeded start in [0, stride) */
+    AQE_M_ADAPTIVE_BLOCK = 15,    /* adaptive_block_sample, DB.cpp:1273-1329: block size from per-zone variance (needs a
+                                     full-table moments pre-pass on the device, cached per table)            */
+    AQE_M_STRATIFIED_BLOCK = 16   /* stratified_block_sample, DB.cpp:1331-1379: blocks of the amount-SORTED table (needs a
+                                     device sort of the column, cached per table); num_threads = strata_count */
 } aqe_method;
 
 typedef enum aqe_agg { AQE_SUM = 0, AQE_AVG = 1, AQE_COUNT = 2 } aqe_agg;
@@ -93,7 +97,8 @@ typedef struct aqe_query {
     int32_t num_threads;      /* T of the parallel / CLT samplers (reference default 4)          */
     double sample_percent;    /* pct, in percent                                                 */
     uint64_t stride_bytes;    /* memory_stride_sample: 0 = auto (DB.cpp:1549-1556)               */
-    uint64_t block_size;      /* block rows (BLOCK/PARALLEL_BLOCK) or page bytes (PAGE)          */
+    uint64_t block_size;      /* block rows (BLOCK/PARALLEL_BLOCK/STRATIFIED), page bytes (PAGE), or
+                                 min_block_size (ADAPTIVE_BLOCK)                                  */
     uint64_t seed;            /* RANDOM_POINTER (low 32 bits), REGION_STRIDE                     */
     int32_t step_size;        /* FAST_POINTER multiplier (reference default 2)                   */
     int32_t check_interval;   /* CLT (reference default 10)                                      */
@@ -107,6 +112,7 @@ typedef struct aqe_query {
     uint32_t flags;           /* AQE_Q_*                                                         */
     uint64_t visible_rows;    /* M of the cached samplers; 0 = global_rows (the
                                  reference's stale-cache quirk DB.cpp:188-191 is not reproduced)  */
+    uint64_t block_size_max;  /* ADAPTIVE_BLOCK: max_block_size (reference default 2000)          */
     uint64_t row_lo, row_hi;  /* row_hi > row_lo: the sampler runs over rows [row_lo, row_hi) only, as if they
                                  were the whole table (key-range pruning: see aqe_key_range_rows); N in the
                                  estimators is then row_hi - row_lo                                */
@@ -204,6 +210,11 @@ AQE_API void aqe_query_defaults(aqe_query* q); /* reference defaults of BIND:56-
 AQE_API int aqe_plan_families(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, uint64_t shard_hi,
                               uint32_t round, aqe_family* fams, uint32_t cap, uint32_t* n_out,
                               uint32_t* rounds_out, uint64_t* samples_out);
+/* adaptive_block_sample is data dependent: its families follow from the ten zone variances (population
+ * variance of the amounts of rows [z*N/10, (z+1)*N/10)), which aqe_reduce obtains with a device pre-pass.
+ * This host-side entry plans it from given variances (tests, external planners). */
+AQE_API int aqe_plan_adaptive_families(const aqe_query* q, uint64_t n_global, const double* zone_var10,
+                                       aqe_family* fams, uint32_t cap, uint32_t* n_out, uint64_t* samples_out);
 /* Ascending unique indices of random_pointer_sample(pct, seed) that fall in [shard_lo, shard_hi). */
 AQE_API int aqe_plan_random_indices(uint64_t n_global, double pct, uint32_t seed, uint64_t shard_lo,
                                     uint64_t shard_hi, uint64_t* out, uint64_t cap, uint64_t* n_out);

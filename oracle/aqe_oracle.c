@@ -291,6 +291,81 @@ int64_t aqo_idx_parallel_block(uint64_t N, double pct, uint64_t B, int T, uint64
     return s.n;
 }
 
+/* DB.cpp:1273-1329 — adaptive_block_sample: ten zones, per-zone population variance from raw moments, block
+ * size shrinking with variance, the first max(1, len*pct/100) rows of every block.  zone_var_out (optional, 10
+ * doubles) receives the zone variances.  -1 where the reference's arithmetic is undefined. */
+int64_t aqo_idx_adaptive_block(const aqo_record* rows, uint64_t N, double pct, uint64_t min_block, uint64_t max_block,
+                               double* zone_var_out, uint64_t* out, int64_t cap) {
+    sink s = {out, cap, 0};
+    if (N == 0) return 0;
+    int target = target_of(N, pct);
+    if (target <= 0) return 0;
+    const uint64_t zones = 10, zone_size = N / zones;
+    if (zone_size == 0 || max_block < min_block || min_block == 0) return -1;
+    double var[10], vmax = 0.0;
+    for (uint64_t z = 0; z < zones; ++z) {
+        uint64_t a = z * zone_size, b = umin(a + zone_size, N);
+        double sum = 0.0, sum_sq = 0.0;
+        for (uint64_t i = a; i < b; ++i) { sum += rows[i].amount; sum_sq += rows[i].amount * rows[i].amount; }
+        double cnt = (double)(b - a), mean = sum / cnt;
+        var[z] = (sum_sq / cnt) - (mean * mean);
+        if (z == 0 || var[z] > vmax) vmax = var[z];
+        if (zone_var_out) zone_var_out[z] = var[z];
+    }
+    if (!(vmax > 0.0)) return -1; /* 0/0 in the reference */
+    for (uint64_t z = 0; z < zones && s.n < target; ++z) {
+        uint64_t a = z * zone_size, b = umin(a + zone_size, N);
+        double ratio = var[z] / vmax;
+        uint64_t abs_ = min_block + (uint64_t)((double)(max_block - min_block) * (1.0 - ratio));
+        for (uint64_t i = a; i < b && s.n < target; i += abs_) {
+            uint64_t be = umin(i + abs_, b);
+            uint64_t cnt = umax(1, (uint64_t)((double)(be - i) * pct / 100.0));
+            for (uint64_t j = 0; j < cnt && i + j < be && s.n < target; ++j) emit(&s, i + j);
+        }
+    }
+    return s.n;
+}
+
+typedef struct { double amount; uint64_t row; } amt_row;
+static int cmp_amt_row(const void* a, const void* b) {
+    const amt_row* x = (const amt_row*)a; const amt_row* y = (const amt_row*)b;
+    if (x->amount < y->amount) return -1;
+    if (x->amount > y->amount) return 1;
+    return x->row < y->row ? -1 : x->row > y->row;
+}
+
+/* DB.cpp:1331-1379 — stratified_block_sample: rows sorted by amount, `strata` equal strata, evenly spaced
+ * blocks inside each, min(target/strata, block) rows from the head of every sampled block.  Emits ROW indices
+ * (ties in amount are ordered by row; the reference's std::sort leaves tie order unspecified). */
+int64_t aqo_idx_stratified_block(const aqo_record* rows, uint64_t N, double pct, uint64_t B, int strata,
+                                 uint64_t* out, int64_t cap) {
+    sink s = {out, cap, 0};
+    if (N == 0) return 0;
+    int target = target_of(N, pct);
+    if (target <= 0) return 0;
+    if (B == 0 || strata <= 0) return -1;
+    amt_row* v = (amt_row*)malloc(sizeof(amt_row) * (size_t)N);
+    if (!v) return -1;
+    for (uint64_t i = 0; i < N; ++i) { v[i].amount = rows[i].amount; v[i].row = i; }
+    qsort(v, (size_t)N, sizeof(amt_row), cmp_amt_row);
+    uint64_t stratum_size = N / (uint64_t)strata, per_stratum = (uint64_t)(target / strata);
+    for (int st = 0; st < strata && s.n < target; ++st) {
+        uint64_t a = (uint64_t)st * stratum_size, b = (st == strata - 1) ? N : a + stratum_size;
+        uint64_t recs = b - a, blocks = (recs + B - 1) / B;
+        uint64_t to_sample = umax(1, (uint64_t)((double)blocks * pct / 100.0));
+        uint64_t interval = blocks / to_sample;
+        if (interval == 0) interval = 1;
+        for (uint64_t blk = 0; blk < blocks && s.n < target; blk += interval) {
+            uint64_t bs = a + blk * B, be = umin(bs + B, b);
+            uint64_t remaining = umin(per_stratum, (uint64_t)target - (uint64_t)s.n);
+            uint64_t take = umin(remaining, be - bs);
+            for (uint64_t i = 0; i < take; ++i) emit(&s, v[bs + i].row);
+        }
+    }
+    free(v);
+    return s.n;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * R9 — optimized_clt_sample (DB.cpp:1046-1147): region-per-thread strided; the "CLT check" after the
  * loop returns the same vector on both branches, so the sampler is deterministic.

@@ -56,6 +56,11 @@ int64_t aqo_idx_block(uint64_t N, double pct, uint64_t block_rows, uint64_t* out
 int64_t aqo_idx_page(uint64_t N, double pct, uint64_t page_bytes, uint64_t* out, int64_t cap);
 int64_t aqo_idx_parallel_block(uint64_t N, double pct, uint64_t block_rows, int T, uint64_t* out, int64_t cap);
 int64_t aqo_idx_optimized_clt(uint64_t N, double pct, int T, uint64_t* out, int64_t cap);
+/* data-dependent samplers ("next" rows of SURVEY §8f): need the rows */
+int64_t aqo_idx_adaptive_block(const aqo_record* rows, uint64_t N, double pct, uint64_t min_block, uint64_t max_block,
+                               double* zone_var_out, uint64_t* out, int64_t cap);
+int64_t aqo_idx_stratified_block(const aqo_record* rows, uint64_t N, double pct, uint64_t B, int strata,
+                                 uint64_t* out, int64_t cap);
 int64_t aqo_idx_fast_pointer(uint64_t N, double pct, int step_size, uint64_t* out, int64_t cap);
 int64_t aqo_idx_dual_pointer(uint64_t N, double pct, uint64_t* out, int64_t cap);
 int64_t aqo_idx_parallel_pointer(uint64_t N, double pct, int T, uint64_t* out, int64_t cap);

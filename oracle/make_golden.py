@@ -105,6 +105,10 @@ def deterministic_suite(ref: Ref, rows: np.ndarray, pcts, with_clt=True) -> list
             record_call(ref, rows, "slow_pointer_sample", pct),
             record_call(ref, rows, "dual_pointer_sample", pct),
             record_call(ref, rows, "parallel_pointer_sample", pct, (4,)),
+            record_call(ref, rows, "adaptive_block_sample", pct, (500, 2000)),
+            record_call(ref, rows, "adaptive_block_sample", pct, (64, 300), with_cli=False),
+            record_call(ref, rows, "stratified_block_sample", pct, (1000, 4)),
+            record_call(ref, rows, "stratified_block_sample", pct, (100, 5), with_cli=False),
         ]
         if with_clt:
             # max_error_percent = 0 never converges on non-constant data: deterministic multiset

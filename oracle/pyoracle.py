@@ -101,6 +101,10 @@ class Oracle:
             f = getattr(L, name)
             f.restype = C.c_int64
             f.argtypes = [C.c_uint64, C.c_double] + extra + [_u64p, C.c_int64]
+        L.aqo_idx_adaptive_block.restype = C.c_int64
+        L.aqo_idx_adaptive_block.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_uint64, C.c_uint64, _f64p, _u64p, C.c_int64]
+        L.aqo_idx_stratified_block.restype = C.c_int64
+        L.aqo_idx_stratified_block.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_uint64, C.c_int, _u64p, C.c_int64]
         L.aqo_idx_random_start_stride.restype = C.c_int64
         L.aqo_idx_random_start_stride.argtypes = [C.c_uint64, C.c_double, C.c_uint64, C.c_uint64, _u64p, _u64p, C.c_int64]
         L.aqo_idx_region_stride.restype = C.c_int64
@@ -180,6 +184,24 @@ class Oracle:
     def idx_slow_pointer(self, N, pct): return self._idx("aqo_idx_fast_pointer", N, pct, 1)
     def idx_dual_pointer(self, N, pct): return self._idx("aqo_idx_dual_pointer", N, pct)
     def idx_parallel_pointer(self, N, pct, T=4): return self._idx("aqo_idx_parallel_pointer", N, pct, T)
+
+    def idx_adaptive_block(self, rows, pct, min_block=500, max_block=2000):
+        f = self.lib.aqo_idx_adaptive_block
+        cnt = f(rows.ctypes.data, len(rows), pct, min_block, max_block, None, None, 0)
+        if cnt < 0:
+            return None
+        out = np.zeros(max(cnt, 1), dtype=np.uint64)
+        f(rows.ctypes.data, len(rows), pct, min_block, max_block, None, _ptr(out, _u64p), cnt)
+        return out[:cnt]
+
+    def idx_stratified_block(self, rows, pct, B=1000, strata=4):
+        f = self.lib.aqo_idx_stratified_block
+        cnt = f(rows.ctypes.data, len(rows), pct, B, strata, None, 0)
+        if cnt < 0:
+            return None
+        out = np.zeros(max(cnt, 1), dtype=np.uint64)
+        f(rows.ctypes.data, len(rows), pct, B, strata, _ptr(out, _u64p), cnt)
+        return out[:cnt]
 
     def idx_random_start_stride(self, M, pct, stride_bytes=0, seed=42, start=None):
         sp = None

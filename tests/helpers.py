@@ -43,6 +43,10 @@ def oracle_indices(o, rows, call, cache_rows=None):
         return o.idx_dual_pointer(N, pct)
     if m == "parallel_pointer_sample":
         return o.idx_parallel_pointer(N, pct, int(a[0]))
+    if m == "adaptive_block_sample":
+        return o.idx_adaptive_block(rows, pct, int(a[0]), int(a[1]))
+    if m == "stratified_block_sample":
+        return o.idx_stratified_block(rows, pct, int(a[0]), int(a[1]))
     if m == "clt_validated_dual_pointer_sample":
         rc, res, idx = o.clt_run(rows, pct, a[0], int(a[1]), int(a[2]), a[3], want_idx=True)
         assert rc == 0

@@ -31,8 +31,7 @@ def test_record_and_result_types_have_the_reference_fields():
                  "multithreaded_memory_stride_sample", "fast_aggregated_memory_stride_sum",
                  "random_start_memory_stride_sample"):  # bindings.cpp:44-101
         assert callable(getattr(db, name)), name
-    for name in ("index_based_sample", "node_skip_sample", "stratified_block_sample", "adaptive_block_sample",
-                 "signal_based_clt_sample", "direct_access_sample"):
+    for name in ("index_based_sample", "node_skip_sample", "signal_based_clt_sample", "direct_access_sample"):
         with pytest.raises(NotImplementedError):
             getattr(db, name)(10.0)
     s = m.CustomApproximateScheduler()

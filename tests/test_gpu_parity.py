@@ -61,6 +61,8 @@ def _query_for(nat, call):
         "slow_pointer_sample": lambda: make_query(nat.M_SLOW_POINTER, pct),
         "dual_pointer_sample": lambda: make_query(nat.M_DUAL_POINTER, pct),
         "parallel_pointer_sample": lambda: make_query(nat.M_PARALLEL_POINTER, pct, num_threads=int(a[0])),
+        "adaptive_block_sample": lambda: make_query(nat.M_ADAPTIVE_BLOCK, pct, block_size=int(a[0]), block_size_max=int(a[1])),
+        "stratified_block_sample": lambda: make_query(nat.M_STRATIFIED_BLOCK, pct, block_size=int(a[0]), num_threads=int(a[1])),
         "clt_validated_dual_pointer_sample": lambda: make_query(
             nat.M_CLT_DUAL_POINTER, pct, confidence_level=a[0], check_interval=int(a[1]), num_threads=int(a[2]),
             max_error_percent=a[3]),

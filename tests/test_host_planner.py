@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol(nat):
     for n in names:
         assert hasattr(L, n), f"libaqe_hip.so does not export {n}"
     assert L.aqe_abi_version() == 1
-    assert C.sizeof(nat.Query) == 136 and C.sizeof(nat.Family) == 80 and C.sizeof(nat.Result) == 120
+    assert C.sizeof(nat.Query) == 144 and C.sizeof(nat.Family) == 80 and C.sizeof(nat.Result) == 120
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback(nat):
@@ -142,12 +142,45 @@ def test_random_start_stride_and_row_windows(nat, oracle):
     assert sorted(f.row0 for f in f0) == sorted(plan.w[i].first + lo for i in range(2))
 
 
+def test_data_dependent_block_samplers(nat, oracle, golden, table):
+    """adaptive_block_sample from given zone variances, stratified_block_sample as positions of the sorted table —
+    against the reference's recorded index sets (via the oracle's zone variances / a stable argsort)."""
+    import ctypes as C
+    from approximatequeryengine_amd.engine import make_query
+    for n in (100_007, 10_000):
+        rows = table(n)
+        T = golden["tables"][str(n)]
+        order = np.argsort(rows["amount"], kind="stable").astype(np.uint64)
+        for call in T["calls"]:
+            pct, a = call["pct"], call["args"]
+            if call["method"] == "adaptive_block_sample":
+                zv = (C.c_double * 10)()
+                cnt = oracle.lib.aqo_idx_adaptive_block(rows.ctypes.data, n, pct, int(a[0]), int(a[1]), zv, None, 0)
+                q = make_query(nat.M_ADAPTIVE_BLOCK, pct, block_size=int(a[0]), block_size_max=int(a[1]))
+                fams, samples = nat.plan_adaptive_families(q, n, list(zv))
+                got = expand(fams)
+                assert samples == cnt == len(got) and digest(got) == call["idx"], call
+                with pytest.raises(nat.AqeError):  # without the variances there is nothing to plan from
+                    nat.plan_families(q, n)
+            elif call["method"] == "stratified_block_sample":
+                q = make_query(nat.M_STRATIFIED_BLOCK, pct, block_size=int(a[0]), num_threads=int(a[1]))
+                fams, _, samples = nat.plan_families(q, n)
+                pos = expand(fams)                       # positions in the amount-sorted table
+                assert digest(order[pos.astype(np.int64)]) == call["idx"], call
+    q = make_query(nat.M_ADAPTIVE_BLOCK, 10.0, block_size=500, block_size_max=100)
+    with pytest.raises(nat.AqeError):
+        nat.plan_adaptive_families(q, 100_000, [1.0] * 10)
+    with pytest.raises(nat.AqeError):
+        nat.plan_adaptive_families(make_query(nat.M_ADAPTIVE_BLOCK, 10.0, block_size=500, block_size_max=2000), 100_000, [0.0] * 10)
+
+
 def test_planner_matches_reference_golden(nat, golden, table):
     """Directly against the reference's recorded index digests (no oracle in between)."""
     n = 100_007
     T = golden["tables"][str(n)]
     for call in T["calls"]:
-        if call["method"] in ("random_pointer_sample", "clt_validated_dual_pointer_sample"):
+        if call["method"] in ("random_pointer_sample", "clt_validated_dual_pointer_sample", "adaptive_block_sample",
+                              "stratified_block_sample"):
             continue
         q = _query(nat, call["method"], call["pct"], call["args"])
         if call["method"] in ("memory_stride_sample", "optimized_address_arithmetic_sample"):
