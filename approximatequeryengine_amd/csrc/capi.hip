@@ -633,11 +633,24 @@ int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64
     // Double-buffered pinned bounce: the CPU fills buffer b while the DMA engine drains buffer b^1.
     // Without KEEP_AOS only the amount column crosses PCIe (8 of every 32 bytes).
     const size_t row_bytes = keep ? sizeof(aqe_record) : sizeof(double);
-    void* pinned[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
+    struct Bounce {  // two pinned buffers + their "drained" events, released on every exit path
+        void* pinned[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        ~Bounce() {
+            for (int b = 0; b < 2; ++b) {
+                if (pinned[b]) (void)hipHostFree(pinned[b]);
+                if (done[b]) (void)hipEventDestroy(done[b]);
+            }
+        }
+    } bounce;
+    void** pinned = bounce.pinned;
+    hipEvent_t* done = bounce.done;
     for (int b = 0; b < 2; ++b) {
-        HIPCHK(c, hipHostMalloc(&pinned[b], kStageChunkRows * row_bytes, hipHostMallocDefault));
-        HIPCHK(c, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+        if (hipHostMalloc(&pinned[b], std::min<uint64_t>(kStageChunkRows, n_local) * row_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) {
+            free_table(c);
+            return fail(c, AQE_ERR_HIP, "staging: cannot allocate pinned bounce buffers");
+        }
     }
     int status = AQE_OK;
     bool dense_ids = true;
@@ -662,10 +675,6 @@ int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess && status == AQE_OK) status = fail(c, AQE_ERR_HIP, std::string("staging sync: ") + hipGetErrorString(e));
-    for (int b = 0; b < 2; ++b) {
-        if (pinned[b]) (void)hipHostFree(pinned[b]);
-        if (done[b]) (void)hipEventDestroy(done[b]);
-    }
     if (status != AQE_OK) { free_table(c); return status; }
     c->ids_dense = dense_ids;
     c->first_id = id0 - static_cast<int64_t>(shard_lo);  // id of global row 0 when the ids are dense
