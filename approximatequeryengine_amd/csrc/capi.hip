@@ -72,7 +72,8 @@ struct SweepForm {
     std::vector<DevFamily> h_fams;
     DevFamily* d_fams = nullptr;
     uint16_t* d_expected = nullptr;
-    double* d_ppart = nullptr;  // [slots][persist_grid][kVec]
+    double* d_ppart = nullptr;  // flat workgroup partials: [step_begin[slots] + kDecSteps][8][kVec]
+    uint32_t step_begin[kMaxPersistRounds + 1] = {0};
     uint64_t round_begin[kMaxPersistRounds + 1] = {0};
     uint32_t part_first[kMaxPersistRounds] = {0}, part_count[kMaxPersistRounds] = {0};
     uint64_t ntiles = 0, samples = 0;
@@ -98,7 +99,6 @@ struct aqe_plan {
     double* partials = nullptr;   // [kMaxBlocks][kVec]   k_round / k_indexed
     unsigned* counter = nullptr;  // sharded tickets, zero between launches
     PersistCtl* d_ctl = nullptr;  // persistent sweep: decisions, stop word, tickets
-    double* d_rtot = nullptr;     // [rounds][kVec] round totals published by the deciders
     // Persistent single-launch forms (persist.hip).  `decide`: whole table on this GPU, decisions taken in the
     // kernel (should_stop).  `totals`: any shard, every round plus the top-up swept speculatively, one total per
     // slot written out — the multi-GPU form: ONE all-reduce of the slot totals, then k_replay decides.
@@ -163,7 +163,6 @@ void destroy_plan(aqe_plan* p) {
     if (p->partials) (void)hipFree(p->partials);
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
-    if (p->d_rtot) (void)hipFree(p->d_rtot);
     for (SweepForm* f : {&p->decide, &p->totals}) {
         if (f->d_fams) (void)hipFree(f->d_fams);
         if (f->d_expected) (void)hipFree(f->d_expected);
@@ -310,10 +309,10 @@ int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup,
     if (!topup && index == 0) p->last_exec = 0;
     RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec);
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
-    if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
-    if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s));
-    else HIPCHK(c, launch_round(a, s));
-    if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
+    hipEvent_t e0 = prof ? p->lev[2 * p->lev_used] : nullptr, e1 = prof ? p->lev[2 * p->lev_used + 1] : nullptr;
+    if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s, e0, e1));
+    else HIPCHK(c, launch_round(a, s, e0, e1));
+    if (prof) p->lev_used++;
     return AQE_OK;
 }
 
@@ -367,6 +366,7 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
         if (members != count) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation run mismatch");
         F.part_first[r] = static_cast<uint32_t>(first);
         F.part_count[r] = static_cast<uint32_t>(count);
+        F.step_begin[r + 1] = F.step_begin[r] + static_cast<uint32_t>((count + 7) / 8);
     }
     if (!F.h_fams.empty()) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_fams), F.h_fams.size() * sizeof(DevFamily)));
@@ -374,7 +374,8 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
     }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_expected), std::max<size_t>(ex.size(), 1) * sizeof(uint16_t)));
     HIPCHK(c, hipMemcpy(F.d_expected, ex.data(), ex.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    const size_t pp = sizeof(double) * kVec * c->persist_grid * std::max<size_t>(S, 1);
+    // the decider reads whole batches of kDecSteps steps: keep one batch of slack behind the last slot
+    const size_t pp = sizeof(double) * kVec * 8 * (static_cast<size_t>(F.step_begin[S]) + kDecSteps);
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), pp));
     HIPCHK(c, hipMemset(F.d_ppart, 0, pp));
     F.ok = true;
@@ -486,8 +487,6 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         if (p->decide.ok || p->totals.ok) {
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
             HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_rtot), sizeof(double) * kVec * kMaxPersistRounds));
-            HIPCHK(c, hipMemset(p->d_rtot, 0, sizeof(double) * kVec * kMaxPersistRounds));
         }
     }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
@@ -523,11 +522,11 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     a.ntiles = F.ntiles;
     for (uint32_t r = 0; r <= F.slots; ++r) a.round_begin[r] = F.round_begin[r];
     for (uint32_t r = 0; r < F.slots; ++r) { a.part_first[r] = F.part_first[r]; a.part_count[r] = F.part_count[r]; }
+    for (uint32_t r = 0; r <= F.slots; ++r) a.step_begin[r] = F.step_begin[r];
     a.rounds = F.slots;
     a.epoch = c->epoch++;
     a.ctl = p->d_ctl;
     a.partials = F.d_ppart;
-    a.round_totals = p->d_rtot;
     a.expected = F.d_expected;
     a.state = p->d_state;
     a.fold = fold_params(p, false);
@@ -545,9 +544,8 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
         HIPCHK(c, hipStreamSynchronize(s));
     }
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
-    if (prof) HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used], s));
-    HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s));
-    if (prof) { HIPCHK(c, hipEventRecord(p->lev[2 * p->lev_used + 1], s)); p->lev_used++; }
+    HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
+    if (prof) p->lev_used++;
     return AQE_OK;
 }
 

@@ -14,6 +14,8 @@
 //   k_split_amount, k_synth   staging
 // (DB.cpp = /root/reference/src/aqe_backend/core/custom_bplus_db.cpp; the shared device code with the
 // rule and estimator restatements is device_common.hpp; the single-launch multi-round sweep is persist.hip.)
+#include <hip/hip_ext.h>
+
 #include "device_common.hpp"
 
 namespace aqe {
@@ -359,15 +361,18 @@ inline unsigned grid_for(u64 work_items, u64 per_block) {
 
 }  // namespace
 
-hipError_t launch_round(const RoundLaunch& a, hipStream_t s) {
+hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     unsigned grid = grid_for(a.ntiles, kWavesPerBlock);
-    hipLaunchKernelGGL(k_round, dim3(grid), dim3(kBlockThreads), 0, s, a);
+    // with events: they take the dispatch's own begin/end timestamps (what rocprofv3 reports as the kernel's duration)
+    if (ev0) hipExtLaunchKernelGGL(k_round, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL(k_round, dim3(grid), dim3(kBlockThreads), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s) {
+hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     unsigned grid = grid_for(n_idx, static_cast<u64>(kBlockThreads) * kTileUnroll);
-    hipLaunchKernelGGL(k_indexed, dim3(grid), dim3(kBlockThreads), 0, s, a, idx, static_cast<u64>(n_idx));
+    if (ev0) hipExtLaunchKernelGGL(k_indexed, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a, idx, static_cast<u64>(n_idx));
+    else hipLaunchKernelGGL(k_indexed, dim3(grid), dim3(kBlockThreads), 0, s, a, idx, static_cast<u64>(n_idx));
     return hipGetLastError();
 }
 

@@ -110,12 +110,14 @@ constexpr int kPersistThreads = 1024;  // one workgroup of 16 waves per CU
 constexpr int kPersistWaves = kPersistThreads / 64;
 constexpr int kMaxPersistGrid = 256;   // workgroups (a power of two <= CU count)
 constexpr int kPersistInlineFams = 16; // family tables up to this size travel in the kernel arguments
+constexpr int kDecSteps = 32;          // decider: steps (8 workgroup partials each) per batch of loads
 
 // Control block in device memory (zeroed once per plan; the protocol leaves every counter at zero).
 struct PersistCtl {
-    unsigned long long dec[kMaxPersistRounds];  // (epoch << 8) | 1: round complete, its total published
     unsigned long long stop_word;               // (epoch << 8) | 1 once a decider has ended the query
-    unsigned long long pad[15];
+    unsigned long long pad0[15];
+    unsigned done_mask;                         // bit r: every workgroup partial of round r is published
+    unsigned pad1[31];
     unsigned shard_cnt[kMaxPersistRounds][kPersistShards][kCtlStride];
     unsigned top_cnt[kMaxPersistRounds][kCtlStride];
 };
@@ -126,14 +128,17 @@ struct PersistLaunch {
     uint64_t round_begin[kMaxPersistRounds + 1];  // first tile of each round; [rounds] == ntiles
     uint32_t part_first[kMaxPersistRounds];       // workgroups owning tiles of round r: the cyclic run
     uint32_t part_count[kMaxPersistRounds];       //   [part_first, part_first + part_count) mod grid
+    // Workgroup partials live in ONE flat list in round order: round r owns the slots
+    // [8 step_begin[r], 8 step_begin[r+1]) (part_count[r] rounded up to 8; pad slots stay zero), the i-th
+    // workgroup of its run writes slot 8 step_begin[r] + i.  A "step" is 8 slots = 64 doubles = one wave load.
+    uint32_t step_begin[kMaxPersistRounds + 1];
     uint32_t rounds;
     uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
     uint32_t finalize_here;    // 1: the ending decider also writes the result (no top-up launch follows)
     uint32_t totals_only;      // 1: no decisions in the kernel; every slot's total is written to out_totals
     unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's
     PersistCtl* ctl;
-    double* partials;          // [rounds][gridDim.x][kVec]  workgroup partials
-    double* round_totals;      // [rounds][kVec]             published by each round's decider
+    double* partials;          // [step_begin[rounds] + kDecSteps][8][kVec]  workgroup partials, flat
     double* out_totals;        // totals_only: [rounds][kVec] (this shard's slot totals, for the all-reduce)
     const uint16_t* expected;  // [rounds][kPersistShards + 1]: participating workgroups per shard, then shards
     QueryState* state;
@@ -144,12 +149,14 @@ struct PersistLaunch {
     DevFamily fams[kPersistInlineFams];
 };
 
-hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s);
+// ev0/ev1 (optional): events that receive the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL)
+hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup_slot, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);
 
-hipError_t launch_round(const RoundLaunch& a, hipStream_t s);
-hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s);
+hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s, hipEvent_t ev0 = nullptr,
+                          hipEvent_t ev1 = nullptr);
 hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, int reset_state, hipStream_t s);
 hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe_result* out, hipStream_t s);
 

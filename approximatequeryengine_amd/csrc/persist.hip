@@ -12,14 +12,13 @@
 //   * when the last wave of a workgroup leaves round r it sums the workgroup's waves through LDS, publishes
 //     the workgroup's partial (n, S-c n, Q) x {fast, slow} with write-through stores and draws a ticket
 //     (sharded counters: a same-address device atomic costs ~20 ns and serialises);
-//   * the wave that draws round r's last ticket is its DECIDER.  In ONE batch of loads it fetches the round's
-//     workgroup partials, the "complete" flags of the earlier rounds and their published round totals; it
-//     sums in workgroup order (bit-reproducible), publishes its own round total + flag, and replays the folds
-//     of rounds 0..r — every lane q <= r evaluating round q's stop rule (DB.cpp:936-961, 993-1016) on the
-//     prefix sums in parallel.  Exactly one decider finds that ITS round is the first to satisfy the rule (or
-//     is the last round): that one writes the state and the result and raises should_stop.  Deciders never
-//     wait for each other in the common case, and a decision is a pure function of the published partials,
-//     so speculative work past the stopping round cannot change the answer;
+//   * the wave that draws round r's last ticket is its DECIDER (decide_round below): one atomic OR settles which
+//     decider judges which rounds, one batch of loads fetches the workgroup partials of the complete prefix,
+//     and every round of the prefix is judged at once, lane q evaluating round q's stop rule
+//     (DB.cpp:936-961, 993-1016).  Exactly one decider owns the first round that satisfies the rule (or the
+//     last round): that one writes the state and the result and raises should_stop.  Deciders never wait for
+//     each other, sums are taken in a fixed order (bit-reproducible), and a decision is a pure function of
+//     the published partials, so speculative work past the stopping round cannot change the answer;
 //   * every wave reads the stop word beside the loads of each tile (an sc1 load in the same vmcnt queue):
 //     after a stop it sweeps nothing more and only hands in its remaining tickets, so every counter is back
 //     at zero when the launch ends.
@@ -27,6 +26,8 @@
 // Hand-offs follow cdna_hip_programming.md Guideline 16 in its all-sc1 form: every shared word is written by
 // ONE lane (or one lane per word) with 8-byte agent-scope stores, drained (s_waitcnt vmcnt(0)) before the
 // ticket / flag that publishes it, and read with agent-scope loads.  Every spin is bounded.
+#include <hip/hip_ext.h>
+
 #include "device_common.hpp"
 
 namespace aqe {
@@ -72,137 +73,147 @@ __device__ __forceinline__ void state_store(QueryState* g, const QueryState& st)
     for (unsigned i = 0; i < sizeof(QueryState) / 8; ++i) __hip_atomic_store(d + i, s[i], AQE_RLX);
 }
 
-// xor-butterfly over the lanes that share (lane & 7): every lane ends with the sum of its 8-lane class.
-__device__ __forceinline__ double class_sum8(double v) {
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
+#ifndef AQE_DECIDE_INLINE
+#define AQE_DECIDE_INLINE __forceinline__
+#endif
+static_assert(kVec == 8, "a step of the flat partial list is 8 slots x 8 doubles = one 64-lane load");
 
-constexpr int kDeciderLoads = kMaxPersistGrid / 8;  // workgroup partials per lane (8 lanes share a component)
+// Decider scratch: the running per-lane sums of one batch of steps.  One decider per workgroup at a time.
+__shared__ double lds_run[kDecSteps][64];
+__shared__ unsigned lds_dec_lock;
 
-// The decider of round r (one whole wave).
-// Not inlined on purpose: it runs once per round in the whole grid, and inlining lets hipcc hoist its address
-// arithmetic into every wave's prologue (and spill it).  It reads the launch descriptor through the kernarg
-// pointer only.
-__device__ __noinline__ void decide_round(KargPtr Kv, unsigned rv) {
-    // arguments arrive in vector registers: make them provably wave-uniform so the descriptor is read with
-    // scalar loads instead of a chain of dependent vector loads
-    const KargPtr K = (KargPtr)uniform64(reinterpret_cast<u64>(Kv));
-    const unsigned r = __builtin_amdgcn_readfirstlane(rv);
-    const int lane = threadIdx.x & 63;
+// The decider of round r (one whole wave): the wave that drew the round's last ticket, so every workgroup
+// partial of round r is published.
+//
+// Who judges which round is settled by ONE atomic: the decider ORs bit r into done_mask.  If every earlier
+// round's bit was already set, this decider extends the complete prefix from r to the first still-open round
+// p and is RESPONSIBLE for rounds [r, p); otherwise the decider of the lowest open round will extend the
+// prefix over r when it arrives, and this one is finished.  Nobody waits for anybody.  The responsible decider
+// loads the flat list of workgroup partials of rounds [0, p) in one batch (64 lanes x 8 B = one step of 8
+// workgroups per load, coalesced), keeps a running sum per lane, and lane q picks the prefix total through
+// round q out of LDS: all stop rules (DB.cpp:936-961, 993-1016) are evaluated at once, lane q judging round q.
+// A decision is a pure function of the published partials, so two responsible deciders that overlap in time
+// agree on the first stopping round and exactly one of them owns it.
+//
+// It runs once per round in the whole grid, so none of it may leak into the sweep: the descriptor pointer and
+// the round are passed through an empty asm, which keeps hipcc from hoisting the decider's address arithmetic
+// into every wave's prologue (and spilling it), and it reads the launch descriptor through the kernarg pointer
+// only (scalar loads).  Inlined: as a called function it would save and restore callee-saved vector registers
+// through scratch — a memory round trip on the way out, on the critical path of the launch.
+__device__ AQE_DECIDE_INLINE void decide_round(KargPtr Kv, unsigned rv) {
+    u64 kbits = uniform64(reinterpret_cast<u64>(Kv));
+    unsigned r = __builtin_amdgcn_readfirstlane(rv);
+    asm volatile("" : "+s"(kbits), "+s"(r));
+    const KargPtr K = (KargPtr)kbits;
+    const unsigned lane = threadIdx.x & 63;
     PersistCtl* const ctl = K->ctl;
-    const unsigned long long epoch = K->epoch;
     const unsigned rounds = K->rounds;
-    double* const round_totals = K->round_totals;
-    const unsigned long long tag = epoch << 8;
+    const unsigned long long stop_tag = (K->epoch << 8) | 1ull;
     const bool totals_only = K->totals_only != 0;
     stamp_round(K->stamps, r, 3, lane);
-    if (!totals_only && __hip_atomic_load(&ctl->stop_word, AQE_RLX) == (tag | 1ull)) {  // an earlier round already ended the query
-        if (lane == 0) __hip_atomic_store(&ctl->dec[r], tag | 1ull, AQE_RLX);
-        return;
-    }
-    // the workgroups that own tiles of round r form one cyclic run [first, first + count) of workgroup ids
-    const unsigned part_first = K->part_first[r], part_count = K->part_count[r], gmask = gridDim.x - 1;
-    const int c = lane & 7, j = lane >> 3;
-    const double* part = K->partials + static_cast<size_t>(r) * gridDim.x * kVec;
 
-    // ---- one batch of loads: this round's workgroup partials, earlier rounds' flags and round totals ----
-    double x[kDeciderLoads];
-    bool use[kDeciderLoads];
-#pragma unroll
-    for (int m = 0; m < kDeciderLoads; ++m) {  // lane (c, j) takes workgroups j, j + 8, j + 16, ...
-        const unsigned b = static_cast<unsigned>(j + 8 * m);
-        use[m] = c < 7 && b < gridDim.x && ((b - part_first) & gmask) < part_count;
-        x[m] = __hip_atomic_load(part + (use[m] ? static_cast<size_t>(b) * kVec + c : 0), AQE_RLX);
+    unsigned q_lo = r, q_hi = r + 1;  // rounds whose (prefix) totals this decider needs
+    if (!totals_only) {
+        const unsigned bit = 1u << r, full = rounds >= 32 ? ~0u : (1u << rounds) - 1u;
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_or(&ctl->done_mask, bit, AQE_RLX);
+        const unsigned long long sw = __hip_atomic_load(&ctl->stop_word, AQE_RLX);
+        old = __builtin_amdgcn_readfirstlane(old);
+        const unsigned now = old | bit;
+        // every round's decider comes here exactly once per launch: the last one leaves the mask at zero
+        if (now == full && lane == 0) __hip_atomic_store(&ctl->done_mask, 0u, AQE_RLX);
+        if (sw == stop_tag) return;                       // an earlier round already ended the query
+        if ((old & (bit - 1u)) != bit - 1u) return;       // an earlier round is still open: its decider judges this one
+        asm volatile("" ::: "memory");                    // the partial loads below stay behind the OR
+        q_lo = 0;
+        q_hi = now == ~0u ? 32u : static_cast<unsigned>(__builtin_ctz(~now));
     }
-    const bool watcher = !totals_only && static_cast<unsigned>(lane) < r;  // lane q < r watches round q
-    unsigned long long flag = __hip_atomic_load(&ctl->dec[watcher ? lane : 0], AQE_RLX);
-    double tot_q[7];  // lane q: the published totals of round q
-#pragma unroll
-    for (int cc = 0; cc < 7; ++cc)
-        tot_q[cc] = __hip_atomic_load(round_totals + static_cast<size_t>(watcher ? lane : 0) * kVec + cc, AQE_RLX);
+    const unsigned S0 = totals_only ? K->step_begin[r] : 0u, S1 = K->step_begin[q_hi];
+    // lane q: the step that completes round q
+    const unsigned my_last = K->step_begin[(lane < rounds ? lane : rounds - 1u) + 1u] - 1u;
+    const bool judge = lane >= q_lo && lane < q_hi;
 
-    // ---- this round's total: workgroups ascending within a lane, then the fixed butterfly over j ----
-    double s = 0.0;
-#pragma unroll
-    for (int m = 0; m < kDeciderLoads; ++m) s += use[m] ? x[m] : 0.0;
-    s = class_sum8(s);  // lanes with (lane & 7) == c hold component c
-    stamp_round(K->stamps, r, 4, lane);
-    if (totals_only) {  // multi-GPU form: hand the slot total out; the decision is taken after the all-reduce
-        if (lane < kVec) K->out_totals[static_cast<size_t>(r) * kVec + lane] = lane < 7 ? s : 0.0;
-        return;
-    }
-
-    // ---- publish the round total and the "complete" flag for later deciders (the last round has none) ----
-    if (r + 1 < rounds) {
-        if (lane < 7) __hip_atomic_store(round_totals + static_cast<size_t>(r) * kVec + lane, s, AQE_RLX);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&ctl->dec[r], tag | 1ull, AQE_RLX);
-    }
-
-    // ---- earlier rounds must be complete; normally they are, otherwise wait (bounded) and re-read ----
-    int timed_out = 0;
-    if (!__all(!watcher || (flag >> 8) == epoch)) {
-        for (unsigned spins = 0;; ++spins) {
-            flag = __hip_atomic_load(&ctl->dec[watcher ? lane : 0], AQE_RLX);
-            const unsigned long long sw = __hip_atomic_load(&ctl->stop_word, AQE_RLX);
-            if (sw == (tag | 1ull)) return;
-            if (__all(!watcher || (flag >> 8) == epoch)) break;
-            if (spins > (1u << 22)) { timed_out = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
+    int lock_failed = 0;
+    if (lane == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_exchange(&lds_dec_lock, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+            if (++spins > (1u << 22)) { lock_failed = 1; break; }  // cannot happen: the holder never waits
+            __builtin_amdgcn_s_sleep(2);
         }
-#pragma unroll
-        for (int cc = 0; cc < 7; ++cc)
-            tot_q[cc] = __hip_atomic_load(round_totals + static_cast<size_t>(watcher ? lane : 0) * kVec + cc, AQE_RLX);
     }
-    // lane r gets this round's totals
-#pragma unroll
-    for (int cc = 0; cc < 7; ++cc) {
-        const double mine = read_lane_f64(s, cc);
-        if (static_cast<unsigned>(lane) == r) tot_q[cc] = mine;
-    }
+    lock_failed = __builtin_amdgcn_readfirstlane(lock_failed);
 
-    // ---- replay: prefix sums in round order (the order of the one-launch-per-round path); lane q keeps
-    //      the state after round q and evaluates that round's stop rule; all rounds are judged at once ----
-    double run[7] = {0, 0, 0, 0, 0, 0, 0}, mine[7] = {0, 0, 0, 0, 0, 0, 0};
+    // ---- the flat partial list, kDecSteps steps per batch of loads; lane = 8 j + c holds component c of the
+    //      j-th workgroup of each step; `run` = sum of everything this lane has seen since S0 ----
+    const double* const flat = K->partials;
+    double run = 0.0;
+    double tot[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
-    for (unsigned q = 0; q <= r; ++q) {
+    for (unsigned m0 = S0; m0 < S1; m0 += kDecSteps) {
+        double x[kDecSteps];
 #pragma unroll
-        for (int cc = 0; cc < 7; ++cc) {
-            run[cc] += read_lane_f64(tot_q[cc], static_cast<int>(q));
-            if (static_cast<unsigned>(lane) == q) mine[cc] = run[cc];
+        for (int m = 0; m < kDecSteps; ++m) x[m] = __hip_atomic_load(flat + static_cast<size_t>(m0 + m) * 64 + lane, AQE_RLX);
+#pragma unroll
+        for (int m = 0; m < kDecSteps; ++m) {
+            if (m0 + m < S1) run += x[m];
+            lds_run[m][lane] = run;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave writes and reads: LDS is in order
+        const unsigned e = my_last - m0;                    // wraps to a large value before this batch
+        if (judge && e < static_cast<unsigned>(kDecSteps)) {
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += lds_run[e][8 * j + cc];  // workgroup classes in fixed order
+                tot[cc] = t;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read before the next batch overwrites
     }
+    if (lane == 0 && !lock_failed) __hip_atomic_store(&lds_dec_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    stamp_round(K->stamps, r, 4, lane);
+
+    if (totals_only) {  // multi-GPU form: hand the slot total out; the decision is taken after the all-reduce
+        if (lane == r) {
+            double* o = K->out_totals + static_cast<size_t>(r) * kVec;
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc) o[cc] = tot[cc];
+            o[7] = 0.0;
+        }
+        return;
+    }
+
+    // ---- lane q holds the moments after round q: judge every round of the prefix at once ----
     int code = 0;
     FoldParams fp;
     fp.shift = K->fold.shift; fp.z = K->fold.z; fp.e = K->fold.e; fp.base = K->fold.base; fp.is_clt = K->fold.is_clt; fp.is_topup = 0; fp.pad = 0;
-    if (fp.is_clt && static_cast<unsigned>(lane) <= r)
-        code = clt_rules(mine[0], mine[1], mine[2], mine[3], mine[4], mine[5], fp);
+    if (fp.is_clt && judge) code = clt_rules(tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], fp);
     const unsigned long long stops = __ballot(code != 0);
     const unsigned first = stops ? static_cast<unsigned>(__builtin_ctzll(stops)) : ~0u;
-    if (first < r) return;  // an earlier round ends the query: its own decider reports it
-    if (!(first == r || r + 1 == rounds || timed_out)) return;  // the query goes on
+    if (first < r) return;  // a round before this decider's range ends the query: the decider that owns it reports it
+    unsigned last_round;
+    if (first < q_hi) last_round = first;                 // the rule is satisfied after round `first`
+    else if (q_hi == rounds) last_round = rounds - 1u;    // samples exhausted
+    else return;                                          // the query goes on
 
-    // ---- this round ends the query (rule satisfied, or samples exhausted) ----
-    if (static_cast<unsigned>(lane) == r) {
+    if (lane == last_round) {
         QueryState st{};
-        st.n_a = mine[0]; st.sd_a = mine[1]; st.qd_a = mine[2];
-        st.n_b = mine[3]; st.sd_b = mine[4]; st.qd_b = mine[5];
-        st.n_p = mine[0] + mine[3]; st.sd_p = mine[1] + mine[4]; st.qd_p = mine[2] + mine[5];
-        st.visited = mine[6];
-        st.rounds = static_cast<int32_t>(r + 1);
+        st.n_a = tot[0]; st.sd_a = tot[1]; st.qd_a = tot[2];
+        st.n_b = tot[3]; st.sd_b = tot[4]; st.qd_b = tot[5];
+        st.n_p = tot[0] + tot[3]; st.sd_p = tot[1] + tot[4]; st.qd_p = tot[2] + tot[5];
+        st.visited = tot[6];
+        st.rounds = static_cast<int32_t>(last_round + 1u);
         st.converged = code;
         st.stop = code != 0;
-        st.error = timed_out;
+        st.error = lock_failed;
         FinalizeParams fin;
         fin.n_global = K->fin.n_global; fin.pct = K->fin.pct; fin.shift = K->fin.shift; fin.agg = K->fin.agg;
         fin.convention = K->fin.convention; fin.is_exact = K->fin.is_exact; fin.is_clt = K->fin.is_clt;
         state_store(K->state, st);
-        if (K->finalize_here) finalize(st, fin, K->result);  // else the top-up launch that follows writes the result  // the top-up launch, if it runs, rewrites the result
+        if (K->finalize_here) finalize(st, fin, K->result);  // else the top-up launch that follows writes the result
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // state and result are out before should_stop is
-        __hip_atomic_store(&ctl->stop_word, tag | 1ull, AQE_RLX);
+        __hip_atomic_store(&ctl->stop_word, stop_tag, AQE_RLX);
     }
     stamp_round(K->stamps, r, 5, lane);
 }
@@ -219,7 +230,8 @@ __device__ __forceinline__ void block_publish(const PersistLaunch& P, KargPtr K,
 #pragma unroll
             for (int w = 0; w < kPersistWaves; ++w)  // only waves that swept tiles of the round wrote their slot
                 if (wave_has_tile(static_cast<u64>(blockIdx.x) * kPersistWaves + w, W, b0, b1)) s += lds_part[r][w][lane];
-            __hip_atomic_store(P.partials + (static_cast<size_t>(r) * gridDim.x + blockIdx.x) * kVec + lane, s, AQE_RLX);
+            const size_t slot = 8u * static_cast<size_t>(K->step_begin[r]) + ((blockIdx.x - K->part_first[r]) & (gridDim.x - 1u));
+            __hip_atomic_store(P.partials + slot * kVec + lane, s, AQE_RLX);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -269,6 +281,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
     __shared__ DevFamily lds_fams[kMaxLdsFams];
     for (unsigned i = threadIdx.x; i < P.rounds * (kPersistShards + 1); i += kPersistThreads) lds_ex[i] = P.expected[i];
     if (threadIdx.x < kMaxPersistRounds) lds_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) lds_dec_lock = 0;
     const KargPtr K = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     if (P.totals_only && blockIdx.x == 0 && threadIdx.x < P.rounds * kVec) {  // slots with no tile on this shard
         const unsigned r0 = threadIdx.x / kVec;
@@ -335,8 +348,9 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
 
 }  // namespace
 
-hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s) {
-    hipLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kPersistThreads), 0, s, a);
+hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) hipExtLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kPersistThreads), 0, s, a);
     return hipGetLastError();
 }
 

@@ -266,8 +266,9 @@ AQE_API int aqe_plan_fetch(aqe_plan* plan, aqe_result* out, void* stream); /* sy
 /* device time between the first and last kernel of the most recent execution (HIP events) */
 AQE_API int aqe_plan_last_kernel_ms(aqe_plan* plan, float* ms);
 /* Per-launch timing for roofline reports: with profiling on, every sweep launch (rounds, top-up) of the
- * next executions is bracketed by its own HIP event pair on the launch stream; aqe_plan_launch_ms
- * returns the elapsed time of each launch of the most recent execution, in launch order. */
+ * next executions carries its own HIP event pair on the launch stream, attached to the dispatch so that it
+ * reads the kernel's begin/end timestamps (hipExtLaunchKernelGGL); aqe_plan_launch_ms returns the duration
+ * of each launch of the most recent execution, in launch order. */
 AQE_API int aqe_plan_set_profiling(aqe_plan* plan, int enable);
 AQE_API int aqe_plan_launch_ms(aqe_plan* plan, float* ms, uint32_t cap, uint32_t* n_out);
 /* samples (sampled rows) each sweep launch of this shard folds, in launch order; the top-up entry is
