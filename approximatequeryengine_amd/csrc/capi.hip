@@ -71,10 +71,10 @@ struct SweepForm {
     uint32_t slots = 0;       // rounds (+ the top-up as an extra slot in the totals form)
     std::vector<DevFamily> h_fams;
     DevFamily* d_fams = nullptr;
-    uint16_t* d_expected = nullptr;
     double* d_ppart = nullptr;  // flat workgroup partials: [step_begin[slots] + kDecSteps][8][kVec]
     uint32_t step_begin[kMaxPersistRounds + 1] = {0};
     uint64_t round_begin[kMaxPersistRounds + 1] = {0};
+    uint32_t round_mod[kMaxPersistRounds + 1] = {0};
     uint32_t part_first[kMaxPersistRounds] = {0}, part_count[kMaxPersistRounds] = {0};
     uint64_t ntiles = 0, samples = 0;
 };
@@ -98,7 +98,8 @@ struct aqe_plan {
     // in flight on different streams of one GPU (the tail of one query overlaps the sweep of the next).
     double* partials = nullptr;   // [kMaxBlocks][kVec]   k_round / k_indexed
     unsigned* counter = nullptr;  // sharded tickets, zero between launches
-    PersistCtl* d_ctl = nullptr;  // persistent sweep: decisions, stop word, tickets
+    PersistCtl* d_ctl = nullptr;  // persistent sweep: the stop word
+    void* d_rehearsal = nullptr;  // persistent sweep: target of the monitor's rehearsal stores
     // Persistent single-launch forms (persist.hip).  `decide`: whole table on this GPU, decisions taken in the
     // kernel (should_stop).  `totals`: any shard, every round plus the top-up swept speculatively, one total per
     // slot written out — the multi-GPU form: ONE all-reduce of the slot totals, then k_replay decides.
@@ -163,9 +164,9 @@ void destroy_plan(aqe_plan* p) {
     if (p->partials) (void)hipFree(p->partials);
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
+    if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
     for (SweepForm* f : {&p->decide, &p->totals}) {
         if (f->d_fams) (void)hipFree(f->d_fams);
-        if (f->d_expected) (void)hipFree(f->d_expected);
         if (f->d_ppart) (void)hipFree(f->d_ppart);
     }
     if (p->d_state) (void)hipFree(p->d_state);
@@ -340,44 +341,49 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
     F.round_begin[S] = tiles;
     F.ntiles = tiles;
     F.slots = static_cast<uint32_t>(S);
-    const uint64_t G = c->persist_grid, W = G * kPersistWaves;
-    auto wave_has = [&](uint64_t w, uint64_t b0, uint64_t b1) { return b0 + ((w - b0) & (W - 1)) < b1; };
-    std::vector<uint16_t> ex(S * (kPersistShards + 1), 0);
+    // Every wave but the monitor (wave 0 of workgroup 0) is a sweeper: sweeper v (physical wave v + 1) owns
+    // tiles v, v + V, ...  The workgroups that own tiles of a slot form ONE cyclic run of workgroup ids (tiles
+    // are consecutive, sweepers cyclic): find it by enumeration and insist on it — the monitor waits for
+    // exactly these workgroups.
+    const uint64_t G = c->persist_grid, V = G * kPersistWaves - 1;
+    auto sweeper_has = [&](uint64_t v, uint64_t b0, uint64_t b1) { const uint64_t m0 = b0 % V; return b0 + (v >= m0 ? v - m0 : v + V - m0) < b1; };
     for (size_t r = 0; r < S; ++r) {
-        uint16_t* e = &ex[r * (kPersistShards + 1)];
-        for (uint64_t b = 0; b < G; ++b) {
-            bool has = false;
-            for (uint64_t j = 0; j < kPersistWaves; ++j) has = has || wave_has(b * kPersistWaves + j, F.round_begin[r], F.round_begin[r + 1]);
-            if (has) e[b % kPersistShards]++;
-        }
-        for (int s = 0; s < kPersistShards; ++s) if (e[s]) e[kPersistShards]++;
-        // the same set as one cyclic run of workgroup ids (tiles are consecutive, waves cyclic)
-        const uint64_t b0 = F.round_begin[r], len = F.round_begin[r + 1] - b0;
-        uint64_t first = (b0 & (W - 1)) / kPersistWaves, count = G;
-        if (len == 0) {
-            count = 0;
-        } else if (len < W) {
-            const uint64_t last = ((b0 + len - 1) & (W - 1)) / kPersistWaves;
-            count = ((last + G - first) & (G - 1)) + 1;
-            if ((b0 & (W - 1)) > ((b0 + len - 1) & (W - 1)) && last >= first) count = G;  // wrapped onto its own first workgroup
-        }
+        F.round_mod[r] = static_cast<uint32_t>(F.round_begin[r] % V);
+        std::vector<char> member(G, 0);
         uint64_t members = 0;
-        for (int s = 0; s < kPersistShards; ++s) members += e[s];
-        if (members != count) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation run mismatch");
+        for (uint64_t b = 0; b < G; ++b) {
+            for (uint64_t j = 0; j < kPersistWaves && !member[b]; ++j) {
+                const uint64_t phys = b * kPersistWaves + j;
+                if (phys != 0 && sweeper_has(phys - 1, F.round_begin[r], F.round_begin[r + 1])) member[b] = 1;
+            }
+            members += member[b];
+        }
+        uint64_t first = 0;
+        if (members != 0 && members != G) {
+            uint64_t starts = 0;
+            for (uint64_t b = 0; b < G; ++b)
+                if (member[b] && !member[(b + G - 1) % G]) { first = b; ++starts; }
+            if (starts != 1) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation is not one cyclic run");
+        }
+        for (uint64_t i = 0; i < members; ++i)
+            if (!member[(first + i) % G]) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation is not one cyclic run");
         F.part_first[r] = static_cast<uint32_t>(first);
-        F.part_count[r] = static_cast<uint32_t>(count);
-        F.step_begin[r + 1] = F.step_begin[r] + static_cast<uint32_t>((count + 7) / 8);
+        F.part_count[r] = static_cast<uint32_t>(members);
+        F.step_begin[r + 1] = F.step_begin[r] + static_cast<uint32_t>((members + 7) / 8);
     }
+    F.round_mod[S] = static_cast<uint32_t>(F.round_begin[S] % V);
     if (!F.h_fams.empty()) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_fams), F.h_fams.size() * sizeof(DevFamily)));
         HIPCHK(c, hipMemcpy(F.d_fams, F.h_fams.data(), F.h_fams.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
     }
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_expected), std::max<size_t>(ex.size(), 1) * sizeof(uint16_t)));
-    HIPCHK(c, hipMemcpy(F.d_expected, ex.data(), ex.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    // the decider reads whole batches of kDecSteps steps: keep one batch of slack behind the last slot
-    const size_t pp = sizeof(double) * kVec * 8 * (static_cast<size_t>(F.step_begin[S]) + kDecSteps);
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), pp));
-    HIPCHK(c, hipMemset(F.d_ppart, 0, pp));
+    // the monitor reads whole windows of kDecSteps steps: keep one window of slack behind the last slot.
+    // Pad slots (a round's run rounded up to 8) are never written: zero data, flag word "always published".
+    std::vector<uint64_t> init(static_cast<size_t>(kVec) * 8 * (static_cast<size_t>(F.step_begin[S]) + kDecSteps), 0);
+    for (size_t r = 0; r < S; ++r)
+        for (size_t slot = 8 * static_cast<size_t>(F.step_begin[r]) + F.part_count[r]; slot < 8 * static_cast<size_t>(F.step_begin[r + 1]); ++slot)
+            init[slot * kVec + 7] = kSlotAlways;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), init.size() * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     F.ok = true;
     return AQE_OK;
 }
@@ -487,6 +493,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         if (p->decide.ok || p->totals.ok) {
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
             HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
+            HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
         }
     }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
@@ -522,16 +529,17 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     a.ntiles = F.ntiles;
     for (uint32_t r = 0; r <= F.slots; ++r) a.round_begin[r] = F.round_begin[r];
     for (uint32_t r = 0; r < F.slots; ++r) { a.part_first[r] = F.part_first[r]; a.part_count[r] = F.part_count[r]; }
-    for (uint32_t r = 0; r <= F.slots; ++r) a.step_begin[r] = F.step_begin[r];
+    for (uint32_t r = 0; r <= F.slots; ++r) { a.step_begin[r] = F.step_begin[r]; a.round_mod[r] = F.round_mod[r]; }
     a.rounds = F.slots;
     a.epoch = c->epoch++;
     a.ctl = p->d_ctl;
     a.partials = F.d_ppart;
-    a.expected = F.d_expected;
     a.state = p->d_state;
     a.fold = fold_params(p, false);
     a.fin = finalize_params(p);
     a.result = p->d_result;
+    a.rehearsal_state = static_cast<QueryState*>(p->d_rehearsal);
+    a.rehearsal_result = reinterpret_cast<aqe_result*>(static_cast<char*>(p->d_rehearsal) + sizeof(QueryState));
     a.stamps = c->d_stamps;
     a.finalize_here = p->host.has_topup ? 0u : 1u;
     a.totals_only = totals_only ? 1u : 0u;
@@ -586,26 +594,30 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
         std::vector<unsigned long long> st(8 * W + 8 * kMaxPersistRounds);
         (void)hipMemcpy(st.data(), c->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* f = std::fopen(std::getenv("AQE_PERSIST_STAMPS"), "a")) {
-            unsigned long long t0 = ~0ull, s_hi = 0, f_lo = ~0ull, f_hi = 0, l_hi = 0, e_hi = 0;
+            unsigned long long t0 = ~0ull, s_hi = 0, f_lo = ~0ull, f_hi = 0, l_hi = 0, e_hi = 0, h_hi = 0, p_hi = 0, d_hi = 0;
             for (size_t w = 0; w < W; ++w) {
                 const unsigned long long* q = &st[8 * w];
                 if (q[0]) { t0 = std::min(t0, q[0]); s_hi = std::max(s_hi, q[0]); }
                 if (q[1]) { f_lo = std::min(f_lo, q[1]); f_hi = std::max(f_hi, q[1]); }
                 l_hi = std::max(l_hi, q[2]);
                 e_hi = std::max(e_hi, q[3]);
+                h_hi = std::max(h_hi, q[4]);
+                p_hi = std::max(p_hi, q[5]);
+                d_hi = std::max(d_hi, q[6]);
             }
             auto us = [&](unsigned long long v) { return v == 0 || v == ~0ull ? -1.0 : (static_cast<double>(v) - static_cast<double>(t0)) / 100.0; };
-            std::fprintf(f, "starts ..%.2f first-tile %.2f..%.2f last-tile %.2f end %.2f |", us(s_hi), us(f_lo), us(f_hi), us(l_hi), us(e_hi));
+            std::fprintf(f, "starts ..%.2f first-tile %.2f..%.2f last-tile %.2f handed %.2f stored %.2f drained %.2f end %.2f |", us(s_hi), us(f_lo),
+                         us(f_hi), us(l_hi), us(h_hi), us(p_hi), us(d_hi), us(e_hi));
             for (size_t r = 0; r < p->rounds.size(); ++r) {
                 const unsigned long long* q = &st[8 * W + 8 * r];
-                std::fprintf(f, " r%zu: chosen %.2f summed %.2f done %.2f |", r, us(q[3]), us(q[4]), us(q[5]));
+                if (r == 0 && q[6]) std::fprintf(f, " rehearsal done %.2f |", us(q[6]));
+                if (q[3]) std::fprintf(f, " ..r%zu: seen %.2f folded %.2f judged %.2f |", r, us(q[3]), us(q[4]), us(q[5]));
             }
             std::fprintf(f, "\n");
             std::fclose(f);
         }
     }
-    if (out->device_status != 0) {  // the round protocol gave up waiting: counters may be left mid-count
-        if (p->d_ctl) (void)hipMemset(p->d_ctl, 0, sizeof(PersistCtl));
+    if (out->device_status != 0) {  // the monitor gave up waiting for a workgroup's partial
         return fail(c, AQE_ERR_HIP, "device-side round protocol timed out");
     }
     if (p->timed) {

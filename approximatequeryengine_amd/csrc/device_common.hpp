@@ -23,31 +23,47 @@ __device__ __forceinline__ u64 uniform64(u64 x) {
 }
 
 // Sum SEVEN per-lane values over the wave with 10 exchanges instead of 42: a butterfly that halves the
-// number of components a lane carries at each of the first three steps (xor 32, 16, 8) and then finishes
+// number of components a lane carries at each of the first three steps (lane bits 5, 4, 3) and then finishes
 // the one remaining component over the low three lane bits.  On return lane L holds the wave total of
-// component (L >> 3) for (L >> 3) < 7 — in all eight lanes of that class.  Fixed exchange pattern:
-// bitwise reproducible.
+// component (L >> 3) for (L >> 3) < 7 — in all eight lanes of that class.  Fixed exchange pattern: bitwise
+// reproducible.  Every exchange is a VALU cross-lane move (gfx950 v_permlane32_swap / v_permlane16_swap, DPP
+// row_ror / quad_perm / row_half_mirror): no LDS round trips — this sits on the critical path of every
+// hand-off.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// lanes < 32: a[L] + a[L + 32];  lanes >= 32: b[L - 32] + b[L]
+__device__ __forceinline__ double swap_add32(double a, double b) {
+    const u32x2 lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2loint(a)), static_cast<unsigned>(__double2loint(b)), false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2hiint(a)), static_cast<unsigned>(__double2hiint(b)), false, false);
+    return __hiloint2double(static_cast<int>(hi.x), static_cast<int>(lo.x)) + __hiloint2double(static_cast<int>(hi.y), static_cast<int>(lo.y));
+}
+// even rows of 16 lanes: a[L] + a[L + 16];  odd rows: b[L - 16] + b[L]
+__device__ __forceinline__ double swap_add16(double a, double b) {
+    const u32x2 lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2loint(a)), static_cast<unsigned>(__double2loint(b)), false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2hiint(a)), static_cast<unsigned>(__double2hiint(b)), false, false);
+    return __hiloint2double(static_cast<int>(hi.x), static_cast<int>(lo.x)) + __hiloint2double(static_cast<int>(hi.y), static_cast<int>(lo.y));
+}
+template <int kCtrl>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum7(const double (&v)[7], int lane) {
-    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
-    double a[4], t[4];
-    // 8 -> 4 components (component 7 is a zero pad)
-    const double v7 = 0.0;
-    t[0] = b5 ? v[0] : v[4]; t[1] = b5 ? v[1] : v[5]; t[2] = b5 ? v[2] : v[6]; t[3] = b5 ? v[3] : v7;
-    a[0] = b5 ? v[4] : v[0]; a[1] = b5 ? v[5] : v[1]; a[2] = b5 ? v[6] : v[2]; a[3] = b5 ? v7 : v[3];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] += __shfl_xor(t[i], 32, 64);
-    // 4 -> 2
-    double s0 = b4 ? a[0] : a[2], s1 = b4 ? a[1] : a[3];
-    double k0 = b4 ? a[2] : a[0], k1 = b4 ? a[3] : a[1];
-    k0 += __shfl_xor(s0, 16, 64);
-    k1 += __shfl_xor(s1, 16, 64);
-    // 2 -> 1
-    double s = b3 ? k0 : k1, k = b3 ? k1 : k0;
-    k += __shfl_xor(s, 8, 64);
-    // the remaining component over lanes that differ in bits 2..0
-    k += __shfl_xor(k, 4, 64);
-    k += __shfl_xor(k, 2, 64);
-    k += __shfl_xor(k, 1, 64);
+    // bit 5: lanes < 32 go on with components 0..3, lanes >= 32 with 4..7 (component 7 is a zero pad)
+    const double u0 = swap_add32(v[0], v[4]), u1 = swap_add32(v[1], v[5]), u2 = swap_add32(v[2], v[6]), u3 = swap_add32(v[3], 0.0);
+    // bit 4: even rows go on with the lower two of their four, odd rows with the upper two
+    const double w0 = swap_add16(u0, u2), w1 = swap_add16(u1, u3);  // rows: components {0,2,4,6} and {1,3,5,7}
+    // bit 3: each half row keeps one component and receives its partner's share of it
+    const bool b3 = (lane & 8) != 0;
+    double k = b3 ? w1 : w0;
+    const double s = b3 ? w0 : w1;
+    k += dpp_f64<0x128>(s);  // row_ror:8 = lane ^ 8 within a row of 16
+    // bits 1, 0, 2 within the half row
+    k += dpp_f64<0xB1>(k);   // quad_perm [1,0,3,2] = lane ^ 1
+    k += dpp_f64<0x4E>(k);   // quad_perm [2,3,0,1] = lane ^ 2
+    k += dpp_f64<0x141>(k);  // row_half_mirror: the other quad of the half row (all four of its lanes agree)
     return k;
 }
 
@@ -121,7 +137,7 @@ __device__ __forceinline__ void fold(QueryState& s, const double (&vec)[kVec], c
 }
 
 // Estimate + interval from the folded state (CLI:189-200, 277-291; DB.cpp:303-315).
-__device__ __forceinline__ void finalize(const QueryState& s, const FinalizeParams& p, aqe_result* out) {
+__device__ __forceinline__ aqe_result make_result(const QueryState& s, const FinalizeParams& p) {
     aqe_result r;
     const double n = s.n_p, visited = s.visited, c = p.shift;
     double mean = 0.0, m2 = 0.0;
@@ -166,8 +182,9 @@ __device__ __forceinline__ void finalize(const QueryState& s, const FinalizePara
     r.margin = margin;
     r.ci_lower = value - margin;
     r.ci_upper = value + margin;
-    *out = r;
+    return r;
 }
+__device__ __forceinline__ void finalize(const QueryState& s, const FinalizeParams& p, aqe_result* out) { *out = make_result(s, p); }
 
 // Per-tile accumulator (one pointer group per tile), merged into the lane's two groups with selects:
 // a data-dependent choice of WHICH accumulator to update makes hipcc index the struct in scratch.

@@ -104,33 +104,33 @@ struct RoundLaunch {
 
 // ---- persistent single-launch sweep of a multi-round (CLT) query: persist.hip ------------------
 constexpr int kMaxPersistRounds = 32;
-constexpr int kPersistShards = 16;
-constexpr int kCtlStride = 32;         // u32 words between counters (128-byte lines)
 constexpr int kPersistThreads = 1024;  // one workgroup of 16 waves per CU
 constexpr int kPersistWaves = kPersistThreads / 64;
 constexpr int kMaxPersistGrid = 256;   // workgroups (a power of two <= CU count)
 constexpr int kPersistInlineFams = 16; // family tables up to this size travel in the kernel arguments
-constexpr int kDecSteps = 32;          // decider: steps (8 workgroup partials each) per batch of loads
+constexpr int kDecSteps = 32;          // monitor: steps (8 workgroup partials each) per batch of loads
 
-// Control block in device memory (zeroed once per plan; the protocol leaves every counter at zero).
+static_assert(kMaxPersistGrid / 8 <= kDecSteps, "a round's slots fit the monitor's window");
+constexpr unsigned long long kSlotAlways = ~0ull;  // flag word of a pad slot: always "published"
+
+// Control block in device memory (zeroed once per plan).
 struct PersistCtl {
-    unsigned long long stop_word;               // (epoch << 8) | 1 once a decider has ended the query
-    unsigned long long pad0[15];
-    unsigned done_mask;                         // bit r: every workgroup partial of round r is published
-    unsigned pad1[31];
-    unsigned shard_cnt[kMaxPersistRounds][kPersistShards][kCtlStride];
-    unsigned top_cnt[kMaxPersistRounds][kCtlStride];
+    unsigned long long stop_word;  // (epoch << 8) | 1 once the monitor has ended the query
+    unsigned long long pad[15];
 };
 
 struct PersistLaunch {
     SweepCommon sw;            // family table of ALL rounds, tile_begin numbered across the whole launch
     uint64_t ntiles;
     uint64_t round_begin[kMaxPersistRounds + 1];  // first tile of each round; [rounds] == ntiles
+    uint32_t round_mod[kMaxPersistRounds + 1];    // round_begin[r] mod (number of sweepers)
     uint32_t part_first[kMaxPersistRounds];       // workgroups owning tiles of round r: the cyclic run
     uint32_t part_count[kMaxPersistRounds];       //   [part_first, part_first + part_count) mod grid
     // Workgroup partials live in ONE flat list in round order: round r owns the slots
-    // [8 step_begin[r], 8 step_begin[r+1]) (part_count[r] rounded up to 8; pad slots stay zero), the i-th
-    // workgroup of its run writes slot 8 step_begin[r] + i.  A "step" is 8 slots = 64 doubles = one wave load.
+    // [8 step_begin[r], 8 step_begin[r+1]) (part_count[r] rounded up to 8; pad slots stay zero and carry the
+    // flag kSlotAlways), the i-th workgroup of its run writes slot 8 step_begin[r] + i: doubles 0..6 = its
+    // partial, word 7 = the launch's epoch once the partial is out.  A "step" is 8 slots = 64 doubles = one
+    // wave load.
     uint32_t step_begin[kMaxPersistRounds + 1];
     uint32_t rounds;
     uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
@@ -140,11 +140,12 @@ struct PersistLaunch {
     PersistCtl* ctl;
     double* partials;          // [step_begin[rounds] + kDecSteps][8][kVec]  workgroup partials, flat
     double* out_totals;        // totals_only: [rounds][kVec] (this shard's slot totals, for the all-reduce)
-    const uint16_t* expected;  // [rounds][kPersistShards + 1]: participating workgroups per shard, then shards
     QueryState* state;
     FoldParams fold;
     FinalizeParams fin;
     aqe_result* result;
+    QueryState* rehearsal_state;     // where the monitor's rehearsal writes (never read)
+    aqe_result* rehearsal_result;
     unsigned long long* stamps;  // diagnostics only (AQE_PERSIST_STAMPS): s_memrealtime marks, else null
     DevFamily fams[kPersistInlineFams];
 };
