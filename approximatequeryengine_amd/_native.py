@@ -43,7 +43,7 @@ class Result(C.Structure):
         ("sum", C.c_double), ("sumsq", C.c_double), ("mean", C.c_double), ("m2", C.c_double),
         ("n", C.c_uint64), ("visited", C.c_uint64), ("topup", C.c_uint64), ("converged", C.c_int32),
         ("rounds", C.c_int32), ("kernel_ms", C.c_double), ("bytes_algorithmic", C.c_uint64),
-        ("device_status", C.c_int32), ("reserved1", C.c_int32),
+        ("device_status", C.c_int32), ("topup_pending", C.c_int32),
     ]
 
     def as_dict(self):
@@ -125,6 +125,11 @@ def lib() -> C.CDLL:
         "aqe_plan_totals_len": (C.c_int, [vp, P(u32)]),
         "aqe_plan_enqueue_sweep_totals": (C.c_int, [vp, vp, vp]),
         "aqe_plan_enqueue_replay": (C.c_int, [vp, vp, vp]),
+        "aqe_batch_create": (C.c_int, [P(vp), u32, P(vp)]),
+        "aqe_batch_destroy": (None, [vp]),
+        "aqe_batch_enqueue_sweeps": (C.c_int, [vp, vp, u64, vp]),
+        "aqe_batch_enqueue_replays": (C.c_int, [vp, vp, u64, vp]),
+        "aqe_batch_fetch": (C.c_int, [vp, P(Result)]),
         "aqe_plan_reset": (C.c_int, [vp, vp]),
         "aqe_plan_fetch": (C.c_int, [vp, P(Result), vp]),
         "aqe_plan_last_kernel_ms": (C.c_int, [vp, P(C.c_float)]),

@@ -317,8 +317,8 @@ int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup,
     return AQE_OK;
 }
 
-// Lay the plan's rounds (and, for the totals form, the top-up as one more slot) out as ONE tile list and work
-// out which workgroups own tiles of which slot.
+// Lay the plan's rounds (optionally the top-up as one more slot) out as ONE tile list and work out which
+// workgroups own tiles of which slot.
 int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
     aqe_ctx* c = p->ctx;
     std::vector<const LaunchDesc*> slots;
@@ -486,8 +486,8 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             if (rc2 != AQE_OK) return rc2;
             p->persist = true;
         }
-        if (multi && R + (p->host.has_topup ? 1 : 0) <= static_cast<size_t>(kMaxPersistRounds)) {
-            int rc2 = build_sweep_form(p.get(), true, p->totals);
+        if (multi && R <= static_cast<size_t>(kMaxPersistRounds)) {
+            int rc2 = build_sweep_form(p.get(), false, p->totals);
             if (rc2 != AQE_OK) return rc2;
         }
         if (p->decide.ok || p->totals.ok) {
@@ -1103,8 +1103,109 @@ int aqe_plan_enqueue_replay(aqe_plan* p, const double* dev_totals, void* stream)
     if (!dev_totals) return fail(p->ctx, AQE_ERR_INVALID, "dev_totals is null");
     HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
     const uint32_t R = static_cast<uint32_t>(p->rounds.size());
-    HIPCHK(p->ctx, launch_replay(dev_totals, R, p->totals.slots > R ? 1u : 0u, fold_params(p, false), finalize_params(p),
+    HIPCHK(p->ctx, launch_replay(dev_totals, R, p->host.has_topup ? 1u : 0u, fold_params(p, false), finalize_params(p),
                                  p->d_state, p->d_result, pick(p, stream)));
+    return AQE_OK;
+}
+
+// Side streams of a batch.  Three, not one per plan: the runtime multiplexes streams onto a handful of hardware
+// queues, and a stream that waits on an event blocks every other stream sharing its queue.  Three lanes plus the
+// caller's stream each get a queue of their own, and two kernels in flight are already enough for one query's
+// hand-off tail to overlap the next query's sweep.
+constexpr size_t kBatchLanes = 3;
+
+struct aqe_batch {
+    aqe_ctx* ctx = nullptr;
+    std::vector<aqe_plan*> plans;
+    std::vector<hipStream_t> lanes;  // plan i runs on lane i % lanes.size()
+    std::vector<hipEvent_t> swept;   // lane l's sweeps are enqueued up to here
+    hipEvent_t reduced = nullptr;    // the caller's stream up to (and including) the collective
+};
+
+void aqe_batch_destroy(aqe_batch* b) {
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    for (hipStream_t s : b->lanes) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t e : b->swept) (void)hipEventDestroy(e);
+    if (b->reduced) (void)hipEventDestroy(b->reduced);
+    delete b;
+}
+
+int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out) {
+    if (!plans || !out || n == 0) return AQE_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!plans[i] || !plans[i]->ctx || plans[i]->ctx != plans[0]->ctx) return AQE_ERR_INVALID;
+        if (!plans[i]->totals.ok) return fail(plans[i]->ctx, AQE_ERR_UNSUPPORTED, "a plan of the batch has no batched (totals) form");
+        for (uint32_t j = 0; j < i; ++j)
+            if (plans[j] == plans[i]) return fail(plans[i]->ctx, AQE_ERR_INVALID, "a plan may appear once in a batch (its hand-off scratch is its own)");
+    }
+    aqe_ctx* c = plans[0]->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::unique_ptr<aqe_batch, void (*)(aqe_batch*)> b(new aqe_batch, aqe_batch_destroy);
+    b->ctx = c;
+    b->plans.assign(plans, plans + n);
+    for (size_t l = 0; l < std::min<size_t>(n, kBatchLanes); ++l) {
+        hipStream_t s = nullptr;
+        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        b->lanes.push_back(s);
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->swept.push_back(e);
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&b->reduced, hipEventDisableTiming));
+    *out = b.release();
+    return AQE_OK;
+}
+
+int aqe_batch_enqueue_sweeps(aqe_batch* b, double* dev_totals, uint64_t row_stride, void* stream) {
+    if (!b || !dev_totals) return AQE_ERR_INVALID;
+    aqe_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const size_t L = b->lanes.size();
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        aqe_plan* p = b->plans[i];
+        int rc = plan_is_current(p);
+        if (rc != AQE_OK) return rc;
+        if (row_stride < static_cast<uint64_t>(p->totals.slots) * kVec) return fail(c, AQE_ERR_INVALID, "row_stride shorter than a plan's totals");
+        p->lev_used = 0;
+        // (the plan's previous replay precedes this sweep in its lane: nothing to wait for)
+        rc = launch_form(p, p->totals, true, dev_totals + i * row_stride, b->lanes[i % L]);
+        if (rc != AQE_OK) return rc;
+    }
+    for (size_t l = 0; l < L; ++l) {  // the caller's stream (the collective) waits for every lane
+        HIPCHK(c, hipEventRecord(b->swept[l], b->lanes[l]));
+        HIPCHK(c, hipStreamWaitEvent(main_s, b->swept[l], 0));
+    }
+    return AQE_OK;
+}
+
+int aqe_batch_enqueue_replays(aqe_batch* b, const double* dev_totals, uint64_t row_stride, void* stream) {
+    if (!b || !dev_totals) return AQE_ERR_INVALID;
+    aqe_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const size_t L = b->lanes.size();
+    HIPCHK(c, hipEventRecord(b->reduced, main_s));
+    for (size_t l = 0; l < L; ++l) HIPCHK(c, hipStreamWaitEvent(b->lanes[l], b->reduced, 0));  // every lane waits for the collective
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        aqe_plan* p = b->plans[i];
+        int rc = plan_is_current(p);
+        if (rc != AQE_OK) return rc;
+        HIPCHK(c, launch_replay(dev_totals + i * row_stride, static_cast<uint32_t>(p->rounds.size()), p->host.has_topup ? 1u : 0u,
+                                fold_params(p, false), finalize_params(p), p->d_state, p->d_result, b->lanes[i % L]));
+    }
+    return AQE_OK;
+}
+
+int aqe_batch_fetch(aqe_batch* b, aqe_result* out_n) {
+    if (!b || !out_n) return AQE_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        int rc = plan_is_current(b->plans[i]);
+        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, b->lanes[i % b->lanes.size()]);
+        if (rc != AQE_OK) return rc;
+    }
     return AQE_OK;
 }
 

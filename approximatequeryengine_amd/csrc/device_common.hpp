@@ -156,7 +156,7 @@ __device__ __forceinline__ aqe_result make_result(const QueryState& s, const Fin
     r.kernel_ms = 0.0;
     r.bytes_algorithmic = r.visited * 8ull;
     r.device_status = s.error;
-    r.reserved1 = 0;
+    r.topup_pending = 0;
 
     double moe = 0.0;  // CLI:279-282: two-pass variance, fixed 1.96
     if (n > 1.0) moe = 1.96 * sqrt(m2 / (n - 1.0)) / sqrt(n);

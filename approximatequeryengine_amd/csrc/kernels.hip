@@ -183,11 +183,10 @@ __global__ void k_update(QueryState* s, const double* vec, FoldParams p, int res
     *s = st;
 }
 
-// Multi-GPU form: `totals` holds the all-reduced total of every slot (rounds in order, then the top-up).
-// Replays the folds in round order — lane q keeps the state after round q and judges that round's stop rule,
-// all rounds at once — takes the first stopping round (or the last), applies the top-up gate
-// (DB.cpp:1031-1040) and writes state + result.  Every rank runs it on identical input.
-__global__ void k_replay(const double* __restrict__ totals, unsigned rounds, unsigned has_topup_slot, FoldParams fp,
+// Multi-GPU form: `totals` holds the all-reduced total of every round, in order.  Replays the folds in round
+// order — lane q keeps the state after round q and judges that round's stop rule, all rounds at once — takes
+// the first stopping round (or the last) and writes the state and the result; a due top-up is marked, not run.
+__global__ void k_replay(const double* __restrict__ totals, unsigned rounds, unsigned has_topup, FoldParams fp,
                          FinalizeParams fin, QueryState* state, aqe_result* result) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x != 0 || threadIdx.x >= 64) return;
@@ -220,14 +219,12 @@ __global__ void k_replay(const double* __restrict__ totals, unsigned rounds, uns
         st.converged = code;
         st.stop = code != 0;
     }
-    if (has_topup_slot && st.n_p < static_cast<double>(fp.base / 4)) {  // DB.cpp:1032
-        const double* t = totals + static_cast<size_t>(rounds) * kVec;
-        st.n_p += t[0]; st.sd_p += t[1]; st.qd_p += t[2];
-        st.topup += t[0];
-        st.visited += t[6];
-    }
     *state = st;
-    finalize(st, fin, result);
+    aqe_result r = make_result(st, fin);
+    // DB.cpp:1032: too few rows collected -> the systematic top-up is due.  It is not swept speculatively (a
+    // second pass over the table for a rare case): the caller runs it as one more step when it sees the mark.
+    r.topup_pending = (has_topup && st.n_p < static_cast<double>(fp.base / 4)) ? 1 : 0;
+    *result = r;
 }
 
 __global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* out) {
@@ -381,9 +378,9 @@ hipError_t launch_update(QueryState* state, const double* vec, const FoldParams&
     return hipGetLastError();
 }
 
-hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup_slot, const FoldParams& fp,
+hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s) {
-    hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, s, totals, rounds, has_topup_slot, fp, fin, state, result);
+    hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, s, totals, rounds, has_topup, fp, fin, state, result);
     return hipGetLastError();
 }
 

@@ -152,7 +152,7 @@ struct PersistLaunch {
 
 // ev0/ev1 (optional): events that receive the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL)
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup_slot, const FoldParams& fp,
+hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);
 
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);

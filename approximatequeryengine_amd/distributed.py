@@ -33,10 +33,12 @@ class ShardedQuery:
     vec         a float64 tensor on the plan's device, at least max(MOMENT_VEC, plan.totals_len) long
     all_reduce  callable(tensor) -> None performing an in-place SUM over the group
     stream      raw stream handle passed through to the plan (0 = the plan's own stream)
-    batched     True: ONE collective per query — every round and the top-up are swept speculatively in one
-                launch, the per-slot totals are all-reduced once, and the stop rules are replayed on the
-                reduced totals (identical answer; the rounds after the stop are swept for nothing, which on a
-                10 M-row shard costs less than a single extra collective).  False: one collective per
+    batched     True: ONE collective per query — every round is swept speculatively in one launch, the
+                per-round totals are all-reduced once, and the stop rules are replayed on the reduced totals
+                (identical answer; the rounds after the stop are swept for nothing, which on a 10 M-row shard
+                costs less than a single extra collective).  The reference's top-up (too few rows collected
+                at the stop) is not speculated: when the fetched result says it is due, ``run`` finishes
+                with the stepwise top-up step (one more collective, rare).  False: one collective per
                 convergence step, nothing swept past the stop.  None: batched when the plan offers it.
     """
 
@@ -55,9 +57,9 @@ class ShardedQuery:
         p, v, s = self.plan, self.vec, self.stream
         if self.batched:
             t = v[: p.totals_len]
-            p.enqueue_sweep_totals(t.data_ptr(), s)  # this shard's total of every slot, one launch
+            p.enqueue_sweep_totals(t.data_ptr(), s)  # this shard's total of every round, one launch
             self.all_reduce(t)                       # ONE collective per query
-            p.enqueue_replay(t.data_ptr(), s)        # stop rules + top-up gate + estimate, on the device
+            p.enqueue_replay(t.data_ptr(), s)        # stop rules + estimate, on the device
             return
         p.reset(s)
         steps = p.rounds + (1 if p.has_topup else 0)
@@ -69,35 +71,79 @@ class ShardedQuery:
             p.enqueue_update(r, t.data_ptr(), s) # fold + CLT rules + should_stop, on the device
         p.enqueue_finalize(s)
 
+    def enqueue_topup(self) -> None:
+        """The stepwise top-up step (device-gated): sweep, one collective, fold, estimate."""
+        p, s = self.plan, self.stream
+        t = self.vec[:MOMENT_VEC]
+        t.zero_()
+        p.enqueue_round(p.rounds, t.data_ptr(), s)
+        self.all_reduce(t)
+        p.enqueue_update(p.rounds, t.data_ptr(), s)
+        p.enqueue_finalize(s)
+
     def run(self):
         self.enqueue()
-        return self.plan.fetch(self.stream)
+        res = self.plan.fetch(self.stream)
+        if self.batched and _pending(res):  # every rank reads the same mark: every rank comes here
+            self.enqueue_topup()
+            res = self.plan.fetch(self.stream)
+        return res
+
+
+def _pending(res) -> bool:
+    return bool(res["topup_pending"] if isinstance(res, dict) else getattr(res, "topup_pending", 0))
 
 
 class ShardedBatch:
-    """B independent queries per collective: each query's slot totals land in its own row of one buffer and a
-    single all-reduce serves them all (xGMI collectives are latency-bound at this size: 8 queries x 7 slots x 64 B
-    cost the same ~tens of microseconds as one).  All plans must offer the batched form."""
+    """B independent queries per collective: each query's round totals land in its own row of one buffer and a
+    single all-reduce serves them all (xGMI collectives are latency-bound at this size: 8 queries x 5 rounds x 64 B
+    cost the same ~tens of microseconds as one).  All plans must offer the batched form.
 
-    def __init__(self, plans, buf, all_reduce: Callable, stream: int = 0):
+    batch (optional): an ``engine.Batch`` over the same plans.  The sweeps then run on the batch's own side
+    streams — one query's hand-off tail overlaps the next query's sweep, as in the single-GPU form — the
+    collective (issued on ``stream``) waits for all of them, every replay goes back to its side stream, and the
+    host pays two calls per step instead of two per query."""
+
+    def __init__(self, plans, buf, all_reduce: Callable, stream: int = 0, batch=None):
         if any(getattr(p, "totals_len", 0) == 0 for p in plans):
             raise ValueError("every plan of a ShardedBatch needs a batched (totals) form")
-        self.plans, self.buf, self.all_reduce, self.stream = list(plans), buf, all_reduce, stream
+        self.plans, self.buf, self.all_reduce, self.stream, self.batch = list(plans), buf, all_reduce, stream, batch
         self.width = max(p.totals_len for p in plans)
-        if buf.dim() != 2 or buf.shape[0] < len(self.plans) or buf.shape[1] < self.width:
-            raise ValueError("buffer must be [len(plans), >= totals_len] float64")
+        if buf.dim() != 2 or buf.shape[0] < len(self.plans) or buf.shape[1] < self.width or not buf.is_contiguous():
+            raise ValueError("buffer must be a contiguous [len(plans), >= totals_len] float64 tensor")
 
     def enqueue(self) -> None:
-        s = self.stream
+        s, ptr, stride = self.stream, self.buf.data_ptr(), self.buf.shape[1]
+        if self.batch is not None:
+            self.batch.enqueue_sweeps(ptr, stride, s)
+            self.all_reduce(self.buf)
+            self.batch.enqueue_replays(ptr, stride, s)
+            return
         for i, p in enumerate(self.plans):
             p.enqueue_sweep_totals(self.buf[i].data_ptr(), s)
         self.all_reduce(self.buf)
         for i, p in enumerate(self.plans):
             p.enqueue_replay(self.buf[i].data_ptr(), s)
 
+    def fetch(self):
+        return self.batch.fetch() if self.batch is not None else [p.fetch(self.stream) for p in self.plans]
+
     def run(self):
         self.enqueue()
-        return [p.fetch(self.stream) for p in self.plans]
+        out = self.fetch()
+        due = [i for i, r in enumerate(out) if _pending(r)]
+        if due:  # the rare top-ups of the batch share one more collective (same marks on every rank)
+            s = self.stream
+            vecs = self.buf.view(-1)[: len(self.plans) * MOMENT_VEC].view(len(self.plans), MOMENT_VEC)  # contiguous
+            vecs.zero_()
+            for i in due:
+                self.plans[i].enqueue_round(self.plans[i].rounds, vecs[i].data_ptr(), s)
+            self.all_reduce(vecs)
+            for i in due:
+                self.plans[i].enqueue_update(self.plans[i].rounds, vecs[i].data_ptr(), s)
+                self.plans[i].enqueue_finalize(s)
+                out[i] = self.plans[i].fetch(s)
+        return out
 
 
 def torch_all_reduce(group=None) -> Callable:

@@ -98,6 +98,41 @@ class Plan:
         return ms.value
 
 
+class Batch:
+    """Plans of one Engine driven through the batched multi-GPU form together (aqe_batch): the sweeps run on
+    side streams the batch owns, ``stream`` — where the caller issues the collective — waits for them, and the
+    replays go back to the side streams.  Two host calls per step for the whole batch."""
+
+    def __init__(self, plans):
+        self.plans = list(plans)
+        self.engine = self.plans[0].engine
+        arr = (C.c_void_p * len(self.plans))(*[p._h for p in self.plans])
+        self._h = C.c_void_p()
+        nat.check(nat.lib().aqe_batch_create(arr, len(self.plans), C.byref(self._h)), self.engine._h)
+
+    def close(self):
+        if self._h:
+            nat.lib().aqe_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enqueue_sweeps(self, dev_totals_ptr: int, row_stride: int, stream: int = 0):
+        nat.check(nat.lib().aqe_batch_enqueue_sweeps(self._h, C.c_void_p(dev_totals_ptr), row_stride, C.c_void_p(stream)), self.engine._h)
+
+    def enqueue_replays(self, dev_totals_ptr: int, row_stride: int, stream: int = 0):
+        nat.check(nat.lib().aqe_batch_enqueue_replays(self._h, C.c_void_p(dev_totals_ptr), row_stride, C.c_void_p(stream)), self.engine._h)
+
+    def fetch(self):
+        out = (Result * len(self.plans))()
+        nat.check(nat.lib().aqe_batch_fetch(self._h, out), self.engine._h)
+        return list(out)
+
+
 class Engine:
     """One GPU context holding one shard [shard_lo, shard_lo+local_rows) of a table of global_rows rows."""
 

@@ -44,9 +44,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--error-percent", type=float, default=0.01, help="--e of the reference CLI, in percent")
-    ap.add_argument("--batch", "--streams", dest="batch", type=int, default=8,
+    ap.add_argument("--batch", "--streams", dest="batch", type=int, default=32,
                     help="independent queries per step.  1 GPU: each has its own plan and HIP stream (the decision tail of "
-                         "one overlaps the sweep of the next).  N GPUs: one all-reduce serves the whole batch.")
+                         "one overlaps the sweep of the next).  N GPUs: one all-reduce serves the whole batch "
+                         "(aqe_batch: sweeps on the library's side streams, two host calls per step).")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     return ap.parse_args()
@@ -99,7 +100,7 @@ def main():
     import torch.distributed as dist
     from approximatequeryengine_amd import _native as nat
     from approximatequeryengine_amd.distributed import ShardedBatch, ShardedQuery, shard_bounds, torch_all_reduce
-    from approximatequeryengine_amd.engine import Engine, make_query
+    from approximatequeryengine_amd.engine import Batch, Engine, make_query
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,8 +113,12 @@ def main():
     rehearsal = os.environ.get("AQE_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    # AQE_BENCH_FORCE_DIST=1: take the N>1 code path (RCCL all-reduce of the slot totals, k_replay) with a world of
+    # one rank — the way to exercise RCCL on a one-GPU box; never used for reported numbers.
+    use_dist = world > 1 or os.environ.get("AQE_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -135,17 +140,19 @@ def main():
     # go into one [B, totals] buffer, ONE RCCL all-reduce per step, then k_replay decides each query.
     B = max(1, args.batch)
     plans = [eng.plan(q) for _ in range(B)]
-    sides = [torch.cuda.Stream() for _ in range(B if world == 1 else 1)]
+    sides = [torch.cuda.Stream() for _ in range(1 if use_dist else B)]
     plan, side = plans[0], sides[0]
     st = side.cuda_stream
     n_streams = len(sides)
 
     with torch.cuda.stream(side):
-        if world > 1:
+        if use_dist:
             if plan.totals_len:
                 buf = torch.zeros(B, plan.totals_len, dtype=torch.float64, device="cuda")
-                sb = ShardedBatch(plans, buf, torch_all_reduce(), stream=st)
+                native = Batch(plans)  # side streams owned by the library; two host calls per step
+                sb = ShardedBatch(plans, buf, torch_all_reduce(), stream=st, batch=native)
                 step = sb.enqueue
+                n_streams = 1 + min(B, 3)
                 collectives_per_step = 1
             else:  # plans without a batched form: one collective per convergence step and query
                 vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
@@ -161,13 +168,15 @@ def main():
 
         def fence():
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
         for _ in range(max(args.warmup, 1)):
             step()
-        firsts = [p.fetch(sides[i % n_streams].cuda_stream) for i, p in enumerate(plans)]
+        batched_dist = use_dist and bool(plan.totals_len)
+        fetch_all = sb.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
+        firsts = fetch_all()
         first = firsts[0]
         fence()
         t0 = time.perf_counter()
@@ -175,16 +184,16 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
-        lasts = [p.fetch(sides[i % n_streams].cuda_stream) for i, p in enumerate(plans)]
+        lasts = fetch_all()
         last = lasts[0]
         assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
 
         # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, one query in flight ----
-        if world == 1:
+        if not use_dist:
             one = lambda: plan.enqueue_all(st)  # noqa: E731
         elif plan.totals_len:
             one_buf = torch.zeros(plan.totals_len, dtype=torch.float64, device="cuda")
@@ -228,7 +237,7 @@ def main():
     # committed value in profiles/ is for this exact workload and kernel, and is only reported for it.
     traffic = None
     try:
-        if world == 1 and rows == ROWS_PER_GPU and e == 0.01:
+        if not use_dist and rows == ROWS_PER_GPU and e == 0.01:
             traffic = json.loads((ROOT / "profiles" / "round1_pmc_raw.json").read_text())["k_sweep_persist_traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -247,7 +256,7 @@ def main():
                             "(percent, as the reference CLI reads it: never converges -> full 20% dual-pointer sweep, "
                             "should_stop armed on every launch), table resident in HBM",
                 "rows_per_gpu": rows, "global_rows": n_global, "sample_percent": pct, "error_percent": e,
-                "pointers": 4 * world, "samples_per_query_per_gpu": int(last.visited if world == 1 else visited_local),
+                "pointers": 4 * world, "samples_per_query_per_gpu": int(visited_local if use_dist else last.visited),
                 "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_query": len(samples),
                 "queries_per_step": B, "streams": n_streams,
                 "collectives_per_step": collectives_per_step,
@@ -259,7 +268,7 @@ def main():
                        "converged": int(last.converged), "rounds": int(last.rounds),
                        "same_as_first": bool(first.value == last.value)},
             "roofline": {
-                "bound": "hbm", "kernel": "k_sweep_persist" if world == 1 else "k_round", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_sweep_persist" if (not use_dist or plan.totals_len) else "k_round", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": "profiles/round1_pmc_raw.json (rocprofv3 --pmc, bytes per launch)" if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms,
@@ -270,7 +279,7 @@ def main():
                         "(profiles/round1_bench_kernel_stats.csv); the top-up launch (a no-op here) is excluded",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not use_dist and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(rows, e, args.cpu_sample_rows)
                 line["cpu_baseline"] = cb.get("reference", cb["port"])
@@ -280,10 +289,12 @@ def main():
                                         "sample": f"failed: {ex!r}"}
         print(json.dumps(line), flush=True)
 
+    if use_dist and plan.totals_len:
+        native.close()
     for p in plans:
         p.close()
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -139,7 +139,8 @@ typedef struct aqe_result {
     double kernel_ms;  /* device time of this query's kernels (events on the query stream)   */
     uint64_t bytes_algorithmic; /* 8 B per visited sample (SoA amount column)                 */
     int32_t device_status; /* 0 ok; nonzero: the device-side round protocol reported an error   */
-    int32_t reserved1;
+    int32_t topup_pending; /* batched multi-GPU form only: 1 = the top-up (DB.cpp:1031-1040) is due and has
+                              not been applied; run it as one more step (see aqe_plan_enqueue_replay) */
 } aqe_result;
 
 /* One arithmetic family of sampled rows: row(o) = row0 + (o / seg_len) * pitch + (o % seg_len) * step
@@ -249,16 +250,37 @@ AQE_API int aqe_plan_rounds(const aqe_plan* plan, uint32_t* rounds, int32_t* has
 AQE_API int aqe_plan_enqueue_round(aqe_plan* plan, uint32_t round, double* dev_vec, void* stream);
 AQE_API int aqe_plan_enqueue_update(aqe_plan* plan, uint32_t round, const double* dev_vec, void* stream);
 AQE_API int aqe_plan_enqueue_finalize(aqe_plan* plan, void* stream);
-/* Batched multi-GPU form (plans of 2..31 rounds): ONE launch sweeps every round and the top-up
- * speculatively and writes this shard's total per slot (aqe_plan_totals_len doubles: AQE_MOMENT_VEC per
- * slot, rounds in order then the top-up); ONE all-reduce SUM of that vector; aqe_plan_enqueue_replay then
- * replays the stop rules on the reduced totals, applies the top-up gate and writes the result.  One
- * collective per query instead of one per convergence step — the stop decision is a pure function of the
- * reduced per-round totals, so the answer is identical; what is given up is not sweeping the rounds after
- * the stop.  totals_len == 0: the plan has no batched form (single-round or > 31 rounds). */
+/* Batched multi-GPU form (plans of 2..32 rounds): ONE launch sweeps every round speculatively and writes
+ * this shard's total per round (aqe_plan_totals_len doubles: AQE_MOMENT_VEC per round, in order); ONE
+ * all-reduce SUM of that vector; aqe_plan_enqueue_replay then replays the stop rules on the reduced totals
+ * and writes the result.  One collective per query instead of one per convergence step — the stop decision
+ * is a pure function of the reduced per-round totals, so the answer is identical; what is given up is not
+ * sweeping the rounds after the stop.  The reference's top-up (DB.cpp:1031-1040: fewer than base/4 rows
+ * collected) is NOT swept speculatively: when it is due the fetched result carries topup_pending = 1 and
+ * the caller finishes with the stepwise calls for step r = rounds:
+ *     aqe_plan_enqueue_round(plan, rounds, vec) -> all-reduce -> aqe_plan_enqueue_update(plan, rounds, vec)
+ *     -> aqe_plan_enqueue_finalize -> aqe_plan_fetch
+ * (every rank sees the same mark, so every rank takes the same path).
+ * totals_len == 0: the plan has no batched form (single-round or > 32 rounds). */
 AQE_API int aqe_plan_totals_len(const aqe_plan* plan, uint32_t* n_doubles);
 AQE_API int aqe_plan_enqueue_sweep_totals(aqe_plan* plan, double* dev_totals, void* stream);
 AQE_API int aqe_plan_enqueue_replay(aqe_plan* plan, const double* dev_totals, void* stream);
+/* A batch of plans of ONE context driven through the batched form together, so that one collective serves all
+ * of them and the host pays two calls per step instead of two per query.  The batch owns a few side streams
+ * and deals the plans over them: sweeps run concurrently (one query's hand-off tail overlaps the next query's
+ * sweep), `stream` (the stream the caller issues the collective on) waits for all of them, and after the
+ * collective every replay goes back to its plan's side stream.
+ *     aqe_batch_enqueue_sweeps(b, totals, row_stride, stream)    row i = plan i's round totals
+ *     <ONE all-reduce SUM of the whole [n, row_stride] buffer on `stream`>
+ *     aqe_batch_enqueue_replays(b, totals, row_stride, stream)
+ *     ... next step ...   aqe_batch_fetch(b, results) synchronises and returns every plan's result
+ * (topup_pending results are finished per plan with the stepwise calls, as above). */
+typedef struct aqe_batch aqe_batch;
+AQE_API int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out);
+AQE_API void aqe_batch_destroy(aqe_batch* batch);
+AQE_API int aqe_batch_enqueue_sweeps(aqe_batch* batch, double* dev_totals, uint64_t row_stride_doubles, void* stream);
+AQE_API int aqe_batch_enqueue_replays(aqe_batch* batch, const double* dev_totals, uint64_t row_stride_doubles, void* stream);
+AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
 /* fused single-GPU form: round + update in one launch (the last workgroup to arrive folds) */
 AQE_API int aqe_plan_enqueue_all(aqe_plan* plan, void* stream);
 AQE_API int aqe_plan_reset(aqe_plan* plan, void* stream); /* re-arm a plan for another execution */

@@ -173,6 +173,10 @@ class Oracle:
         assert got == cnt
         return out[:cnt]
 
+    def count(self, fname: str, n_rows: int, pct: float, *extra) -> int:
+        """How many rows the reference's sampler returns (no index list: usable at full table sizes)."""
+        return int(getattr(self.lib, fname)(n_rows, pct, *extra, None, 0))
+
     def idx_memory_stride(self, M, pct, stride_bytes=0): return self._idx("aqo_idx_memory_stride", M, pct, stride_bytes)
     def idx_address_arithmetic(self, M, pct): return self._idx("aqo_idx_address_arithmetic", M, pct)
     def idx_random_pointer(self, N, pct, seed=42): return self._idx("aqo_idx_random_pointer", N, pct, seed)

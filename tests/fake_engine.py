@@ -33,8 +33,8 @@ class OracleShardPlan:
         else:
             self.rounds, self.has_topup = 1, False
         # batched form: rounds in order then the top-up, VEC doubles per slot (plans of 2..31 rounds)
-        slots = self.rounds + (1 if self.has_topup else 0)
-        self.totals_len = slots * VEC if (self.kind == "clt" and 2 <= self.rounds and slots <= 32) else 0
+        self.totals_len = self.rounds * VEC if (self.kind == "clt" and 2 <= self.rounds <= 32) else 0
+        self.topup_pending = 0
         self.reset()
 
     def reset(self, stream=0):
@@ -109,23 +109,16 @@ class OracleShardPlan:
                 s["converged"], s["stop"] = 2, 1
 
     def enqueue_finalize(self, stream=0):
-        pass
+        self.topup_pending = 0
 
-    # ---- batched form: everything swept speculatively, decisions replayed on the reduced totals ----
+    # ---- batched form: every round swept speculatively, decisions replayed on the reduced totals; a due
+    #      top-up is marked for the caller (ShardedQuery.run takes the stepwise top-up step) ----
     def enqueue_sweep_totals(self, ptr, stream=0):
         t = np.ctypeslib.as_array((C.c_double * self.totals_len).from_address(ptr)).reshape(-1, VEC)
         saved = self.st
         for r in range(self.rounds):
-            self.reset()  # no stop, no gate: every slot is swept
+            self.reset()  # no stop, no gate: every round is swept
             self.enqueue_round(r, t[r].ctypes.data)
-        if self.has_topup:
-            self.reset()
-            amt = self.rows["amount"]
-            step = max(1, self.N // (self.base // 4))
-            idx = np.arange(0, self.N, step, dtype=np.int64)[: self.base]
-            idx = idx[(idx >= self.lo) & (idx < self.hi)] - self.lo
-            t[self.rounds, 0:3] = self._shifted(amt[idx]); t[self.rounds, 3:6] = 0
-            t[self.rounds, 6] = len(idx); t[self.rounds, 7] = 0
         self.st = saved
 
     def enqueue_replay(self, ptr, stream=0):
@@ -135,8 +128,7 @@ class OracleShardPlan:
             if self.st["stop"]:
                 break
             self.enqueue_update(r, t[r].ctypes.data)
-        if self.has_topup:
-            self.enqueue_update(self.rounds, t[self.rounds].ctypes.data)
+        self.topup_pending = 1 if (self.has_topup and self.st["n_p"] < self.base // 4) else 0
 
     def fetch(self, stream=0):
         s = self.st
@@ -145,4 +137,4 @@ class OracleShardPlan:
         mean = S / n if n else 0.0
         m2 = max(s["qd_p"] - s["sd_p"] ** 2 / n, 0.0) if n else 0.0
         return dict(n=int(n), sum=S, mean=mean, m2=m2, converged=s["converged"], rounds=s["rounds"], topup=int(s["topup"]),
-                    visited=int(s["visited"]))
+                    visited=int(s["visited"]), topup_pending=self.topup_pending)

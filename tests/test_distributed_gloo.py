@@ -43,7 +43,8 @@ def _worker(rank, world, port, n, specs, out_dir, batched=False):
         sq = ShardedQuery(plan, vec, all_reduce, batched=batched)
         res = sq.run()
         res["collectives"] = calls[0]
-        res["steps"] = 1 if sq.batched else plan.rounds + (1 if plan.has_topup else 0)
+        res["batched"] = sq.batched
+        res["steps"] = plan.rounds + (1 if plan.has_topup else 0)
         results.append(res)
     torch.save(results, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
@@ -55,6 +56,7 @@ SPECS = [
     ("clt", 20.0, 0.95, 10, 4, 1.0, 256, 2),     # converges early -> top-up
     ("clt", 20.0, 0.95, 10, 4, 0.0, 4096, 4),    # never converges
     ("clt", 10.0, 0.95, 10, 6, 0.5, 64, 2),
+    ("clt", 20.0, 0.95, 10, 4, 5.0, 64, 2),      # stops after ~768 rows < base/4 -> the top-up is due
 ]
 
 
@@ -70,7 +72,8 @@ def test_sharded_query_over_gloo_matches_single_process_oracle(oracle, table, tm
         for g in got[1:]:  # every rank folds the same reduced vector -> identical answers
             assert g == got[0]
         g = got[0]
-        assert g["collectives"] == g["steps"]  # one all-reduce per convergence step (+ top-up), or one per query when batched
+        if not g["batched"]:
+            assert g["collectives"] == g["steps"]  # one all-reduce per convergence step (+ the top-up step)
         if spec[0] == "stride":
             idx = oracle.idx_memory_stride(n, spec[1])
             m = oracle.moments_idx(rows, idx)
@@ -80,6 +83,8 @@ def test_sharded_query_over_gloo_matches_single_process_oracle(oracle, table, tm
             rc, want, _ = oracle.clt_run(rows, pct, conf, ci, T, e, R0=R0, growth=growth)
             assert rc == 0
             assert (g["n"], g["converged"], g["rounds"], g["topup"]) == (want.final.n, want.converged, want.rounds, want.topup)
+            if g["batched"]:  # one all-reduce per query; one more only when the top-up was due
+                assert g["collectives"] == 1 + (1 if want.topup else 0) and g["topup_pending"] == 0
             assert abs(g["sum"] - want.final.sum) <= 1e-12 * abs(want.final.sum)
             assert abs(g["m2"] - want.final.m2) <= 1e-9 * abs(want.final.m2)
 

@@ -480,9 +480,10 @@ def test_sharded_plan_api_single_gpu_virtual_shards(nat, oracle, table):
                 assert (o_.n, o_.visited, o_.converged, o_.rounds, o_.topup) == (want.n, want.visited, want.converged, want.rounds, want.topup)
                 assert rel(o_.sum, want.sum) <= SUM_TOL and rel(o_.value, want.value) <= EST_TOL
                 assert rel(o_.ci_lower, want.ci_lower) <= EST_TOL
-            # batched form: every slot swept in one launch per shard, ONE reduction, decisions replayed
+            # batched form: every round swept in one launch per shard, ONE reduction, decisions replayed; a due
+            # top-up comes back as a mark and is run as the stepwise top-up step
             if plans[0].totals_len:
-                assert all(p.totals_len == plans[0].totals_len for p in plans)
+                assert all(p.totals_len == plans[0].totals_len == rounds * nat.MOMENT_VEC for p in plans)
                 with torch.cuda.stream(side):
                     tot = torch.full((G, plans[0].totals_len), float("nan"), dtype=torch.float64, device="cuda")
                     for g, p in enumerate(plans):
@@ -492,6 +493,19 @@ def test_sharded_plan_api_single_gpu_virtual_shards(nat, oracle, table):
                     for p in plans:
                         p.enqueue_replay(red.data_ptr(), st)
                         outs.append(p.fetch(st))
+                    marks = {o_.topup_pending for o_ in outs}
+                    assert len(marks) == 1 and marks <= {0, 1} and (marks == {0} or topup)
+                    assert marks == {1 if want.topup else 0}
+                    if marks == {1}:
+                        vecs.zero_()
+                        for g, p in enumerate(plans):
+                            p.enqueue_round(rounds, vecs[g].data_ptr(), st)
+                        total = vecs.sum(0)
+                        outs = []
+                        for p in plans:
+                            p.enqueue_update(rounds, total.data_ptr(), st)
+                            p.enqueue_finalize(st)
+                            outs.append(p.fetch(st))
                 for o_ in outs:
                     assert (o_.n, o_.visited, o_.converged, o_.rounds, o_.topup) == (want.n, want.visited, want.converged, want.rounds, want.topup)
                     assert rel(o_.sum, want.sum) <= SUM_TOL and rel(o_.value, want.value) <= EST_TOL
@@ -502,3 +516,103 @@ def test_sharded_plan_api_single_gpu_virtual_shards(nat, oracle, table):
                 p.close()
         for e in engs:
             e.close()
+
+
+@pytest.mark.parametrize("n", [100_000_000, 1_000_000_000], ids=["100M", "1B"])
+def test_full_size_properties(nat, oracle, n):
+    """BASELINE.json's full table sizes (configs 3-5: 100 M and 1 B rows), where the oracle cannot be run:
+    size-independent properties instead — additivity of the reducer over row windows and over a WHERE partition,
+    the reference's sample counts, the persistent sweep against one launch per round, and the synthetic data's
+    known moments.  (The monitor works through several windows of its partial list only on tables this large.)"""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    with Engine(0) as eng:
+        eng.generate_synthetic(n, keep_aos=False)
+        whole = eng.reduce(make_query(nat.M_EXACT, 100.0))
+        assert whole.n == whole.visited == n
+        # uniform [1, 1000): mean 500.5, sigma 288.39 -> the exact mean is within 6 sigma / sqrt(n)
+        assert abs(whole.sum / n - 500.5) < 6 * 288.39 / n ** 0.5
+        # additivity over row windows (ragged cuts) ...
+        cuts = [0, 1, 4097, n // 7, n // 3 + 5, n // 2, n - 100_003, n - 1, n]
+        parts = [eng.reduce(make_query(nat.M_EXACT, 100.0, rows=(a, b))) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert sum(p.n for p in parts) == n
+        assert rel(math.fsum(p.sum for p in parts), whole.sum) <= 1e-12
+        assert rel(math.fsum(p.sumsq for p in parts), whole.sumsq) <= 1e-12
+        # ... and over a partition of the value range (both ends inclusive, DB.cpp:329)
+        lo_hi = [(1.0, 250.0), (float(np.nextafter(250.0, 1e9)), 750.0), (float(np.nextafter(750.0, 1e9)), 1000.0)]
+        bands = [eng.reduce(make_query(nat.M_EXACT, 100.0, where=w)) for w in lo_hi]
+        assert sum(b.n for b in bands) == n and all(b.visited == n for b in bands)
+        assert rel(math.fsum(b.sum for b in bands), whole.sum) <= 1e-12
+        # the reference's sample counts (index generators run count-only)
+        for q, want in (
+            (make_query(nat.M_MEMORY_STRIDE, 1.0), oracle.count("aqo_idx_memory_stride", n, 1.0, 0)),
+            (make_query(nat.M_BLOCK, 1.0, where=(250.0, 750.0)), oracle.count("aqo_idx_block", n, 1.0, 1000)),
+            (make_query(nat.M_BLOCK, 20.0), oracle.count("aqo_idx_block", n, 20.0, 1000)),
+            (make_query(nat.M_PAGE, 5.0, block_size=4096), oracle.count("aqo_idx_page", n, 5.0, 4096)),
+            (make_query(nat.M_OPTIMIZED_CLT, 20.0), oracle.count("aqo_idx_optimized_clt", n, 20.0, 4)),
+        ):
+            r = eng.reduce(q)
+            assert r.visited == want and (r.n == want or q.has_where)
+            # a sample mean of uniform data: within 6 standard errors of the table's mean (WHERE band: of 500)
+            centre, sigma = (500.0, 144.4) if q.has_where else (whole.sum / n, 288.39)
+            assert abs(r.sum / r.n - centre) < 6 * sigma / r.n ** 0.5 + 1e-9
+        # CLT monitor: one persistent launch == one launch per round, for a sweep that never converges, one that
+        # stops in the middle and one that stops at once
+        for e in (0.0, 0.005, 0.05, 1.0):
+            q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=4096, clt_growth=4)
+            q.flags = nat.Q_NO_PERSIST
+            multi = eng.reduce(q)
+            q.flags = 0
+            res = eng.reduce(q)
+            assert (res.n, res.visited, res.converged, res.rounds, res.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
+            assert rel(res.sum, multi.sum) <= 1e-13 and rel(res.sumsq, multi.sumsq) <= 1e-13 and rel(res.ci_lower, multi.ci_lower) <= 1e-12
+            if e == 0.0:  # the reference's full dual-pointer sweep: 2 x base rows (SURVEY R8), no top-up
+                assert res.n == 2 * int(n * 20.0 / 100.0) and res.topup == 0 and res.converged == 0
+            assert abs(res.value - whole.sum / n) <= 3.0 * (res.ci_upper - res.ci_lower) / 2  # 95 % half-width x 3 ~ 6 sigma
+
+
+def test_native_batch_drives_several_plans_with_two_calls_per_step(nat, table):
+    """aqe_batch: sweeps of several plans on the library's side streams, one buffer for the collective, replays
+    back on the side streams; same answers as the single-GPU path, step after step."""
+    from approximatequeryengine_amd.distributed import ShardedBatch
+    from approximatequeryengine_amd.engine import Batch, Engine, make_query
+    import torch
+    n = 1_000_000
+    rows = table(n)
+    qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=r0, clt_growth=g, num_threads=t)
+          for e, r0, g, t in ((0.0, 4096, 4, 4), (1.0, 256, 2, 8), (0.3, 16, 2, 8), (0.0, 4096, 4, 4))]
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)
+        want = [eng.reduce(q) for q in qs]
+        plans = [eng.plan(q) for q in qs]
+        width = max(p.totals_len for p in plans) + 8  # a row stride wider than any plan needs
+        side = torch.cuda.Stream()
+        calls = [0]
+
+        def all_reduce(t):  # a world of one: the identity, but it must see the sweeps' output
+            calls[0] += 1
+            assert bool(torch.isfinite(t[:, : plans[0].totals_len][0]).all())
+
+        with torch.cuda.stream(side):
+            buf = torch.full((len(plans), width), float("nan"), dtype=torch.float64, device="cuda")
+            native = Batch(plans)
+            sb = ShardedBatch(plans, buf, all_reduce, stream=side.cuda_stream, batch=native)
+            for _ in range(3):
+                for _ in range(4):
+                    sb.enqueue()          # steps back to back, no host synchronisation in between
+                got = sb.fetch()
+                assert [g_.topup_pending for g_ in got] == [1 if w.topup else 0 for w in want]
+                for g_, w in zip(got, want):
+                    assert (g_.converged, g_.rounds, g_.device_status) == (w.converged, w.rounds, 0)
+                    if not w.topup:
+                        assert (g_.n, g_.visited) == (w.n, w.visited)
+                        assert rel(g_.sum, w.sum) <= 1e-13 and rel(g_.ci_lower, w.ci_lower) <= 1e-12
+            out = sb.run()                # run() also finishes the due top-ups with the stepwise step
+            for g_, w in zip(out, want):
+                assert (g_.n, g_.visited, g_.converged, g_.rounds, g_.topup, g_.topup_pending) == (w.n, w.visited, w.converged, w.rounds, w.topup, 0)
+                assert rel(g_.sum, w.sum) <= 1e-13 and rel(g_.value, w.value) <= 1e-13
+            assert any(w.topup for w in want) and not all(w.topup for w in want)
+            native.close()
+        with pytest.raises(nat.AqeError):
+            Batch([plans[0], plans[0]])
+        for p in plans:
+            p.close()
