@@ -14,6 +14,8 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NO_TABLE, ERR_IO, ERR_CAPACITY, ERR
 M_EXACT, M_MEMORY_STRIDE, M_ADDRESS_ARITHMETIC, M_RANDOM_POINTER, M_BLOCK, M_PAGE, M_PARALLEL_BLOCK = range(7)
 M_OPTIMIZED_CLT, M_CLT_DUAL_POINTER, M_FAST_POINTER, M_SLOW_POINTER, M_DUAL_POINTER = 7, 8, 9, 10, 11
 M_PARALLEL_POINTER, M_REGION_STRIDE, M_RANDOM_START_STRIDE, M_ADAPTIVE_BLOCK, M_STRATIFIED_BLOCK = 12, 13, 14, 15, 16
+M_ROWID_MOD = 17
+GROUP_REGION, GROUP_PRODUCT = 1, 2
 
 SUM, AVG, COUNT = 0, 1, 2
 EST_CLI, EST_CPP, EST_RAW = 0, 1, 2
@@ -54,6 +56,14 @@ class Family(C.Structure):
     _fields_ = [("row0", C.c_uint64), ("pitch", C.c_uint64), ("seg_len", C.c_uint64), ("step", C.c_uint64),
                 ("ord_lo", C.c_uint64), ("ord_hi", C.c_uint64), ("row0_b", C.c_uint64), ("ord_lo_b", C.c_uint64),
                 ("ord_hi_b", C.c_uint64), ("group", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class GroupResult(C.Structure):
+    _fields_ = [("key", C.c_int64), ("n", C.c_uint64), ("visited", C.c_uint64), ("sum", C.c_double), ("sumsq", C.c_double),
+                ("mean", C.c_double), ("value", C.c_double), ("ci_lower", C.c_double), ("ci_upper", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class TableInfo(C.Structure):
@@ -114,6 +124,7 @@ def lib() -> C.CDLL:
         "aqe_confidence_heuristic": (dbl, [dbl, u64]),
         "aqe_error_to_sample_percent": (dbl, [dbl]),
         "aqe_reduce": (C.c_int, [vp, P(Query), P(Result)]),
+        "aqe_reduce_grouped": (C.c_int, [vp, P(Query), C.c_int, P(GroupResult), u32, P(u32)]),
         "aqe_gather": (C.c_int, [vp, P(Query), vp, u64, P(u64)]),
         "aqe_plan_create": (C.c_int, [vp, P(Query), P(vp)]),
         "aqe_plan_destroy": (None, [vp]),

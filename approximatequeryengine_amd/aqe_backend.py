@@ -18,6 +18,7 @@ Tree-walking samplers that §8 of SURVEY.md rules out raise NotImplementedError.
 """
 from __future__ import annotations
 
+import ctypes as C
 import enum
 import os
 import time
@@ -30,7 +31,7 @@ from . import _native as nat
 from .engine import RECORD_DTYPE, Engine, make_query
 
 __all__ = ["Record", "CustomBPlusDB", "CustomApproximateScheduler", "CustomValidationResult",
-           "CustomApproximationStatus", "ApproxResult", "BenchmarkResults"]
+           "CustomApproximationStatus", "ApproxResult", "BenchmarkResults", "GroupEstimate"]
 
 
 class Record:
@@ -103,6 +104,27 @@ _OUT_OF_SCOPE = (
     "direct_access_sample", "byte_offset_sample", "random_start_nth_sample", "address_arithmetic_sample",
     "signal_based_clt_sample",
 )
+
+
+class GroupEstimate:
+    """One group of approx_group_by: executor.h's QueryResult {value, ci_lower, ci_upper} plus the moments behind it."""
+    __slots__ = ("value", "ci_lower", "ci_upper", "n", "sum", "mean")
+
+    def __init__(self, r):
+        self.value, self.ci_lower, self.ci_upper = r.value, r.ci_lower, r.ci_upper
+        self.n, self.sum, self.mean = int(r.n), r.sum, r.mean
+
+    def __repr__(self):
+        return f"GroupEstimate(value={self.value:.6g}, ci=[{self.ci_lower:.6g}, {self.ci_upper:.6g}], n={self.n})"
+
+    def __iter__(self):  # unpacks like the reference's (value, ci_lower, ci_upper)
+        return iter((self.value, self.ci_lower, self.ci_upper))
+
+
+def parse_where(query: str) -> Optional[Tuple[float, float]]:
+    """The amount range of a query's WHERE clause as the scheduler reads it (custom_scheduler.cpp:277-294), or None."""
+    lo, hi = C.c_double(), C.c_double()
+    return (lo.value, hi.value) if nat.lib().aqe_parse_where(query.encode(), C.byref(lo), C.byref(hi)) else None
 
 
 def _records(arr: np.ndarray) -> List[Record]:
@@ -414,6 +436,21 @@ class CustomBPlusDB:
         if res.visited == 0:
             raise RuntimeError("No samples collected")
         return ApproxResult(res, method)
+
+    def approx_group_by(self, agg: str, group_by: str = "region", sample_percent: float = 10.0, method: str = "rowid",
+                        where: Optional[Tuple[float, float]] = None, block_size: int = 1000) -> "dict[str, GroupEstimate]":
+        """APPROX <agg>(amount) ... GROUP BY region | product_id with a 95 % interval per group: the reference's
+        execute_query_groupby_with_ci (executor.cpp:202-321; GroupResultWithCI = map<string, {value, ci_lower,
+        ci_upper}>) in one sweep.  method "rowid" is that function's own sample (rowid % (100 / sample_percent) == 0);
+        "stride", "block", "page" and "exact" group the CustomBPlusDB samplers the same way.
+        SUM is sum * 100/pct (the reference reports mean * 100/pct under that name; GroupEstimate.mean has the mean)."""
+        col = {"region": nat.GROUP_REGION, "product_id": nat.GROUP_PRODUCT}[group_by.strip().lower()]
+        m = {"rowid": nat.M_ROWID_MOD, "stride": nat.M_MEMORY_STRIDE, "block": nat.M_BLOCK, "page": nat.M_PAGE, "exact": nat.M_EXACT}[method]
+        if self._n == 0:
+            return {}
+        bs = 4096 if (method == "page" and block_size == 1000) else block_size
+        q = make_query(m, sample_percent, agg=_AGG[agg.upper()], where=where, block_size=int(bs))
+        return {str(r.key): GroupEstimate(r) for r in self._eng().reduce_grouped(q, col)}
 
     def approx_sum(self, **kw) -> ApproxResult:
         return self.approx("SUM", **kw)

@@ -113,6 +113,19 @@ def run(args, out=sys.stdout) -> int:
     n = db.get_total_records()
     print(f"query: {args.query}\ndatabase: {args.db} ({n:,} records)\ntype: {qtype}", file=out)
     t0 = time.perf_counter()
+    gb = re.search(r"GROUP\s+BY\s+(region|product_id)\b", clean, flags=re.IGNORECASE)
+    if gb:  # one sweep, one (n, S, Q) bin per key, an interval per group (executor.cpp:202-321 semantics)
+        pct = args.s if args.s is not None else (100.0 if qtype == QUERY_EXACT else 10.0)
+        groups = db.approx_group_by(agg, group_by=gb.group(1), sample_percent=pct, method="exact" if pct >= 100.0 else "rowid",
+                                    where=aqe_backend.parse_where(clean))
+        ms = (time.perf_counter() - t0) * 1e3
+        print(f"\nGROUP BY {gb.group(1).lower()} ({'exact' if pct >= 100.0 else f'rowid sample {pct:g}%'}):", file=out)
+        for key, g in groups.items():
+            ci = f"   ({g.ci_lower:,.4f} - {g.ci_upper:,.4f})" if (args.ci and pct < 100.0) else ""
+            print(f"   {key:>6}: {g.value:,.4f}{ci}   n={g.n:,}", file=out)
+        print(f"   execution time: {ms:.2f} ms", file=out)
+        db.close_database()
+        return 0
     if qtype == QUERY_EMBEDDED:
         method = args.method or get_optimal_method_for_query(clean, n)
         qtype = QUERY_CLT if method == "clt" else QUERY_RANDOM  # enhanced_aqe_cli.py:489-494

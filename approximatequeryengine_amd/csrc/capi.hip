@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -49,6 +50,10 @@ struct aqe_ctx {
     double zone_var[10] = {0};
     double* sorted_amount = nullptr;
     uint32_t* sorted_row = nullptr;
+    // GROUP BY: key columns (SoA int32), extracted from the AoS rows or generated for a synthetic table on first use
+    int32_t* keycol[2] = {nullptr, nullptr};  // [AQE_GROUP_REGION - 1], [AQE_GROUP_PRODUCT - 1]
+    int32_t key_min[2] = {0, 0}, key_max[2] = {-1, -1};
+    bool synthetic = false;  // made by aqe_generate_synthetic: keys follow from the row number
     bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
     int64_t first_id = 0;
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
@@ -143,6 +148,11 @@ void free_table(aqe_ctx* c) {
     }
     if (c->sorted_amount) (void)hipFree(c->sorted_amount);
     if (c->sorted_row) (void)hipFree(c->sorted_row);
+    for (int k = 0; k < 2; ++k) {
+        if (c->keycol[k]) (void)hipFree(c->keycol[k]);
+        c->keycol[k] = nullptr;
+    }
+    c->synthetic = false;
     c->sorted_amount = nullptr;
     c->sorted_row = nullptr;
     c->zone_var_valid = false;
@@ -390,6 +400,31 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
 
 int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
 int enqueue_all(aqe_plan* p, hipStream_t s, bool timed);
+
+// GROUP BY needs the key column as SoA int32 on the device: from the resident 32-byte rows, or — for a table made
+// by aqe_generate_synthetic — from the row number.  Built on first use, kept until the table changes.
+int ensure_keys(aqe_ctx* c, int column) {
+    const int k = column - 1;
+    if (c->keycol[k] || c->n_local == 0) return AQE_OK;
+    if (!c->aos && !c->synthetic)
+        return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction needs the key columns: stage the table with AQE_STAGE_KEEP_AOS");
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->keycol[k]), c->n_local * sizeof(int32_t)));
+    c->hbm_bytes += c->n_local * sizeof(int32_t);
+    if (c->aos) HIPCHK(c, launch_extract_key(c->aos, c->keycol[k], c->n_local, column, c->stream));
+    else HIPCHK(c, launch_synth_key(c->keycol[k], c->n_local, c->shard_lo, column, c->stream));
+    int32_t* d_range = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_range), 2 * sizeof(int32_t)));
+    int32_t init[2] = {std::numeric_limits<int32_t>::max(), std::numeric_limits<int32_t>::min()};
+    hipError_t e = hipMemcpyAsync(d_range, init, sizeof init, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_key_range(c->keycol[k], c->n_local, d_range, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(init, d_range, sizeof init, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_range);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("key range: ") + hipGetErrorString(e));
+    c->key_min[k] = init[0];
+    c->key_max[k] = init[1];
+    return AQE_OK;
+}
 int fetch(aqe_plan* p, aqe_result* out, hipStream_t s);
 
 // adaptive_block_sample's pre-pass (DB.cpp:1291-1308): population variance of each of the ten zones from raw
@@ -855,6 +890,7 @@ int aqe_generate_synthetic(aqe_ctx* c, uint64_t n_local, uint64_t shard_lo, uint
     }
     c->ids_dense = true;  // id = row + 1
     c->first_id = 1;
+    c->synthetic = true;
     HIPCHK(c, launch_synth(c->aos, c->amount, n_local, shard_lo, seed, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AQE_OK;
@@ -1206,6 +1242,53 @@ int aqe_batch_fetch(aqe_batch* b, aqe_result* out_n) {
         if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, b->lanes[i % b->lanes.size()]);
         if (rc != AQE_OK) return rc;
     }
+    return AQE_OK;
+}
+
+int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_group_result* out, uint32_t cap, uint32_t* n_groups) {
+    if (!c) return AQE_ERR_INVALID;
+    if (!q || !n_groups || (cap && !out)) return fail(c, AQE_ERR_INVALID, "null argument");
+    if (group_column != AQE_GROUP_REGION && group_column != AQE_GROUP_PRODUCT) return fail(c, AQE_ERR_INVALID, "group_column must be AQE_GROUP_REGION or AQE_GROUP_PRODUCT");
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    if (!(q->sample_percent > 0.0)) return fail(c, AQE_ERR_INVALID, "sample_percent must be positive");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_groups = 0;
+    aqe_plan* p = nullptr;
+    int rc = cached_plan(c, q, &p);
+    if (rc != AQE_OK) return rc;
+    if (p->host.is_random || p->host.is_clt || p->host.on_sorted || p->rounds.size() > 1)
+        return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction takes a single-round family sampler (exact, stride, rowid-mod, block, page, pointer, region ...)");
+    if (p->rounds.empty() || c->n_local == 0) return AQE_OK;  // nothing sampled: no groups
+    for (const DevFamily& f : p->h_fams)
+        if (f.flags & AQE_F_PAIR) return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction does not take pair families");
+    rc = ensure_keys(c, group_column);
+    if (rc != AQE_OK) return rc;
+    const int k = group_column - 1;
+    const int64_t span = static_cast<int64_t>(c->key_max[k]) - c->key_min[k] + 1;
+    if (span < 1 || span > kMaxGroupBins) return fail(c, AQE_ERR_UNSUPPORTED, "group column spans more than 1024 distinct values");
+    const uint32_t nbins = static_cast<uint32_t>(span);
+    const LaunchDesc& L = p->rounds[0];
+    const unsigned grid = grouped_grid(L.ntiles);
+    double* d_partial = nullptr;
+    aqe_group_result* d_out = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_partial), static_cast<size_t>(grid) * nbins * 4 * sizeof(double)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), nbins * sizeof(aqe_group_result));
+    std::vector<aqe_group_result> host(nbins);
+    if (e == hipSuccess) e = launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, c->keycol[k], c->key_min[k], nbins, d_partial, grid, c->stream);
+    if (e == hipSuccess) e = launch_grouped_finish(d_partial, grid, nbins, c->key_min[k], c->shift, q->sample_percent, q->agg, d_out, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, nbins * sizeof(aqe_group_result), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_partial);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("grouped reduction: ") + hipGetErrorString(e));
+    uint32_t g = 0;
+    for (const aqe_group_result& r : host) {
+        if (r.visited == 0) continue;  // a key nobody sampled
+        if (g < cap) out[g] = r;
+        ++g;
+    }
+    *n_groups = g;
+    if (g > cap) return fail(c, AQE_ERR_CAPACITY, "more groups than the caller's buffer holds (n_groups has the count)");
     return AQE_OK;
 }
 

@@ -173,4 +173,16 @@ hipError_t launch_split_amount(const aqe_record* aos, double* amount, uint64_t n
 hipError_t launch_synth(aqe_record* aos_or_null, double* amount, uint64_t n, uint64_t first_row, uint64_t seed,
                         hipStream_t s);
 
+// ---- GROUP BY: grouped.hip -----------------------------------------------------------------------
+constexpr int kMaxGroupBins = 1024;     // key_max - key_min + 1 of a group column
+constexpr unsigned kGroupedMaxBlocks = 1024;
+hipError_t launch_extract_key(const aqe_record* aos, int32_t* out, uint64_t n, int column, hipStream_t s);
+hipError_t launch_synth_key(int32_t* out, uint64_t n, uint64_t first_row, int column, hipStream_t s);
+hipError_t launch_key_range(const int32_t* keys, uint64_t n, int32_t* out2, hipStream_t s);
+unsigned grouped_grid(uint64_t ntiles);
+hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t* keys, int32_t key_min, uint32_t nbins, double* partial,
+                          unsigned grid, hipStream_t s);
+hipError_t launch_grouped_finish(const double* partial, unsigned nblocks, uint32_t nbins, int32_t key_min, double shift, double pct, int agg,
+                                 aqe_group_result* out, hipStream_t s);
+
 }  // namespace aqe

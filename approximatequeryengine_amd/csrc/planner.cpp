@@ -232,6 +232,12 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
             fams.push_back(strided(start, stride, std::min<u64>(static_cast<u64>(target), prog_count(start, M, stride))));
             return finish_single();
         }
+        case AQE_M_ROWID_MOD: {  // executor.cpp:21-26, 36-41: rowid % step = 0 with rowid = row + 1, step = 100 / int(pct)
+            const int ipct = static_cast<int>(pct);
+            const u64 step = (ipct <= 0 || ipct >= 100) ? 1 : static_cast<u64>(100 / ipct);
+            if (N >= step) fams.push_back(strided(step - 1, step, N / step));
+            return finish_single();
+        }
         case AQE_M_ADDRESS_ARITHMETIC: {  // DB.cpp:1667-1703
             if (M == 0) return finish_single();
             int target = target_of(M, pct);

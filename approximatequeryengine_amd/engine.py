@@ -214,6 +214,14 @@ class Engine:
         self._chk(nat.lib().aqe_reduce(self._h, C.byref(query), C.byref(res)))
         return res
 
+    def reduce_grouped(self, query: Query, group_column: int, max_groups: int = 1024):
+        """GROUP BY region / product_id with a per-group interval (executor.cpp:202-321): list of GroupResult,
+        ascending key, only keys with at least one sampled row."""
+        out = (nat.GroupResult * max_groups)()
+        n = C.c_uint32()
+        self._chk(nat.lib().aqe_reduce_grouped(self._h, C.byref(query), int(group_column), out, max_groups, C.byref(n)))
+        return list(out[: n.value])
+
     def gather(self, query: Query) -> np.ndarray:
         """Rows of the record-returning sampler, as a RECORD_DTYPE array."""
         n = C.c_uint64()

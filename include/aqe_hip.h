@@ -77,6 +77,8 @@ typedef enum aqe_method {
     AQE_M_RANDOM_START_STRIDE = 14, /* random_start_memory_stride_sample, DB.cpp:1838-1878, seeded start in [0, stride) */
     AQE_M_ADAPTIVE_BLOCK = 15,    /* adaptive_block_sample, DB.cpp:1273-1329: block size from per-zone variance (needs a
                                      full-table moments pre-pass on the device, cached per table)            */
+    AQE_M_ROWID_MOD = 17,         /* the SQLite executor's sampler: rows with rowid % (100 / int(sample_percent)) == 0,
+                                     rowid = row + 1 (executor.cpp:21-26, 36-41); sample_percent >= 100: every row */
     AQE_M_STRATIFIED_BLOCK = 16   /* stratified_block_sample, DB.cpp:1331-1379: blocks of the amount-SORTED table (needs a
                                      device sort of the column, cached per table); num_threads = strata_count */
 } aqe_method;
@@ -234,6 +236,28 @@ AQE_API int aqe_reduce(aqe_ctx* ctx, const aqe_query* q, aqe_result* out);
 /* Record-returning form of the same samplers (BIND:50-101): rows in the reference's order
  * (CLT: round-major order; compare as a multiset).  Needs AQE_STAGE_KEEP_AOS. */
 AQE_API int aqe_gather(aqe_ctx* ctx, const aqe_query* q, void* out_aos32, uint64_t cap, uint64_t* n_out);
+
+/* ---- GROUP BY with a per-group interval -------------------------------------------------------
+ * The same sampled sweep with one (n, S, Q) bin per key of `group_column` (region or product_id), then estimate
+ * and interval per group.  Replaces execute_query_groupby_with_ci (executor.cpp:202-321, the reference's SQLite
+ * path; use AQE_M_ROWID_MOD for its `rowid % step = 0` sample, any other single-round family sampler works too).
+ * Per group: mean = S/n, var = (Q - S^2/n)/(n-1), half-width 1.96 sqrt(var/n) (n >= 2, else no interval);
+ * AVG reports the mean; SUM reports S * 100/pct with the half-width scaled by 100/pct as the reference does
+ * (the reference scales the MEAN and calls it the sum, executor.cpp:289-296: that defect is not reproduced —
+ * `mean` is returned beside it); COUNT reports n * 100/pct without an interval.  query.convention is ignored.
+ * Groups come back in ascending key order; only keys with at least one sampled row are listed.
+ * Needs the key columns: stage with AQE_STAGE_KEEP_AOS, or a table made by aqe_generate_synthetic. */
+#define AQE_GROUP_REGION 1
+#define AQE_GROUP_PRODUCT 2
+typedef struct aqe_group_result {
+    int64_t key;
+    uint64_t n;       /* sampled rows of the group that pass WHERE */
+    uint64_t visited; /* sampled rows of the group                 */
+    double sum, sumsq, mean;
+    double value, ci_lower, ci_upper;
+} aqe_group_result;
+AQE_API int aqe_reduce_grouped(aqe_ctx* ctx, const aqe_query* q, int group_column, aqe_group_result* out, uint32_t cap,
+                               uint32_t* n_groups);
 
 /* ---- stepwise / multi-GPU form ----------------------------------------------------------------
  * One process per GPU; each rank plans the same query over its own shard.  Per round:

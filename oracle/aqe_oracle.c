@@ -694,6 +694,75 @@ int aqo_clt_run(const aqo_record* rows, uint64_t N, double pct, double conf, int
 /* ------------------------------------------------------------------------------------------------
  * on-disk format, DB.cpp:665-711 (native endian, 24-byte header)
  * ---------------------------------------------------------------------------------------------- */
+/* ---- GROUP BY (EXE:202-321) ---- */
+static int64_t key_of(const aqo_record* r, int col) { return col == AQO_COL_REGION ? (int64_t)r->region : (int64_t)r->product_id; }
+
+/* insertion into a small key-sorted table (the reference iterates SELECT DISTINCT; order is presentation only) */
+static int64_t group_slot(int64_t key, int64_t* keys, uint64_t* n, double* sum, double* sumsq, int64_t* used, int64_t cap) {
+    int64_t lo = 0, hi = *used < cap ? *used : cap;
+    while (lo < hi) { int64_t mid = (lo + hi) / 2; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+    int64_t filled = *used < cap ? *used : cap;
+    if (lo < filled && keys[lo] == key) return lo;
+    if (*used >= cap) { (*used)++; return -1; } /* counted, not stored */
+    for (int64_t i = filled; i > lo; --i) { keys[i] = keys[i - 1]; n[i] = n[i - 1]; sum[i] = sum[i - 1]; sumsq[i] = sumsq[i - 1]; }
+    keys[lo] = key; n[lo] = 0; sum[lo] = 0.0; sumsq[lo] = 0.0;
+    (*used)++;
+    return lo;
+}
+
+int64_t aqo_group_idx(const aqo_record* rows, const uint64_t* idx, int64_t n_idx, int group_col, int has_where, double wmin,
+                      double wmax, int64_t* keys, uint64_t* n, double* sum, double* sumsq, int64_t cap) {
+    int64_t used = 0;
+    for (int64_t k = 0; k < n_idx; ++k) {
+        const aqo_record* r = rows + idx[k];
+        if (has_where && !(r->amount >= wmin && r->amount <= wmax)) continue;
+        int64_t s = group_slot(key_of(r, group_col), keys, n, sum, sumsq, &used, cap);
+        if (s < 0) continue;
+        n[s] += 1; sum[s] += r->amount; sumsq[s] += r->amount * r->amount; /* EXE:236-238 */
+    }
+    return used;
+}
+
+int64_t aqo_group_rowid_mod(const aqo_record* rows, uint64_t N, int sample_percent, int group_col, int has_where,
+                            double wmin, double wmax, int64_t* keys, uint64_t* n, double* sum, double* sumsq, int64_t cap) {
+    int step = (sample_percent <= 0 || sample_percent >= 100) ? 0 : 100 / sample_percent; /* EXE:21-26 */
+    int64_t used = 0;
+    for (uint64_t i = 0; i < N; ++i) {
+        if (step > 0 && (i + 1) % (uint64_t)step != 0) continue; /* rowid % step = 0, EXE:243 */
+        const aqo_record* r = rows + i;
+        if (has_where && !(r->amount >= wmin && r->amount <= wmax)) continue;
+        int64_t s = group_slot(key_of(r, group_col), keys, n, sum, sumsq, &used, cap);
+        if (s < 0) continue;
+        n[s] += 1; sum[s] += r->amount; sumsq[s] += r->amount * r->amount;
+    }
+    return used;
+}
+
+void aqo_group_ci(int agg, uint64_t count, double sum, double sumsq, int sample_percent, int reference_sum, double* value,
+                  double* lo, double* hi) {
+    int step = (sample_percent <= 0 || sample_percent >= 100) ? 0 : 100 / sample_percent;
+    double scale = 100.0 / (double)sample_percent;
+    double c = (double)count;
+    if (count < 2) { /* EXE:248-274: no interval */
+        double v = agg == AQO_SUM ? sum : agg == AQO_AVG ? (count ? sum / c : 0.0) : c;
+        if (step > 0 && agg != AQO_AVG) v *= scale;
+        *value = *lo = *hi = v;
+        return;
+    }
+    double mean = sum / c;                               /* EXE:277 */
+    double var = (sumsq - (sum * sum / c)) / (c - 1.0);  /* EXE:280 */
+    double margin = 1.96 * sqrt(var / c);                /* EXE:283-286 */
+    double v = mean;
+    if (agg == AQO_SUM) {                                /* EXE:289-296 */
+        v = (reference_sum ? mean : sum) * scale;
+        margin *= scale;
+    } else if (agg == AQO_COUNT) {
+        v = step > 0 ? c * scale : c;
+        margin = 0.0;
+    }
+    *value = v; *lo = v - margin; *hi = v + margin;
+}
+
 int aqo_file_write(const char* path, const aqo_record* rows, uint64_t n, uint64_t height) {
     FILE* f = fopen(path, "wb");
     if (!f) return -1;

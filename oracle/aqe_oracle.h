@@ -137,6 +137,24 @@ void aqo_clt_round_partial(const aqo_record* rows_at_lo, uint64_t lo, uint64_t h
                            const aqo_clt_plan* plan, uint64_t ord_begin, uint64_t ord_end,
                            aqo_moments* fast_sums, aqo_moments* slow_sums);
 
+/* ---- GROUP BY with a per-group interval: the SQLite executor's semantics (EXE:202-321) on the same rows ----
+ * Sample = rows whose rowid (= row index + 1) satisfies rowid % step == 0, step = 100 / sample_percent
+ * (integer division; EXE:21-26; sample_percent <= 0 or >= 100: every row).  Per distinct key of the group
+ * column among the SAMPLED rows that pass WHERE: COUNT, SUM, SUM(x*x) in rowid order (EXE:236-243).
+ * keys ascending.  Returns the number of groups (may exceed cap; only cap are written). */
+enum { AQO_COL_REGION = 1, AQO_COL_PRODUCT = 2 };
+int64_t aqo_group_rowid_mod(const aqo_record* rows, uint64_t N, int sample_percent, int group_col, int has_where,
+                            double wmin, double wmax, int64_t* keys, uint64_t* n, double* sum, double* sumsq, int64_t cap);
+/* the same grouping over an explicit index list (any sampler), index order */
+int64_t aqo_group_idx(const aqo_record* rows, const uint64_t* idx, int64_t n_idx, int group_col, int has_where, double wmin,
+                      double wmax, int64_t* keys, uint64_t* n, double* sum, double* sumsq, int64_t cap);
+/* EXE:247-302: (count, sum, sumsq) of one group -> value and interval.  count < 2: no interval, value = the
+ * aggregate of the sampled rows, scaled by 100/pct unless AVG (EXE:248-274).  Otherwise mean +/- 1.96 sqrt(var/n);
+ * for SUM the reference scales the MEAN by 100/pct (EXE:291-296, reproduced when reference_sum != 0); with
+ * reference_sum == 0 the value is sum * 100/pct with the same scaled margin (what the product reports). */
+void aqo_group_ci(int agg, uint64_t count, double sum, double sumsq, int sample_percent, int reference_sum, double* value,
+                  double* lo, double* hi);
+
 /* ---- on-disk format (DB.cpp:665-711): size_t total | size_t height | size_t count | rows ---- */
 int aqo_file_write(const char* path, const aqo_record* rows, uint64_t n, uint64_t height);
 int64_t aqo_file_count(const char* path);

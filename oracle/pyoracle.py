@@ -152,6 +152,15 @@ class Oracle:
         L.aqo_file_count.argtypes = [C.c_char_p]
         L.aqo_file_read.restype = C.c_int64
         L.aqo_file_read.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        i64p = C.POINTER(C.c_int64)
+        L.aqo_group_rowid_mod.restype = C.c_int64
+        L.aqo_group_rowid_mod.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i64p, _u64p,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64]
+        L.aqo_group_idx.restype = C.c_int64
+        L.aqo_group_idx.argtypes = [C.c_void_p, _u64p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, i64p, _u64p,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64]
+        L.aqo_group_ci.restype = None
+        L.aqo_group_ci.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3
         L.aqo_mt19937_stream.restype = None
         L.aqo_mt19937_stream.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_int]
 
@@ -161,6 +170,27 @@ class Oracle:
         if n:
             self.lib.aqo_synth_fill(rows.ctypes.data, first, n, seed)
         return rows
+
+    # ---- GROUP BY (EXE:202-321) ----
+    def group(self, rows, group_col, sample_percent=None, idx=None, where=None, cap=4096):
+        """Per-group (key, n, sum, sumsq), keys ascending: over the rowid %% step sample (sample_percent) or an index list."""
+        keys = np.zeros(cap, dtype=np.int64); n = np.zeros(cap, dtype=np.uint64)
+        s = np.zeros(cap, dtype=np.float64); q = np.zeros(cap, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        hw, lo, hi = (1, float(where[0]), float(where[1])) if where else (0, 0.0, 0.0)
+        args = (group_col, hw, lo, hi, keys.ctypes.data_as(C.POINTER(C.c_int64)), _ptr(n, _u64p), s.ctypes.data_as(dp), q.ctypes.data_as(dp), cap)
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.uint64)
+            g = self.lib.aqo_group_idx(rows.ctypes.data, _ptr(idx, _u64p), len(idx), *args)
+        else:
+            g = self.lib.aqo_group_rowid_mod(rows.ctypes.data, len(rows), int(sample_percent), *args)
+        assert g <= cap
+        return [(int(keys[i]), int(n[i]), float(s[i]), float(q[i])) for i in range(g)]
+
+    def group_ci(self, agg, count, total, sumsq, sample_percent, reference_sum=False):
+        v, lo, hi = C.c_double(), C.c_double(), C.c_double()
+        self.lib.aqo_group_ci(agg, count, total, sumsq, int(sample_percent), int(reference_sum), C.byref(v), C.byref(lo), C.byref(hi))
+        return v.value, lo.value, hi.value
 
     # ---- index sets ----
     def _idx(self, fname: str, n_rows: int, pct: float, *extra) -> np.ndarray | None:

@@ -214,6 +214,8 @@ def test_cli_end_to_end(tmp_path, oracle, table):
         (["SELECT AVG(amount) FROM sales", "--db", str(p), "--e", "2"], "CLT"),
         (["SELECT APPROX(SUM(amount)) FROM sales", "--db", str(p)], "CLT"),
         (["SELECT COUNT(*) FROM sales", "--db", str(p)], "exact"),
+        (["SELECT AVG(amount) FROM sales GROUP BY region", "--db", str(p), "--s", "10", "--ci"], "GROUP BY region (rowid sample 10%)"),
+        (["SELECT SUM(amount) FROM sales WHERE amount BETWEEN 250 AND 750 GROUP BY product_id", "--db", str(p)], "GROUP BY product_id (exact)"),
     ):
         out = io.StringIO()
         assert cli.run(cli.build_parser().parse_args(argv), out) == 0, out.getvalue()
@@ -223,3 +225,25 @@ def test_cli_end_to_end(tmp_path, oracle, table):
     val = float(out.getvalue().split("value:")[1].split()[0].replace(",", ""))
     assert abs(val - exact) < 1e-3
     assert p.stat().st_size == 24 + 32 * 100_000  # the CLI never rewrites the database
+
+
+@pytest.mark.gpu
+def test_group_by_entry_point(db100k, oracle, table):
+    """approx_group_by: the reference's GroupResultWithCI shape (key string -> value, ci_lower, ci_upper)."""
+    rows = table(100_000)
+    # (rowid % 10 == 0 on this table only ever meets regions 1 and 3 — region = row % 4 — exactly as the reference's
+    #  own sampler would; step 33 visits all four)
+    assert list(db100k.approx_group_by("AVG", group_by="region", sample_percent=10)) == ["1", "3"]
+    got = db100k.approx_group_by("AVG", group_by="region", sample_percent=3)
+    want = oracle.group(rows, 1, sample_percent=3)
+    assert list(got) == [str(k) for k, *_ in want] == ["0", "1", "2", "3"]
+    for (k, n, s_, q_), g in zip(want, got.values()):
+        v, lo, hi = oracle.group_ci(1, n, s_, q_, 3, reference_sum=True)  # AVG: the reference's own numbers
+        value, ci_lower, ci_upper = g                                       # unpacks like executor.h's QueryResult
+        assert g.n == n and abs(value - v) <= 1e-9 * v and abs(ci_lower - lo) <= 1e-8 * lo and abs(ci_upper - hi) <= 1e-8 * hi
+    total = db100k.approx_group_by("SUM", group_by="product_id", method="exact", sample_percent=100)
+    assert len(total) == 100 and abs(sum(g.value for g in total.values()) - math.fsum(rows["amount"])) <= 1e-6
+    blocks = db100k.approx_group_by("COUNT", group_by="region", method="block", sample_percent=5, where=(250.0, 750.0))
+    idx = oracle.idx_block(len(rows), 5.0, 1000)
+    for k, n, *_ in oracle.group(rows, 1, idx=idx, where=(250.0, 750.0)):
+        assert blocks[str(k)].n == n and blocks[str(k)].value == n * 20.0

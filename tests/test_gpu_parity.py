@@ -616,3 +616,58 @@ def test_native_batch_drives_several_plans_with_two_calls_per_step(nat, table):
             Batch([plans[0], plans[0]])
         for p in plans:
             p.close()
+
+
+def test_group_by_with_per_group_interval(nat, oracle, table):
+    """GROUP BY region / product_id (executor.cpp:202-321): per-group (n, S, Q) against what SQLite returned for the
+    reference's statements (tests/golden/groupby_sqlite.json), estimate and interval against the oracle's
+    restatement; then any single-round sampler on a device-generated table against the oracle's grouping."""
+    import json, os
+    from approximatequeryengine_amd.engine import Engine, make_query
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "groupby_sqlite.json")))
+    rows = table(g["table_rows"], g["seed"])
+    col = {"region": nat.GROUP_REGION, "product_id": nat.GROUP_PRODUCT}
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=True)
+        for case in g["cases"]:
+            pct, where = case["sample_percent"], case["where"]
+            want = [w for w in case["groups"] if w["count"] > 0]
+            for agg, name in ((nat.SUM, "SUM"), (nat.AVG, "AVG"), (nat.COUNT, "COUNT")):
+                got = eng.reduce_grouped(make_query(nat.M_ROWID_MOD, pct, agg=agg, where=tuple(where) if where else None), col[case["group_by"]])
+                # (a key whose sampled rows all fail WHERE is listed with n = 0; SQLite's COUNT for it is 0 as well)
+                assert [r.key for r in got if r.n] == [w["key"] for w in want] and all(r.visited for r in got)
+                for r, w in zip([r for r in got if r.n], want):
+                    assert r.n == w["count"] and rel(r.sum, w["sum"]) <= SUM_TOL and rel(r.sumsq, w["sumsq"]) <= SUM_TOL
+                    v, lo, hi = oracle.group_ci(agg, w["count"], w["sum"], w["sumsq"], pct, reference_sum=False)
+                    assert rel(r.value, v) <= EST_TOL and rel(r.ci_lower, lo) <= 1e-8 and rel(r.ci_upper, hi) <= 1e-8
+                    if name == "AVG" and w["count"] >= 2:  # where the reference is right, the same numbers as the reference
+                        rv, rlo, rhi = w["reference_ci"]["AVG"]
+                        assert rel(r.value, rv) <= EST_TOL and rel(r.ci_lower, rlo) <= 1e-8 and rel(r.ci_upper, rhi) <= 1e-8
+                    if name == "SUM" and w["count"] >= 2:  # the reference scales the MEAN: r.mean x scale is its "sum"
+                        assert rel(r.mean * (100.0 / pct), w["reference_ci"]["SUM"][0]) <= EST_TOL
+        with pytest.raises(nat.AqeError):  # multi-round (CLT) queries have no grouped form
+            eng.reduce_grouped(make_query(nat.M_CLT_DUAL_POINTER, 20.0), nat.GROUP_REGION)
+        eng.stage_records(rows, keep_aos=False)
+        with pytest.raises(nat.AqeError):  # no key columns on the device
+            eng.reduce_grouped(make_query(nat.M_ROWID_MOD, 10.0), nat.GROUP_REGION)
+    n = 1_000_000
+    big = table(n)
+    with Engine(0) as eng:
+        eng.generate_synthetic(n, keep_aos=False)  # keys follow from the row number
+        for q, idx, where in (
+            (make_query(nat.M_BLOCK, 5.0, where=(250.0, 750.0)), oracle.idx_block(n, 5.0, 1000), (250.0, 750.0)),
+            (make_query(nat.M_MEMORY_STRIDE, 1.0), oracle.idx_memory_stride(n, 1.0), None),
+            (make_query(nat.M_EXACT, 100.0), np.arange(n, dtype=np.uint64), None),
+            (make_query(nat.M_PAGE, 3.0, block_size=4096), oracle.idx_page(n, 3.0, 4096), None),
+        ):
+            for column in (nat.GROUP_REGION, nat.GROUP_PRODUCT):
+                got = eng.reduce_grouped(q, column)
+                want = oracle.group(big, column, idx=idx, where=where)
+                vis = dict((k, c) for k, c, *_ in oracle.group(big, column, idx=idx))
+                want = {k: (c, s_, q_) for k, c, s_, q_ in want}
+                assert [r.key for r in got] == sorted(vis)  # every key with a sampled row, WHERE or not
+                for r in got:
+                    c, s_, q_ = want.get(r.key, (0, 0.0, 0.0))
+                    assert (r.n, r.visited) == (c, vis[r.key])
+                    assert abs(r.sum - s_) <= SUM_TOL * max(abs(s_), 1.0) and abs(r.sumsq - q_) <= SUM_TOL * max(abs(q_), 1.0)
+                assert sum(r.visited for r in got) == len(idx)

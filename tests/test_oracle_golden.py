@@ -247,3 +247,32 @@ def test_synthetic_generator_properties(oracle):
     assert a[500:].tobytes() == b.tobytes()        # shard-independent
     assert a["id"][0] == 1 and a["region"][5] == 1 and a["product_id"][123] == 23 and a["timestamp"][7] == 7
     assert 1.0 <= a["amount"].min() and a["amount"].max() < 1000.0
+
+
+def test_group_by_matches_sqlite_running_the_reference_sql(oracle):
+    """GROUP BY with per-group intervals (executor.cpp:202-321): the per-group (COUNT, SUM, SUM(x*x)) SQLite returns
+    for the statements the reference builds, and the reference's interval arithmetic (tests/golden/groupby_sqlite.json,
+    oracle/make_golden_groupby.py)."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "groupby_sqlite.json")))
+    rows = oracle.synth(g["table_rows"], g["seed"])
+    col = {"region": 1, "product_id": 2}
+    for case in g["cases"]:
+        got = oracle.group(rows, col[case["group_by"]], sample_percent=case["sample_percent"], where=case["where"])
+        want = [w for w in case["groups"] if w["count"] > 0]  # DISTINCT lists every key; only sampled keys have moments
+        assert [k for k, *_ in got] == [w["key"] for w in want]
+        for (k, n, s, q), w in zip(got, want):
+            assert n == w["count"]
+            assert abs(s - w["sum"]) <= 1e-12 * abs(w["sum"]) and abs(q - w["sumsq"]) <= 1e-12 * abs(w["sumsq"])
+            for agg, code in (("SUM", 0), ("AVG", 1)):
+                v, lo, hi = oracle.group_ci(code, w["count"], w["sum"], w["sumsq"], case["sample_percent"], reference_sum=True)
+                rv, rlo, rhi = w["reference_ci"][agg]
+                assert abs(v - rv) <= 1e-12 * abs(rv) and abs(lo - rlo) <= 1e-9 * abs(rlo) and abs(hi - rhi) <= 1e-9 * abs(rhi)
+    # the same grouping over an explicit index list (any sampler) agrees with numpy
+    import numpy as np
+    idx = oracle.idx_block(len(rows), 10.0, 1000)
+    got = oracle.group(rows, 2, idx=idx)
+    sub = rows[idx.astype(np.int64)]
+    for k, n, s, q in got:
+        m = sub["product_id"] == k
+        assert n == int(m.sum()) and abs(s - sub["amount"][m].sum()) <= 1e-9 * s
