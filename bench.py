@@ -172,27 +172,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(max(args.warmup, 1)):
-            step()
-        batched_dist = use_dist and bool(plan.totals_len)
-        fetch_all = sb.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
-        firsts = fetch_all()
-        first = firsts[0]
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, ONE query in flight,
+        #      taken before the throughput loop ----
+        for _ in range(3):
             step()
         fence()
-        dt = time.perf_counter() - t0
-        lasts = fetch_all()
-        last = lasts[0]
-        assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-
-        # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, one query in flight ----
         if not use_dist:
             one = lambda: plan.enqueue_all(st)  # noqa: E731
         elif plan.totals_len:
@@ -220,6 +204,26 @@ def main():
             plan.fetch(st)
             lat.append(time.perf_counter() - t1)
         lat.sort()
+
+        for _ in range(max(args.warmup, 1)):
+            step()
+        batched_dist = use_dist and bool(plan.totals_len)
+        fetch_all = sb.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
+        firsts = fetch_all()
+        first = firsts[0]
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        lasts = fetch_all()
+        last = lasts[0]
+        assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
 
     # the separate top-up launch never fires in this workload: not a sweep (the batched form has no such launch)
     sweeps = len(samples) - (1 if (plan.has_topup and len(samples) > 1) else 0)

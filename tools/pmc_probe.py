@@ -17,4 +17,7 @@ for _ in range(20):
     eng.reduce(clt)
 for _ in range(20):
     eng.reduce(blk)
+grp = make_query(nat.M_ROWID_MOD, 10.0, agg=nat.AVG)
+for _ in range(20):
+    eng.reduce_grouped(grp, nat.GROUP_PRODUCT)
 print("done")
