@@ -54,6 +54,9 @@ struct aqe_ctx {
     int32_t* keycol[2] = {nullptr, nullptr};  // [AQE_GROUP_REGION - 1], [AQE_GROUP_PRODUCT - 1]
     int32_t key_min[2] = {0, 0}, key_max[2] = {-1, -1};
     bool synthetic = false;  // made by aqe_generate_synthetic: keys follow from the row number
+    double* grp_partial = nullptr;          // GROUP BY scratch, grown on demand and kept with the context
+    size_t grp_partial_bytes = 0;
+    aqe_group_result* grp_out = nullptr;    // [kMaxGroupBins]
     bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
     int64_t first_id = 0;
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
@@ -806,6 +809,8 @@ void aqe_destroy(aqe_ctx* c) {
     drop_cache(c);
     free_table(c);
     if (c->d_stamps) (void)hipFree(c->d_stamps);
+    if (c->grp_partial) (void)hipFree(c->grp_partial);
+    if (c->grp_out) (void)hipFree(c->grp_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1269,17 +1274,23 @@ int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_gro
     const uint32_t nbins = static_cast<uint32_t>(span);
     const LaunchDesc& L = p->rounds[0];
     const unsigned grid = grouped_grid(L.ntiles);
-    double* d_partial = nullptr;
-    aqe_group_result* d_out = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_partial), static_cast<size_t>(grid) * nbins * 4 * sizeof(double)));
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), nbins * sizeof(aqe_group_result));
+    const size_t need = static_cast<size_t>(grid) * nbins * 4 * sizeof(double);
+    if (c->grp_partial_bytes < need) {  // scratch lives with the context: no allocation on the query path after the first call
+        if (c->grp_partial) (void)hipFree(c->grp_partial);
+        c->grp_partial = nullptr;
+        c->grp_partial_bytes = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_partial), need));
+        c->grp_partial_bytes = need;
+    }
+    if (!c->grp_out) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_out), kMaxGroupBins * sizeof(aqe_group_result)));
+    double* d_partial = c->grp_partial;
+    aqe_group_result* d_out = c->grp_out;
     std::vector<aqe_group_result> host(nbins);
+    hipError_t e = hipSuccess;
     if (e == hipSuccess) e = launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, c->keycol[k], c->key_min[k], nbins, d_partial, grid, c->stream);
     if (e == hipSuccess) e = launch_grouped_finish(d_partial, grid, nbins, c->key_min[k], c->shift, q->sample_percent, q->agg, d_out, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, nbins * sizeof(aqe_group_result), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_partial);
-    if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("grouped reduction: ") + hipGetErrorString(e));
     uint32_t g = 0;
     for (const aqe_group_result& r : host) {

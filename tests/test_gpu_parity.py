@@ -555,6 +555,15 @@ def test_full_size_properties(nat, oracle, n):
             # a sample mean of uniform data: within 6 standard errors of the table's mean (WHERE band: of 500)
             centre, sigma = (500.0, 144.4) if q.has_where else (whole.sum / n, 288.39)
             assert abs(r.sum / r.n - centre) < 6 * sigma / r.n ** 0.5 + 1e-9
+        # GROUP BY: the bins partition the sample — counts add up, sums add up to the ungrouped query's
+        for q in (make_query(nat.M_EXACT, 100.0), make_query(nat.M_BLOCK, 20.0, where=(250.0, 750.0)), make_query(nat.M_ROWID_MOD, 3.0)):
+            flat = eng.reduce(q)
+            for column, groups in ((nat.GROUP_REGION, 4), (nat.GROUP_PRODUCT, 100)):
+                got = eng.reduce_grouped(q, column)
+                assert len(got) == groups and [g_.key for g_ in got] == list(range(groups))
+                assert sum(g_.n for g_ in got) == flat.n and sum(g_.visited for g_ in got) == flat.visited
+                assert rel(math.fsum(g_.sum for g_ in got), flat.sum) <= 1e-12
+                assert rel(math.fsum(g_.sumsq for g_ in got), flat.sumsq) <= 1e-12
         # CLT monitor: one persistent launch == one launch per round, for a sweep that never converges, one that
         # stops in the middle and one that stops at once
         for e in (0.0, 0.005, 0.05, 1.0):
