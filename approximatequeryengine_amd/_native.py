@@ -138,7 +138,8 @@ def lib() -> C.CDLL:
         "aqe_plan_enqueue_replay": (C.c_int, [vp, vp, vp]),
         "aqe_batch_create": (C.c_int, [P(vp), u32, P(vp)]),
         "aqe_batch_destroy": (None, [vp]),
-        "aqe_batch_enqueue_sweeps": (C.c_int, [vp, vp, u64, vp]),
+        "aqe_batch_enqueue_sweeps": (C.c_int, [vp, vp, u64]),
+        "aqe_batch_join": (C.c_int, [vp, vp]),
         "aqe_batch_enqueue_replays": (C.c_int, [vp, vp, u64, vp]),
         "aqe_batch_fetch": (C.c_int, [vp, P(Result)]),
         "aqe_plan_reset": (C.c_int, [vp, vp]),

@@ -36,6 +36,8 @@ struct LaunchDesc {
 constexpr size_t kStageChunkRows = 1u << 21;  // 2 Mi rows: 64 MiB of AoS per pinned buffer
 }  // namespace
 
+constexpr size_t kBatchLanes = 3;  // side streams of the batched multi-GPU form (see ensure_lanes)
+
 struct aqe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -54,6 +56,7 @@ struct aqe_ctx {
     int32_t* keycol[2] = {nullptr, nullptr};  // [AQE_GROUP_REGION - 1], [AQE_GROUP_PRODUCT - 1]
     int32_t key_min[2] = {0, 0}, key_max[2] = {-1, -1};
     bool synthetic = false;  // made by aqe_generate_synthetic: keys follow from the row number
+    std::vector<hipStream_t> lanes;         // side streams of the batched multi-GPU form (aqe_batch), made on first use
     double* grp_partial = nullptr;          // GROUP BY scratch, grown on demand and kept with the context
     size_t grp_partial_bytes = 0;
     aqe_group_result* grp_out = nullptr;    // [kMaxGroupBins]
@@ -811,6 +814,7 @@ void aqe_destroy(aqe_ctx* c) {
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->grp_partial) (void)hipFree(c->grp_partial);
     if (c->grp_out) (void)hipFree(c->grp_out);
+    for (hipStream_t s : c->lanes) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1149,24 +1153,32 @@ int aqe_plan_enqueue_replay(aqe_plan* p, const double* dev_totals, void* stream)
     return AQE_OK;
 }
 
-// Side streams of a batch.  Three, not one per plan: the runtime multiplexes streams onto a handful of hardware
-// queues, and a stream that waits on an event blocks every other stream sharing its queue.  Three lanes plus the
-// caller's stream each get a queue of their own, and two kernels in flight are already enough for one query's
-// hand-off tail to overlap the next query's sweep.
-constexpr size_t kBatchLanes = 3;
+// Side streams of the batched form, owned by the context and shared by its batches.  Three, not one per plan: the
+// runtime multiplexes streams onto a handful of hardware queues, and a stream that waits on an event blocks every
+// other stream sharing its queue.  Three lanes plus the caller's stream each get a queue of their own, and two
+// kernels in flight are already enough for one query's hand-off tail to overlap the next query's sweep.
+int ensure_lanes(aqe_ctx* c) {
+    while (c->lanes.size() < kBatchLanes) {
+        hipStream_t s = nullptr;
+        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        c->lanes.push_back(s);
+    }
+    return AQE_OK;
+}
 
 struct aqe_batch {
     aqe_ctx* ctx = nullptr;
-    std::vector<aqe_plan*> plans;
-    std::vector<hipStream_t> lanes;  // plan i runs on lane i % lanes.size()
-    std::vector<hipEvent_t> swept;   // lane l's sweeps are enqueued up to here
-    hipEvent_t reduced = nullptr;    // the caller's stream up to (and including) the collective
+    std::vector<aqe_plan*> plans;   // plan i runs on lane i % kBatchLanes of the context
+    std::vector<hipEvent_t> swept;  // lane l's sweeps of this batch are enqueued up to here
+    hipEvent_t reduced = nullptr;   // the caller's stream up to (and including) the collective
 };
 
 void aqe_batch_destroy(aqe_batch* b) {
     if (!b) return;
-    if (b->ctx) (void)hipSetDevice(b->ctx->device);
-    for (hipStream_t s : b->lanes) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        for (hipStream_t s : b->ctx->lanes) (void)hipStreamSynchronize(s);
+    }
     for (hipEvent_t e : b->swept) (void)hipEventDestroy(e);
     if (b->reduced) (void)hipEventDestroy(b->reduced);
     delete b;
@@ -1182,13 +1194,12 @@ int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out) {
     }
     aqe_ctx* c = plans[0]->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_lanes(c);
+    if (rc != AQE_OK) return rc;
     std::unique_ptr<aqe_batch, void (*)(aqe_batch*)> b(new aqe_batch, aqe_batch_destroy);
     b->ctx = c;
     b->plans.assign(plans, plans + n);
-    for (size_t l = 0; l < std::min<size_t>(n, kBatchLanes); ++l) {
-        hipStream_t s = nullptr;
-        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        b->lanes.push_back(s);
+    for (size_t l = 0; l < kBatchLanes; ++l) {
         hipEvent_t e = nullptr;
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         b->swept.push_back(e);
@@ -1198,12 +1209,10 @@ int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out) {
     return AQE_OK;
 }
 
-int aqe_batch_enqueue_sweeps(aqe_batch* b, double* dev_totals, uint64_t row_stride, void* stream) {
+int aqe_batch_enqueue_sweeps(aqe_batch* b, double* dev_totals, uint64_t row_stride) {
     if (!b || !dev_totals) return AQE_ERR_INVALID;
     aqe_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const size_t L = b->lanes.size();
     for (size_t i = 0; i < b->plans.size(); ++i) {
         aqe_plan* p = b->plans[i];
         int rc = plan_is_current(p);
@@ -1211,13 +1220,19 @@ int aqe_batch_enqueue_sweeps(aqe_batch* b, double* dev_totals, uint64_t row_stri
         if (row_stride < static_cast<uint64_t>(p->totals.slots) * kVec) return fail(c, AQE_ERR_INVALID, "row_stride shorter than a plan's totals");
         p->lev_used = 0;
         // (the plan's previous replay precedes this sweep in its lane: nothing to wait for)
-        rc = launch_form(p, p->totals, true, dev_totals + i * row_stride, b->lanes[i % L]);
+        rc = launch_form(p, p->totals, true, dev_totals + i * row_stride, c->lanes[i % kBatchLanes]);
         if (rc != AQE_OK) return rc;
     }
-    for (size_t l = 0; l < L; ++l) {  // the caller's stream (the collective) waits for every lane
-        HIPCHK(c, hipEventRecord(b->swept[l], b->lanes[l]));
-        HIPCHK(c, hipStreamWaitEvent(main_s, b->swept[l], 0));
-    }
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipEventRecord(b->swept[l], c->lanes[l]));
+    return AQE_OK;
+}
+
+int aqe_batch_join(aqe_batch* b, void* stream) {
+    if (!b) return AQE_ERR_INVALID;
+    aqe_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(main_s, b->swept[l], 0));
     return AQE_OK;
 }
 
@@ -1226,15 +1241,14 @@ int aqe_batch_enqueue_replays(aqe_batch* b, const double* dev_totals, uint64_t r
     aqe_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const size_t L = b->lanes.size();
     HIPCHK(c, hipEventRecord(b->reduced, main_s));
-    for (size_t l = 0; l < L; ++l) HIPCHK(c, hipStreamWaitEvent(b->lanes[l], b->reduced, 0));  // every lane waits for the collective
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->lanes[l], b->reduced, 0));  // every lane waits for the collective
     for (size_t i = 0; i < b->plans.size(); ++i) {
         aqe_plan* p = b->plans[i];
         int rc = plan_is_current(p);
         if (rc != AQE_OK) return rc;
         HIPCHK(c, launch_replay(dev_totals + i * row_stride, static_cast<uint32_t>(p->rounds.size()), p->host.has_topup ? 1u : 0u,
-                                fold_params(p, false), finalize_params(p), p->d_state, p->d_result, b->lanes[i % L]));
+                                fold_params(p, false), finalize_params(p), p->d_state, p->d_result, c->lanes[i % kBatchLanes]));
     }
     return AQE_OK;
 }
@@ -1244,7 +1258,7 @@ int aqe_batch_fetch(aqe_batch* b, aqe_result* out_n) {
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
     for (size_t i = 0; i < b->plans.size(); ++i) {
         int rc = plan_is_current(b->plans[i]);
-        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, b->lanes[i % b->lanes.size()]);
+        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, b->ctx->lanes[i % kBatchLanes]);
         if (rc != AQE_OK) return rc;
     }
     return AQE_OK;

@@ -112,18 +112,29 @@ class ShardedBatch:
         if buf.dim() != 2 or buf.shape[0] < len(self.plans) or buf.shape[1] < self.width or not buf.is_contiguous():
             raise ValueError("buffer must be a contiguous [len(plans), >= totals_len] float64 tensor")
 
-    def enqueue(self) -> None:
+    def enqueue_sweeps(self) -> None:
+        """First half of a step: every plan's sweep (this shard's round totals into the plan's row of the buffer)."""
+        if self.batch is not None:
+            self.batch.enqueue_sweeps(self.buf.data_ptr(), self.buf.shape[1])
+            return
+        for i, p in enumerate(self.plans):
+            p.enqueue_sweep_totals(self.buf[i].data_ptr(), self.stream)
+
+    def finish(self) -> None:
+        """Second half: the ONE collective of the batch, then every plan's replay."""
         s, ptr, stride = self.stream, self.buf.data_ptr(), self.buf.shape[1]
         if self.batch is not None:
-            self.batch.enqueue_sweeps(ptr, stride, s)
+            self.batch.join(s)
             self.all_reduce(self.buf)
             self.batch.enqueue_replays(ptr, stride, s)
             return
-        for i, p in enumerate(self.plans):
-            p.enqueue_sweep_totals(self.buf[i].data_ptr(), s)
         self.all_reduce(self.buf)
         for i, p in enumerate(self.plans):
             p.enqueue_replay(self.buf[i].data_ptr(), s)
+
+    def enqueue(self) -> None:
+        self.enqueue_sweeps()
+        self.finish()
 
     def fetch(self):
         return self.batch.fetch() if self.batch is not None else [p.fetch(self.stream) for p in self.plans]
@@ -144,6 +155,35 @@ class ShardedBatch:
                 self.plans[i].enqueue_finalize(s)
                 out[i] = self.plans[i].fetch(s)
         return out
+
+
+class PipelinedBatches:
+    """Two (or more) ShardedBatch objects over the same engine, software-pipelined: a step enqueues the sweeps of
+    one batch and only then finishes the previous step's batch, so that batch's collective (tens of microseconds
+    of latency on xGMI, during which its GPU would idle) runs under the next batch's sweeps.  Same queries, same
+    answers; ``flush`` finishes the step still in flight."""
+
+    def __init__(self, batches):
+        self.batches = list(batches)
+        self._k = 0
+        self._pending = None
+
+    def enqueue(self) -> None:
+        cur = self.batches[self._k % len(self.batches)]
+        self._k += 1
+        cur.enqueue_sweeps()
+        if self._pending is not None:
+            self._pending.finish()
+        self._pending = cur
+
+    def flush(self) -> None:
+        if self._pending is not None:
+            self._pending.finish()
+            self._pending = None
+
+    def fetch(self):
+        self.flush()
+        return [r for b in self.batches for r in b.fetch()]
 
 
 def torch_all_reduce(group=None) -> Callable:

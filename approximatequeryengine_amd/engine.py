@@ -100,8 +100,8 @@ class Plan:
 
 class Batch:
     """Plans of one Engine driven through the batched multi-GPU form together (aqe_batch): the sweeps run on
-    side streams the batch owns, ``stream`` — where the caller issues the collective — waits for them, and the
-    replays go back to the side streams.  Two host calls per step for the whole batch."""
+    the engine's side streams, ``stream`` — where the caller issues the collective — is made to wait for them
+    (join), and the replays go back to the side streams.  Three host calls per step for the whole batch."""
 
     def __init__(self, plans):
         self.plans = list(plans)
@@ -121,8 +121,11 @@ class Batch:
         except Exception:
             pass
 
-    def enqueue_sweeps(self, dev_totals_ptr: int, row_stride: int, stream: int = 0):
-        nat.check(nat.lib().aqe_batch_enqueue_sweeps(self._h, C.c_void_p(dev_totals_ptr), row_stride, C.c_void_p(stream)), self.engine._h)
+    def enqueue_sweeps(self, dev_totals_ptr: int, row_stride: int):
+        nat.check(nat.lib().aqe_batch_enqueue_sweeps(self._h, C.c_void_p(dev_totals_ptr), row_stride), self.engine._h)
+
+    def join(self, stream: int = 0):
+        nat.check(nat.lib().aqe_batch_join(self._h, C.c_void_p(stream)), self.engine._h)
 
     def enqueue_replays(self, dev_totals_ptr: int, row_stride: int, stream: int = 0):
         nat.check(nat.lib().aqe_batch_enqueue_replays(self._h, C.c_void_p(dev_totals_ptr), row_stride, C.c_void_p(stream)), self.engine._h)

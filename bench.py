@@ -99,7 +99,7 @@ def main():
     import torch
     import torch.distributed as dist
     from approximatequeryengine_amd import _native as nat
-    from approximatequeryengine_amd.distributed import ShardedBatch, ShardedQuery, shard_bounds, torch_all_reduce
+    from approximatequeryengine_amd.distributed import PipelinedBatches, ShardedBatch, ShardedQuery, shard_bounds, torch_all_reduce
     from approximatequeryengine_amd.engine import Batch, Engine, make_query
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,10 +136,12 @@ def main():
     q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=0.95, check_interval=10,
                    num_threads=4 * world, max_error_percent=e, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
     # One step = a batch of B independent copies of the query, each with its own plan (hand-off scratch).
-    # 1 GPU: one HIP stream per query, in-kernel decisions (k_sweep_persist).  N GPUs: every query's slot totals
-    # go into one [B, totals] buffer, ONE RCCL all-reduce per step, then k_replay decides each query.
+    # 1 GPU: one HIP stream per query, in-kernel decisions (k_sweep_persist).  N GPUs: every query's round totals
+    # go into one [B, totals] buffer, ONE RCCL all-reduce per step, then k_replay decides each query; two such
+    # batches alternate, software-pipelined, so that one step's collective runs under the next step's sweeps.
     B = max(1, args.batch)
     plans = [eng.plan(q) for _ in range(B)]
+    pipe = None
     sides = [torch.cuda.Stream() for _ in range(1 if use_dist else B)]
     plan, side = plans[0], sides[0]
     st = side.cuda_stream
@@ -148,11 +150,15 @@ def main():
     with torch.cuda.stream(side):
         if use_dist:
             if plan.totals_len:
-                buf = torch.zeros(B, plan.totals_len, dtype=torch.float64, device="cuda")
-                native = Batch(plans)  # side streams owned by the library; two host calls per step
-                sb = ShardedBatch(plans, buf, torch_all_reduce(), stream=st, batch=native)
-                step = sb.enqueue
-                n_streams = 1 + min(B, 3)
+                plans = plans + [eng.plan(q) for _ in range(B)]  # the second batch of the pipeline
+                natives, sbs = [], []
+                for half in (plans[:B], plans[B:]):
+                    buf = torch.zeros(B, plan.totals_len, dtype=torch.float64, device="cuda")
+                    natives.append(Batch(half))  # sweeps and replays on the library's side streams
+                    sbs.append(ShardedBatch(half, buf, torch_all_reduce(), stream=st, batch=natives[-1]))
+                pipe = PipelinedBatches(sbs)
+                step = pipe.enqueue
+                n_streams = 1 + 3
                 collectives_per_step = 1
             else:  # plans without a batched form: one collective per convergence step and query
                 vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
@@ -167,6 +173,8 @@ def main():
                     p.enqueue_all(s_.cuda_stream)
 
         def fence():
+            if pipe is not None:
+                pipe.flush()
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
@@ -208,7 +216,7 @@ def main():
         for _ in range(max(args.warmup, 1)):
             step()
         batched_dist = use_dist and bool(plan.totals_len)
-        fetch_all = sb.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
+        fetch_all = pipe.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
         firsts = fetch_all()
         first = firsts[0]
         fence()
@@ -293,8 +301,9 @@ def main():
                                         "sample": f"failed: {ex!r}"}
         print(json.dumps(line), flush=True)
 
-    if use_dist and plan.totals_len:
-        native.close()
+    if pipe is not None:
+        for nb in natives:
+            nb.close()
     for p in plans:
         p.close()
     eng.close()

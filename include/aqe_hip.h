@@ -290,19 +290,23 @@ AQE_API int aqe_plan_totals_len(const aqe_plan* plan, uint32_t* n_doubles);
 AQE_API int aqe_plan_enqueue_sweep_totals(aqe_plan* plan, double* dev_totals, void* stream);
 AQE_API int aqe_plan_enqueue_replay(aqe_plan* plan, const double* dev_totals, void* stream);
 /* A batch of plans of ONE context driven through the batched form together, so that one collective serves all
- * of them and the host pays two calls per step instead of two per query.  The batch owns a few side streams
- * and deals the plans over them: sweeps run concurrently (one query's hand-off tail overlaps the next query's
- * sweep), `stream` (the stream the caller issues the collective on) waits for all of them, and after the
- * collective every replay goes back to its plan's side stream.
- *     aqe_batch_enqueue_sweeps(b, totals, row_stride, stream)    row i = plan i's round totals
+ * of them and the host pays a few calls per step instead of two per query.  The context owns three side streams
+ * and a batch deals its plans over them: sweeps run concurrently (one query's hand-off tail overlaps the next
+ * query's sweep), the caller's `stream` — where it issues the collective — is made to wait for them, and after
+ * the collective every replay goes back to its plan's side stream.
+ *     aqe_batch_enqueue_sweeps(b, totals, row_stride)            row i = plan i's round totals
+ *     aqe_batch_join(b, stream)                                  `stream` waits for the batch's sweeps
  *     <ONE all-reduce SUM of the whole [n, row_stride] buffer on `stream`>
- *     aqe_batch_enqueue_replays(b, totals, row_stride, stream)
+ *     aqe_batch_enqueue_replays(b, totals, row_stride, stream)   the side streams wait for `stream`, then replay
  *     ... next step ...   aqe_batch_fetch(b, results) synchronises and returns every plan's result
+ * Two batches (each with its own buffer) can be software-pipelined — sweeps of B, then join/collective/replays of
+ * A, then sweeps of A, ... — so that one batch's collective runs under the other's sweeps.
  * (topup_pending results are finished per plan with the stepwise calls, as above). */
 typedef struct aqe_batch aqe_batch;
 AQE_API int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out);
 AQE_API void aqe_batch_destroy(aqe_batch* batch);
-AQE_API int aqe_batch_enqueue_sweeps(aqe_batch* batch, double* dev_totals, uint64_t row_stride_doubles, void* stream);
+AQE_API int aqe_batch_enqueue_sweeps(aqe_batch* batch, double* dev_totals, uint64_t row_stride_doubles);
+AQE_API int aqe_batch_join(aqe_batch* batch, void* stream);
 AQE_API int aqe_batch_enqueue_replays(aqe_batch* batch, const double* dev_totals, uint64_t row_stride_doubles, void* stream);
 AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
 /* fused single-GPU form: round + update in one launch (the last workgroup to arrive folds) */

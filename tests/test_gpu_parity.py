@@ -609,6 +609,7 @@ def test_native_batch_drives_several_plans_with_two_calls_per_step(nat, table):
                 for _ in range(4):
                     sb.enqueue()          # steps back to back, no host synchronisation in between
                 got = sb.fetch()
+                assert calls[0] % 4 == 0
                 assert [g_.topup_pending for g_ in got] == [1 if w.topup else 0 for w in want]
                 for g_, w in zip(got, want):
                     assert (g_.converged, g_.rounds, g_.device_status) == (w.converged, w.rounds, 0)
@@ -620,6 +621,24 @@ def test_native_batch_drives_several_plans_with_two_calls_per_step(nat, table):
                 assert (g_.n, g_.visited, g_.converged, g_.rounds, g_.topup, g_.topup_pending) == (w.n, w.visited, w.converged, w.rounds, w.topup, 0)
                 assert rel(g_.sum, w.sum) <= 1e-13 and rel(g_.value, w.value) <= 1e-13
             assert any(w.topup for w in want) and not all(w.topup for w in want)
+            # two batches software-pipelined: a step's collective is issued after the NEXT step's sweeps
+            from approximatequeryengine_amd.distributed import PipelinedBatches
+            plans2 = [eng.plan(q) for q in qs]
+            buf2 = torch.full((len(plans2), width), float("nan"), dtype=torch.float64, device="cuda")
+            native2 = Batch(plans2)
+            pipe = PipelinedBatches([sb, ShardedBatch(plans2, buf2, all_reduce, stream=side.cuda_stream, batch=native2)])
+            before = calls[0]
+            for _ in range(7):
+                pipe.enqueue()
+            got = pipe.fetch()
+            assert calls[0] - before == 7 and len(got) == 2 * len(qs)
+            for g_, w in zip(got, want + want):
+                assert (g_.converged, g_.rounds, g_.device_status, g_.topup_pending) == (w.converged, w.rounds, 0, 1 if w.topup else 0)
+                if not w.topup:
+                    assert (g_.n, g_.visited) == (w.n, w.visited) and rel(g_.sum, w.sum) <= 1e-13
+            native2.close()
+            for p in plans2:
+                p.close()
             native.close()
         with pytest.raises(nat.AqeError):
             Batch([plans[0], plans[0]])
