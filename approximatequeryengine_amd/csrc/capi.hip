@@ -101,8 +101,10 @@ struct aqe_plan {
     LaunchDesc topup;
     uint64_t* d_idx = nullptr;
     QueryState* d_state = nullptr;
-    aqe_result* d_result = nullptr;
-    aqe_result* h_result = nullptr;  // pinned
+    // The result lives in pinned host memory mapped into the device: the kernel that finishes the query stores the
+    // 120 bytes across PCIe itself, and fetching is a stream synchronisation — no copy to enqueue.
+    aqe_result* h_result = nullptr;  // pinned, mapped
+    aqe_result* d_result = nullptr;  // the device's address of h_result
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     // Scratch of the hand-off protocols.  It belongs to the plan, not the context, so several plans can be
@@ -186,7 +188,6 @@ void destroy_plan(aqe_plan* p) {
         if (f->d_ppart) (void)hipFree(f->d_ppart);
     }
     if (p->d_state) (void)hipFree(p->d_state);
-    if (p->d_result) (void)hipFree(p->d_result);
     if (p->h_result) (void)hipHostFree(p->h_result);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -543,8 +544,9 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
     HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_result), sizeof(aqe_result)));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), sizeof(aqe_result), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), sizeof(aqe_result), hipHostMallocMapped));
+    std::memset(p->h_result, 0, sizeof(aqe_result));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
     HIPCHK(c, hipEventCreate(&p->ev0));
     HIPCHK(c, hipEventCreate(&p->ev1));
     *out = p.release();
@@ -627,7 +629,6 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
 
 int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     aqe_ctx* c = p->ctx;
-    HIPCHK(c, hipMemcpyAsync(p->h_result, p->d_result, sizeof(aqe_result), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     *out = *p->h_result;
     if (c->d_stamps && p->persist) {
