@@ -576,6 +576,24 @@ def test_full_size_properties(nat, oracle, n):
             assert rel(res.sum, multi.sum) <= 1e-13 and rel(res.sumsq, multi.sumsq) <= 1e-13 and rel(res.ci_lower, multi.ci_lower) <= 1e-12
             if e == 0.0:  # the reference's full dual-pointer sweep: 2 x base rows, no top-up
                 assert res.n == 2 * int(n * 20.0 / 100.0) and res.topup == 0 and res.converged == 0
+            # ... and == the batched multi-GPU form on a world of one shard (every round's total in one launch,
+            # replayed; the top-up, when due, as the stepwise step)
+            import torch
+            plan = eng.plan(q)
+            tot = torch.full((plan.totals_len,), float("nan"), dtype=torch.float64, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            plan.enqueue_sweep_totals(tot.data_ptr(), st)
+            plan.enqueue_replay(tot.data_ptr(), st)
+            b = plan.fetch(st)
+            assert b.topup_pending == (1 if res.topup else 0) and (b.converged, b.rounds) == (res.converged, res.rounds)
+            if b.topup_pending:
+                vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
+                plan.enqueue_round(plan.rounds, vec.data_ptr(), st)
+                plan.enqueue_update(plan.rounds, vec.data_ptr(), st)
+                plan.enqueue_finalize(st)
+                b = plan.fetch(st)
+            assert (b.n, b.visited, b.topup) == (res.n, res.visited, res.topup) and rel(b.sum, res.sum) <= 1e-13 and rel(b.ci_upper, res.ci_upper) <= 1e-12
+            plan.close()
             assert abs(res.value - whole.sum / n) <= 3.0 * (res.ci_upper - res.ci_lower) / 2  # 95 % half-width x 3 ~ 6 sigma
 
 
