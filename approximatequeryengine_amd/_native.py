@@ -125,6 +125,9 @@ def lib() -> C.CDLL:
         "aqe_error_to_sample_percent": (dbl, [dbl]),
         "aqe_reduce": (C.c_int, [vp, P(Query), P(Result)]),
         "aqe_reduce_grouped": (C.c_int, [vp, P(Query), C.c_int, P(GroupResult), u32, P(u32)]),
+        "aqe_group_key_range": (C.c_int, [vp, C.c_int, P(C.c_int32), P(C.c_int32)]),
+        "aqe_grouped_enqueue_bins": (C.c_int, [vp, P(Query), C.c_int, C.c_int32, u32, vp, vp]),
+        "aqe_grouped_finish": (C.c_int, [vp, P(Query), C.c_int32, u32, vp, vp, P(GroupResult), u32, P(u32)]),
         "aqe_gather": (C.c_int, [vp, P(Query), vp, u64, P(u64)]),
         "aqe_plan_create": (C.c_int, [vp, P(Query), P(vp)]),
         "aqe_plan_destroy": (None, [vp]),

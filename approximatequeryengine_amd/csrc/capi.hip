@@ -60,6 +60,7 @@ struct aqe_ctx {
     double* grp_partial = nullptr;          // GROUP BY scratch, grown on demand and kept with the context
     size_t grp_partial_bytes = 0;
     aqe_group_result* grp_out = nullptr;    // [kMaxGroupBins]
+    double* grp_bins = nullptr;             // [kMaxGroupBins][4] (single-GPU form)
     bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
     int64_t first_id = 0;
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
@@ -477,6 +478,9 @@ int ensure_sorted(aqe_ctx* c) {
 
 int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    if (q->agg < AQE_SUM || q->agg > AQE_COUNT) return fail(c, AQE_ERR_INVALID, "agg must be AQE_SUM, AQE_AVG or AQE_COUNT");
+    if (q->convention < AQE_EST_CLI || q->convention > AQE_EST_RAW) return fail(c, AQE_ERR_INVALID, "convention must be AQE_EST_CLI, AQE_EST_CPP or AQE_EST_RAW");
+    if (q->has_where && (q->where_min != q->where_min || q->where_max != q->where_max)) return fail(c, AQE_ERR_INVALID, "WHERE bound is NaN");
     std::unique_ptr<aqe_plan, void (*)(aqe_plan*)> p(new aqe_plan(), destroy_plan);
     p->ctx = c;
     p->q = *q;
@@ -815,6 +819,7 @@ void aqe_destroy(aqe_ctx* c) {
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->grp_partial) (void)hipFree(c->grp_partial);
     if (c->grp_out) (void)hipFree(c->grp_out);
+    if (c->grp_bins) (void)hipFree(c->grp_bins);
     for (hipStream_t s : c->lanes) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1265,28 +1270,55 @@ int aqe_batch_fetch(aqe_batch* b, aqe_result* out_n) {
     return AQE_OK;
 }
 
-int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_group_result* out, uint32_t cap, uint32_t* n_groups) {
-    if (!c) return AQE_ERR_INVALID;
-    if (!q || !n_groups || (cap && !out)) return fail(c, AQE_ERR_INVALID, "null argument");
+namespace {
+int grouped_args(aqe_ctx* c, const aqe_query* q, int group_column) {
+    if (!q) return fail(c, AQE_ERR_INVALID, "null query");
     if (group_column != AQE_GROUP_REGION && group_column != AQE_GROUP_PRODUCT) return fail(c, AQE_ERR_INVALID, "group_column must be AQE_GROUP_REGION or AQE_GROUP_PRODUCT");
     if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
     if (!(q->sample_percent > 0.0)) return fail(c, AQE_ERR_INVALID, "sample_percent must be positive");
+    return AQE_OK;
+}
+}  // namespace
+
+int aqe_group_key_range(aqe_ctx* c, int group_column, int32_t* key_min, int32_t* key_max) {
+    if (!c) return AQE_ERR_INVALID;
+    if (!key_min || !key_max) return fail(c, AQE_ERR_INVALID, "null argument");
+    if (group_column != AQE_GROUP_REGION && group_column != AQE_GROUP_PRODUCT) return fail(c, AQE_ERR_INVALID, "group_column must be AQE_GROUP_REGION or AQE_GROUP_PRODUCT");
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
     HIPCHK(c, hipSetDevice(c->device));
-    *n_groups = 0;
+    *key_min = std::numeric_limits<int32_t>::max();  // an empty shard: the neutral elements of MIN / MAX
+    *key_max = std::numeric_limits<int32_t>::min();
+    if (c->n_local == 0) return AQE_OK;
+    int rc = ensure_keys(c, group_column);
+    if (rc != AQE_OK) return rc;
+    *key_min = c->key_min[group_column - 1];
+    *key_max = c->key_max[group_column - 1];
+    return AQE_OK;
+}
+
+int aqe_grouped_enqueue_bins(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, double* dev_bins, void* stream) {
+    if (!c) return AQE_ERR_INVALID;
+    int rc = grouped_args(c, q, group_column);
+    if (rc != AQE_OK) return rc;
+    if (!dev_bins || nbins == 0 || nbins > static_cast<uint32_t>(kMaxGroupBins)) return fail(c, AQE_ERR_INVALID, "dev_bins null or nbins outside 1..1024");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     aqe_plan* p = nullptr;
-    int rc = cached_plan(c, q, &p);
+    rc = cached_plan(c, q, &p);
     if (rc != AQE_OK) return rc;
     if (p->host.is_random || p->host.is_clt || p->host.on_sorted || p->rounds.size() > 1)
         return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction takes a single-round family sampler (exact, stride, rowid-mod, block, page, pointer, region ...)");
-    if (p->rounds.empty() || c->n_local == 0) return AQE_OK;  // nothing sampled: no groups
     for (const DevFamily& f : p->h_fams)
         if (f.flags & AQE_F_PAIR) return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction does not take pair families");
+    if (p->rounds.empty() || c->n_local == 0 || p->rounds[0].ntiles == 0) {  // nothing of the sample in this shard
+        HIPCHK(c, hipMemsetAsync(dev_bins, 0, static_cast<size_t>(nbins) * 4 * sizeof(double), s));
+        return AQE_OK;
+    }
     rc = ensure_keys(c, group_column);
     if (rc != AQE_OK) return rc;
     const int k = group_column - 1;
-    const int64_t span = static_cast<int64_t>(c->key_max[k]) - c->key_min[k] + 1;
-    if (span < 1 || span > kMaxGroupBins) return fail(c, AQE_ERR_UNSUPPORTED, "group column spans more than 1024 distinct values");
-    const uint32_t nbins = static_cast<uint32_t>(span);
+    if (c->key_min[k] < key_min || static_cast<int64_t>(c->key_max[k]) - key_min >= static_cast<int64_t>(nbins))
+        return fail(c, AQE_ERR_INVALID, "this shard has keys outside [key_min, key_min + nbins)");
     const LaunchDesc& L = p->rounds[0];
     const unsigned grid = grouped_grid(L.ntiles);
     const size_t need = static_cast<size_t>(grid) * nbins * 4 * sizeof(double);
@@ -1297,16 +1329,24 @@ int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_gro
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_partial), need));
         c->grp_partial_bytes = need;
     }
+    HIPCHK(c, launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, c->keycol[k], key_min, nbins, c->grp_partial, grid, s));
+    HIPCHK(c, launch_grouped_sum(c->grp_partial, grid, nbins, dev_bins, s));
+    return AQE_OK;
+}
+
+int aqe_grouped_finish(aqe_ctx* c, const aqe_query* q, int32_t key_min, uint32_t nbins, const double* dev_bins, void* stream,
+                       aqe_group_result* out, uint32_t cap, uint32_t* n_groups) {
+    if (!c) return AQE_ERR_INVALID;
+    if (!q || !n_groups || (cap && !out) || !dev_bins || nbins == 0 || nbins > static_cast<uint32_t>(kMaxGroupBins)) return fail(c, AQE_ERR_INVALID, "bad argument");
+    if (q->agg < AQE_SUM || q->agg > AQE_COUNT || !(q->sample_percent > 0.0)) return fail(c, AQE_ERR_INVALID, "bad agg or sample_percent");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    *n_groups = 0;
     if (!c->grp_out) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_out), kMaxGroupBins * sizeof(aqe_group_result)));
-    double* d_partial = c->grp_partial;
-    aqe_group_result* d_out = c->grp_out;
     std::vector<aqe_group_result> host(nbins);
-    hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, c->keycol[k], c->key_min[k], nbins, d_partial, grid, c->stream);
-    if (e == hipSuccess) e = launch_grouped_finish(d_partial, grid, nbins, c->key_min[k], c->shift, q->sample_percent, q->agg, d_out, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, nbins * sizeof(aqe_group_result), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("grouped reduction: ") + hipGetErrorString(e));
+    HIPCHK(c, launch_grouped_finish(dev_bins, nbins, key_min, c->shift, q->sample_percent, q->agg, c->grp_out, s));
+    HIPCHK(c, hipMemcpyAsync(host.data(), c->grp_out, nbins * sizeof(aqe_group_result), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
     uint32_t g = 0;
     for (const aqe_group_result& r : host) {
         if (r.visited == 0) continue;  // a key nobody sampled
@@ -1316,6 +1356,25 @@ int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_gro
     *n_groups = g;
     if (g > cap) return fail(c, AQE_ERR_CAPACITY, "more groups than the caller's buffer holds (n_groups has the count)");
     return AQE_OK;
+}
+
+int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_group_result* out, uint32_t cap, uint32_t* n_groups) {
+    if (!c) return AQE_ERR_INVALID;
+    if (!n_groups || (cap && !out)) return fail(c, AQE_ERR_INVALID, "null argument");
+    int rc = grouped_args(c, q, group_column);
+    if (rc != AQE_OK) return rc;
+    *n_groups = 0;
+    int32_t kmin = 0, kmax = -1;
+    rc = aqe_group_key_range(c, group_column, &kmin, &kmax);
+    if (rc != AQE_OK) return rc;
+    if (kmax < kmin) return AQE_OK;  // empty table: no groups
+    const int64_t span = static_cast<int64_t>(kmax) - kmin + 1;
+    if (span > kMaxGroupBins) return fail(c, AQE_ERR_UNSUPPORTED, "group column spans more than 1024 distinct values");
+    const uint32_t nbins = static_cast<uint32_t>(span);
+    if (!c->grp_bins) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_bins), static_cast<size_t>(kMaxGroupBins) * 4 * sizeof(double)));
+    rc = aqe_grouped_enqueue_bins(c, q, group_column, kmin, nbins, c->grp_bins, c->stream);
+    if (rc != AQE_OK) return rc;
+    return aqe_grouped_finish(c, q, kmin, nbins, c->grp_bins, c->stream, out, cap, n_groups);
 }
 
 int aqe_plan_enqueue_all(aqe_plan* p, void* stream) {

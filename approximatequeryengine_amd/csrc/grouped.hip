@@ -8,8 +8,9 @@
 //   * a workgroup accumulates into LDS-privatised bins.  With up to kRegBins bins (region) every lane keeps its own
 //     bins in registers and adds them to LDS once at the end — 64 lanes hammering 4 LDS addresses with atomics would
 //     serialise; with more bins (product_id) lanes add straight to LDS (ds_add_f64), where collisions are rare;
-//   * workgroups write their bins to a [workgroup][bin][4] buffer and k_grouped_finish sums them per bin in
-//     workgroup order and works out mean, variance, estimate and interval (executor.cpp:277-296).
+//   * workgroups write their bins to a [workgroup][bin][4] buffer, k_grouped_sum adds them per bin in workgroup
+//     order (this is what ranks all-reduce in the multi-GPU form: the bins are additive), and k_grouped_finish
+//     works out mean, variance, estimate and interval (executor.cpp:277-296).
 //
 // Counts are exact.  Within a workgroup the LDS additions happen in whatever order the lanes arrive, so the
 // floating-point sums of a group are reproducible to rounding (1e-15 relative), not bit for bit.
@@ -145,16 +146,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
     for (unsigned i = threadIdx.x; i < a.nbins * 4; i += kBlockThreads) out[i] = bins[i];
 }
 
-// One thread per bin: sum the workgroups' bins in workgroup order, then estimate and interval of the group.
-__global__ __launch_bounds__(64) void k_grouped_finish(const double* __restrict__ partial, unsigned nblocks, unsigned nbins, int32_t key_min,
-                                                       double shift, double pct, int agg, aqe_group_result* __restrict__ out) {
+// One thread per (bin, component): sum the workgroups' bins in workgroup order -> bins[nbins][4].
+__global__ __launch_bounds__(256) void k_grouped_sum(const double* __restrict__ partial, unsigned nblocks, unsigned nbins, double* __restrict__ bins) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nbins * 4) return;
+    double t = 0.0;
+    for (unsigned w = 0; w < nblocks; ++w) t += partial[static_cast<size_t>(w) * nbins * 4 + i];
+    bins[i] = t;
+}
+
+// One thread per bin: estimate and interval of the group from its (all-reduced) sums.
+__global__ __launch_bounds__(64) void k_grouped_finish(const double* __restrict__ bins, unsigned nbins, int32_t key_min, double shift, double pct,
+                                                       int agg, aqe_group_result* __restrict__ out) {
     const unsigned b = blockIdx.x * 64 + threadIdx.x;
     if (b >= nbins) return;
-    double n = 0.0, sd = 0.0, qd = 0.0, visited = 0.0;
-    for (unsigned w = 0; w < nblocks; ++w) {
-        const double* p = partial + (static_cast<size_t>(w) * nbins + b) * 4;
-        n += p[0]; sd += p[1]; qd += p[2]; visited += p[3];
-    }
+    const double n = bins[b * 4 + 0], sd = bins[b * 4 + 1], qd = bins[b * 4 + 2], visited = bins[b * 4 + 3];
     aqe_group_result r;
     r.key = static_cast<int64_t>(key_min) + b;
     r.n = static_cast<uint64_t>(n);
@@ -214,9 +220,14 @@ hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t*
     return hipGetLastError();
 }
 
-hipError_t launch_grouped_finish(const double* partial, unsigned nblocks, uint32_t nbins, int32_t key_min, double shift, double pct, int agg,
-                                 aqe_group_result* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_grouped_finish, dim3((nbins + 63) / 64), dim3(64), 0, s, partial, nblocks, nbins, key_min, shift, pct, agg, out);
+hipError_t launch_grouped_sum(const double* partial, unsigned nblocks, uint32_t nbins, double* bins, hipStream_t s) {
+    hipLaunchKernelGGL(k_grouped_sum, dim3((nbins * 4 + 255) / 256), dim3(256), 0, s, partial, nblocks, nbins, bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_grouped_finish(const double* bins, uint32_t nbins, int32_t key_min, double shift, double pct, int agg, aqe_group_result* out,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(k_grouped_finish, dim3((nbins + 63) / 64), dim3(64), 0, s, bins, nbins, key_min, shift, pct, agg, out);
     return hipGetLastError();
 }
 

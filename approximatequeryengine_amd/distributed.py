@@ -186,11 +186,39 @@ class PipelinedBatches:
         return [r for b in self.batches for r in b.fetch()]
 
 
-def torch_all_reduce(group=None) -> Callable:
-    """SUM all-reduce through torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" on CPU)."""
+def sharded_group_by(engine, query, group_column: int, bins, all_reduce_sum: Callable, all_reduce_max: Callable, stream: int = 0):
+    """GROUP BY across the ranks of a process group (engine.Engine interface): the per-key bins (n, S - c n, Q,
+    visited) are additive, so every rank bins the part of the sample inside its shard over the same key range and
+    ONE all-reduce SUM merges them; the key range itself is agreed first (one MAX all-reduce of [-min, max]).
+
+    bins            float64 tensor on the engine's device with room for 4 * (number of distinct keys) doubles
+    all_reduce_max  callable(tensor) -> None, in-place MAX over the group (``torch_all_reduce(op="max")``)
+    stream          raw handle of the stream the collectives are issued on.  NOT 0: a null handle means "the
+                    engine's own stream" to the C ABI, which is not ordered against torch's default stream — run
+                    under ``with torch.cuda.stream(side)`` and pass ``side.cuda_stream``.
+    """
+    lo, hi = engine.group_key_range(group_column)
+    rng = bins.new_tensor([-float(lo), float(hi)])
+    all_reduce_max(rng)
+    kmin, kmax = -int(rng[0].item()), int(rng[1].item())
+    if kmax < kmin:
+        return []  # an empty table
+    nbins = kmax - kmin + 1
+    if bins.numel() < 4 * nbins:
+        raise ValueError(f"bin buffer holds {bins.numel()} doubles, {4 * nbins} needed")
+    b = bins[: 4 * nbins]
+    engine.grouped_enqueue_bins(query, group_column, kmin, nbins, b.data_ptr(), stream)
+    all_reduce_sum(b)
+    return engine.grouped_finish(query, kmin, nbins, b.data_ptr(), stream)
+
+
+def torch_all_reduce(group=None, op: str = "sum") -> Callable:
+    """In-place all-reduce (SUM, or MAX with op="max") through torch.distributed (backend "nccl" is RCCL on ROCm;
+    "gloo" on CPU)."""
     import torch.distributed as dist
+    red = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op]
 
     def _ar(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(t, op=red, group=group)
 
     return _ar

@@ -225,6 +225,23 @@ class Engine:
         self._chk(nat.lib().aqe_reduce_grouped(self._h, C.byref(query), int(group_column), out, max_groups, C.byref(n)))
         return list(out[: n.value])
 
+    # multi-GPU form of reduce_grouped: key range -> (all-reduce MIN/MAX) -> bins -> (all-reduce SUM) -> finish
+    def group_key_range(self, group_column: int):
+        lo, hi = C.c_int32(), C.c_int32()
+        self._chk(nat.lib().aqe_group_key_range(self._h, int(group_column), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def grouped_enqueue_bins(self, query: Query, group_column: int, key_min: int, nbins: int, dev_bins_ptr: int, stream: int = 0):
+        self._chk(nat.lib().aqe_grouped_enqueue_bins(self._h, C.byref(query), int(group_column), int(key_min), int(nbins),
+                                                     C.c_void_p(dev_bins_ptr), C.c_void_p(stream)))
+
+    def grouped_finish(self, query: Query, key_min: int, nbins: int, dev_bins_ptr: int, stream: int = 0, max_groups: int = 1024):
+        out = (nat.GroupResult * max_groups)()
+        n = C.c_uint32()
+        self._chk(nat.lib().aqe_grouped_finish(self._h, C.byref(query), int(key_min), int(nbins), C.c_void_p(dev_bins_ptr),
+                                               C.c_void_p(stream), out, max_groups, C.byref(n)))
+        return list(out[: n.value])
+
     def gather(self, query: Query) -> np.ndarray:
         """Rows of the record-returning sampler, as a RECORD_DTYPE array."""
         n = C.c_uint64()

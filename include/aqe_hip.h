@@ -258,6 +258,20 @@ typedef struct aqe_group_result {
 } aqe_group_result;
 AQE_API int aqe_reduce_grouped(aqe_ctx* ctx, const aqe_query* q, int group_column, aqe_group_result* out, uint32_t cap,
                                uint32_t* n_groups);
+/* Multi-GPU form: the bins are additive, so every rank bins the part of the sample that falls in its shard over
+ * the SAME key range and one all-reduce SUM merges them:
+ *     aqe_group_key_range(ctx, column, &kmin, &kmax)        this shard's keys (empty shard: INT32_MAX, INT32_MIN);
+ *                                                            all-reduce MIN / MAX them, nbins = kmax - kmin + 1 <= 1024
+ *     aqe_grouped_enqueue_bins(ctx, q, column, kmin, nbins, dev_bins, stream)    nbins x 4 doubles per rank:
+ *                                                            {n, S - c n, Q (shifted), visited} per key
+ *     <all-reduce SUM of nbins * 4 doubles on `stream`>
+ *     aqe_grouped_finish(ctx, q, kmin, nbins, dev_bins, stream, out, cap, &n_groups)   synchronises `stream`
+ * aqe_reduce_grouped is exactly this with a world of one. */
+AQE_API int aqe_group_key_range(aqe_ctx* ctx, int group_column, int32_t* key_min, int32_t* key_max);
+AQE_API int aqe_grouped_enqueue_bins(aqe_ctx* ctx, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, double* dev_bins,
+                                     void* stream);
+AQE_API int aqe_grouped_finish(aqe_ctx* ctx, const aqe_query* q, int32_t key_min, uint32_t nbins, const double* dev_bins, void* stream,
+                               aqe_group_result* out, uint32_t cap, uint32_t* n_groups);
 
 /* ---- stepwise / multi-GPU form ----------------------------------------------------------------
  * One process per GPU; each rank plans the same query over its own shard.  Per round:
@@ -266,7 +280,8 @@ AQE_API int aqe_reduce_grouped(aqe_ctx* ctx, const aqe_query* q, int group_colum
  *     aqe_plan_enqueue_update(plan, r, dev_vec, stream)    fold + CLT rules + should_stop (on device)
  * then aqe_plan_enqueue_finalize and aqe_plan_fetch.  Every rank sees the same reduced vector, takes
  * the same stop decision, and a round enqueued after the stop is a device-side no-op.
- * `stream` is a hipStream_t passed as void* (NULL = the context's own stream). */
+ * `stream` is a hipStream_t passed as void* (NULL = the context's own stream, a non-blocking stream: it is NOT
+ * ordered against a framework's default/null stream — pass the explicit stream your collectives run on). */
 #define AQE_MOMENT_VEC 8 /* {n_a, S_a-c n_a, Q_a (shifted), n_b, S_b.., Q_b.., visited, 0} */
 AQE_API int aqe_plan_create(aqe_ctx* ctx, const aqe_query* q, aqe_plan** out);
 AQE_API void aqe_plan_destroy(aqe_plan* plan);

@@ -221,6 +221,10 @@ def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
         assert ei.value.status == nat.ERR_INVALID
     with pytest.raises(nat.AqeError):
         eng.reduce(make_query(nat.M_DUAL_POINTER, 0.02))
+    for bad in (dict(agg=7), dict(convention=-1), dict(where=(float("nan"), 1.0))):
+        with pytest.raises(nat.AqeError) as ei:
+            eng.reduce(make_query(nat.M_MEMORY_STRIDE, 1.0, **bad))
+        assert ei.value.status == nat.ERR_INVALID
 
 
 def test_conventions_and_where_composition(nat, oracle, table, engines):
@@ -717,3 +721,52 @@ def test_group_by_with_per_group_interval(nat, oracle, table):
                     assert (r.n, r.visited) == (c, vis[r.key])
                     assert abs(r.sum - s_) <= SUM_TOL * max(abs(s_), 1.0) and abs(r.sumsq - q_) <= SUM_TOL * max(abs(q_), 1.0)
                 assert sum(r.visited for r in got) == len(idx)
+
+
+def test_group_by_over_virtual_shards(nat, oracle, table):
+    """The multi-GPU form of GROUP BY on G shards of one GPU: agree the key range, bin per shard, add the bins
+    (stand-in for the all-reduce), finish — identical to the single-shard answer for G in {1, 2, 3, 8}."""
+    from approximatequeryengine_amd.distributed import sharded_group_by
+    from approximatequeryengine_amd.engine import Engine, make_query
+    import torch
+    n = 100_007
+    rows = table(n)
+    queries = [make_query(nat.M_ROWID_MOD, 3.0, agg=nat.AVG), make_query(nat.M_BLOCK, 10.0, agg=nat.SUM, where=(250.0, 750.0)),
+               make_query(nat.M_EXACT, 100.0, agg=nat.COUNT)]
+    with Engine(0) as whole:
+        whole.stage_records(rows, keep_aos=True)
+        refs = {(i, col): whole.reduce_grouped(q, col) for i, q in enumerate(queries) for col in (nat.GROUP_REGION, nat.GROUP_PRODUCT)}
+        # a world of one through the helper: identity collectives
+        bins = torch.zeros(4 * 1024, dtype=torch.float64, device="cuda")
+        got = sharded_group_by(whole, queries[0], nat.GROUP_PRODUCT, bins, lambda t: None, lambda t: None, torch.cuda.current_stream().cuda_stream)
+        # (counts exact; a group's floating-point sum depends on the order lanes reach the LDS bin: equal to rounding)
+        assert [(g_.key, g_.n) for g_ in got] == [(w.key, w.n) for w in refs[(0, nat.GROUP_PRODUCT)]]
+        assert all(rel(g_.sum, w.sum) <= 1e-13 for g_, w in zip(got, refs[(0, nat.GROUP_PRODUCT)]))
+    for G in (1, 2, 3, 8):
+        bounds = [(g * n) // G for g in range(G + 1)]
+        engs = []
+        for g in range(G):
+            e = Engine(0)
+            e.stage_records(rows[bounds[g]:bounds[g + 1]], shard_lo=bounds[g], n_global=n, keep_aos=True)
+            e.set_shift(float(rows["amount"][:1024].mean()))
+            engs.append(e)
+        side = torch.cuda.Stream()  # (a raw handle of 0 — torch's default stream — would mean "the context's own stream")
+        st = side.cuda_stream
+        for (i, col), want in refs.items():
+            ranges = [e.group_key_range(col) for e in engs]
+            kmin, kmax = min(r[0] for r in ranges), max(r[1] for r in ranges)
+            nbins = kmax - kmin + 1
+            with torch.cuda.stream(side):
+                per = torch.full((G, 4 * nbins), float("nan"), dtype=torch.float64, device="cuda")
+                for g, e in enumerate(engs):
+                    e.grouped_enqueue_bins(queries[i], col, kmin, nbins, per[g].data_ptr(), st)
+                total = per.sum(0)  # stand-in for the all-reduce, same stream => ordered
+            for e in engs:  # every rank finishes from the same reduced bins
+                got = e.grouped_finish(queries[i], kmin, nbins, total.data_ptr(), st)
+                assert [g_.key for g_ in got] == [w.key for w in want]
+                for g_, w in zip(got, want):
+                    assert (g_.n, g_.visited) == (w.n, w.visited)
+                    assert abs(g_.sum - w.sum) <= SUM_TOL * max(abs(w.sum), 1.0) and abs(g_.value - w.value) <= 1e-9 * max(abs(w.value), 1.0)
+                    assert abs(g_.ci_lower - w.ci_lower) <= 1e-8 * max(abs(w.ci_lower), 1.0)
+        for e in engs:
+            e.close()
