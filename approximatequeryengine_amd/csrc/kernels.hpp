@@ -134,8 +134,8 @@ struct PersistLaunch {
     uint32_t step_begin[kMaxPersistRounds + 1];
     uint32_t rounds;
     uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
-    uint32_t finalize_here;    // 1: the ending decider also writes the result (no top-up launch follows)
-    uint32_t totals_only;      // 1: no decisions in the kernel; every slot's total is written to out_totals
+    uint32_t finalize_here;    // 1: the monitor also writes the result when it ends the query (no top-up launch follows)
+    uint32_t totals_only;      // 1: no decisions in the kernel; the monitor writes every round's total to out_totals
     unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's
     PersistCtl* ctl;
     double* partials;          // [step_begin[rounds] + kDecSteps][8][kVec]  workgroup partials, flat
