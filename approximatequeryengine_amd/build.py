@@ -42,7 +42,7 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     LIB.parent.mkdir(parents=True, exist_ok=True)
     tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
     cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-function", "-fno-fast-math", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-function", "-fno-fast-math", "-ffp-contract=off", "-pthread",
            "-I", str(ROOT / "include"), "-o", str(tmp)] + [str(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
