@@ -47,7 +47,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_key_range(const int32_t* __re
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one pair of atomics per workgroup (a same-address device atomic costs ~20 ns and serialises)
+    __shared__ int wlo[kWavesPerBlock], whi[kWavesPerBlock];
+    if ((threadIdx.x & 63) == 0) { wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) { lo = wlo[w] < lo ? wlo[w] : lo; hi = whi[w] > hi ? whi[w] : hi; }
         atomicMin(&out[0], lo);
         atomicMax(&out[1], hi);
     }
@@ -146,13 +151,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
     for (unsigned i = threadIdx.x; i < a.nbins * 4; i += kBlockThreads) out[i] = bins[i];
 }
 
-// One thread per (bin, component): sum the workgroups' bins in workgroup order -> bins[nbins][4].
-__global__ __launch_bounds__(256) void k_grouped_sum(const double* __restrict__ partial, unsigned nblocks, unsigned nbins, double* __restrict__ bins) {
-    const unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nbins * 4) return;
+// One wave per (bin, component): lane l adds the workgroups l, l + 64, ... in order, then a fixed xor butterfly
+// adds the lanes -> bins[nbins][4].  (One thread per bin walking a thousand workgroups' partials one dependent
+// load after the other took 100 us; this takes a few.)
+__global__ __launch_bounds__(64) void k_grouped_sum(const double* __restrict__ partial, unsigned nblocks, unsigned nbins, double* __restrict__ bins) {
+    const unsigned i = blockIdx.x;  // (bin, component)
+    const unsigned lane = threadIdx.x;
     double t = 0.0;
-    for (unsigned w = 0; w < nblocks; ++w) t += partial[static_cast<size_t>(w) * nbins * 4 + i];
-    bins[i] = t;
+    for (unsigned w = lane; w < nblocks; w += 64) t += partial[static_cast<size_t>(w) * nbins * 4 + i];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) bins[i] = t;
 }
 
 // One thread per bin: estimate and interval of the group from its (all-reduced) sums.
@@ -207,7 +215,7 @@ hipError_t launch_synth_key(int32_t* out, uint64_t n, uint64_t first_row, int co
 
 hipError_t launch_key_range(const int32_t* keys, uint64_t n, int32_t* out2, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_key_range, dim3(blocks_for(n, kBlockThreads * 16, 1024)), dim3(kBlockThreads), 0, s, keys, static_cast<u64>(n), out2);
+    hipLaunchKernelGGL(k_key_range, dim3(blocks_for(n, kBlockThreads * 16, 512)), dim3(kBlockThreads), 0, s, keys, static_cast<u64>(n), out2);
     return hipGetLastError();
 }
 
@@ -221,7 +229,7 @@ hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t*
 }
 
 hipError_t launch_grouped_sum(const double* partial, unsigned nblocks, uint32_t nbins, double* bins, hipStream_t s) {
-    hipLaunchKernelGGL(k_grouped_sum, dim3((nbins * 4 + 255) / 256), dim3(256), 0, s, partial, nblocks, nbins, bins);
+    hipLaunchKernelGGL(k_grouped_sum, dim3(nbins * 4), dim3(64), 0, s, partial, nblocks, nbins, bins);
     return hipGetLastError();
 }
 
