@@ -128,10 +128,10 @@ struct FoldOut {
 // 8 j + c takes component c of the j-th slot of each step) and folded into the running per-lane sum `run`
 // (carried from fold to fold: the sum over every step since step 0); lane q picks the prefix total through
 // round q out of LDS, and every new round is judged at once, lane q evaluating round q's stop rule
-// (DB.cpp:936-961, 993-1016).  The next polls are in flight while the rounds are folded and judged: if they
-// show more rounds complete, those are folded straight away.  Returns (run, rounds judged) if the query goes on.  If it ends here
-// — a rule is satisfied, or the samples are exhausted — the monitor writes the state and the result, raises
-// should_stop and ENDS ITS WAVE inside this function.
+// (DB.cpp:936-961, 993-1016).  The next poll is in flight while the rounds are judged: if it shows more rounds
+// complete, those are folded straight away.  Returns (run, rounds judged) if the query goes on.  If it ends
+// here — a rule is satisfied, or the samples are exhausted — the monitor writes the state and the result,
+// raises should_stop and ENDS ITS WAVE inside this function.
 //
 // Inlined into monitor_main: as a called function it would save and restore callee-saved registers through
 // scratch — a memory round trip on the way out.
