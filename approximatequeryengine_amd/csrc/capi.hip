@@ -42,6 +42,7 @@ constexpr size_t kStageChunkRows = 1u << 21;  // 2 Mi rows: 64 MiB of AoS per pi
 }  // namespace
 
 constexpr size_t kBatchLanes = 3;  // side streams of the batched multi-GPU form (see ensure_lanes)
+constexpr size_t kGraphMinRounds = 4, kGraphMaxRounds = 8192;  // one-launch-per-round plans replayed as a HIP graph
 
 struct aqe_ctx {
     int device = 0;
@@ -124,6 +125,7 @@ struct aqe_plan {
     // slot written out — the multi-GPU form: ONE all-reduce of the slot totals, then k_replay decides.
     bool persist = false;
     SweepForm decide, totals;
+    hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
     bool profile = false;
@@ -194,6 +196,7 @@ void destroy_plan(aqe_plan* p) {
         if (f->d_ppart) (void)hipFree(f->d_ppart);
     }
     if (p->d_state) (void)hipFree(p->d_state);
+    if (p->round_graph) (void)hipGraphExecDestroy(p->round_graph);
     if (p->h_result) (void)hipHostFree(p->h_result);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -613,6 +616,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
     aqe_ctx* c = p->ctx;
     if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
     p->lev_used = 0;
+    bool topup_done = false;
     if (p->rounds.empty()) {  // nothing to sample (empty table / zero target): a zero state, finalized
         HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
         HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
@@ -620,13 +624,32 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
         if (p->persist) {
             int rc = launch_form(p, p->decide, false, nullptr, s);
             if (rc != AQE_OK) return rc;
+        } else if (p->rounds.size() >= kGraphMinRounds && p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH")) {
+            // One launch per round is a launch-bound loop (every launch after the stop is a device-side no-op): it is
+            // captured ONCE per plan into a HIP graph — the launches' arguments never change — and replayed.
+            if (!p->round_graph) {
+                hipGraph_t g = nullptr;
+                HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                int rc = AQE_OK;
+                for (uint32_t i = 0; i < p->rounds.size() && rc == AQE_OK; ++i) rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
+                if (rc == AQE_OK && p->host.has_topup)
+                    rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+                hipError_t e = hipStreamEndCapture(s, &g);  // always ends the capture, also after a failed launch
+                if (rc != AQE_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+                if (e == hipSuccess) e = hipGraphInstantiate(&p->round_graph, g, nullptr, nullptr, 0);
+                if (g) (void)hipGraphDestroy(g);
+                if (e != hipSuccess) { p->round_graph = nullptr; return fail(c, AQE_ERR_HIP, std::string("capturing the round launches: ") + hipGetErrorString(e)); }
+            }
+            p->last_exec = 0;
+            HIPCHK(c, hipGraphLaunch(p->round_graph, s));
+            topup_done = true;
         } else {
             for (uint32_t i = 0; i < p->rounds.size(); ++i) {
                 int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
                 if (rc != AQE_OK) return rc;
             }
         }
-        if (p->host.has_topup) {
+        if (p->host.has_topup && !topup_done) {
             int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
             if (rc != AQE_OK) return rc;
         }
