@@ -1533,6 +1533,45 @@ int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, 
 }
 
 // ---- one-call forms -----------------------------------------------------------------------------
+namespace {
+// Synchronous callers (aqe_reduce, aqe_gather).  A plan of very many rounds — the reference's own cadence, ten rows
+// per worker and round — would enqueue tens of thousands of launches of which all but the first few are device-side
+// no-ops once should_stop is set.  Here the host enqueues a chunk of rounds, looks at should_stop, and stops
+// launching when it is set.  (aqe_plan_enqueue_all stays fully asynchronous: it enqueues every round.)
+constexpr uint32_t kSyncChunkRounds = 256;
+
+int run_sync(aqe_plan* p, hipStream_t s, bool timed) {
+    aqe_ctx* c = p->ctx;
+    if (p->persist || p->rounds.size() <= kSyncChunkRounds) return enqueue_all(p, s, timed);
+    if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));
+    p->lev_used = 0;
+    p->last_exec = 0;
+    const uint32_t R = static_cast<uint32_t>(p->rounds.size());
+    for (uint32_t i = 0; i < R; i += kSyncChunkRounds) {
+        for (uint32_t j = i; j < std::min(R, i + kSyncChunkRounds); ++j) {
+            int rc = enqueue_launch(p, p->rounds[j], j, false, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
+        if (!p->host.is_clt) continue;
+        // (the result block is pinned host memory the caller has not been handed yet: borrow a word of it)
+        int32_t* peek = &p->h_result->device_status;
+        HIPCHK(c, hipMemcpyAsync(peek, &p->d_state->stop, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (*peek) break;  // every later round would leave at once: do not launch them
+    }
+    if (p->host.has_topup) {
+        int rc = enqueue_launch(p, p->topup, R, true, true, nullptr, s);
+        if (rc != AQE_OK) return rc;
+    } else {
+        // the last round of the plan carries the finalize; after an early break nobody has written the result
+        HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
+    }
+    if (timed) HIPCHK(c, hipEventRecord(p->ev1, s));
+    p->timed = timed;
+    return AQE_OK;
+}
+}  // namespace
+
 int aqe_reduce(aqe_ctx* c, const aqe_query* q, aqe_result* out) {
     if (!c || !q || !out) return AQE_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1541,7 +1580,7 @@ int aqe_reduce(aqe_ctx* c, const aqe_query* q, aqe_result* out) {
     aqe_plan* p = nullptr;
     int rc = cached_plan(c, q, &p);
     if (rc != AQE_OK) return rc;
-    rc = enqueue_all(p, c->stream, true);
+    rc = run_sync(p, c->stream, true);
     if (rc != AQE_OK) return rc;
     return fetch(p, out, c->stream);
 }
@@ -1561,7 +1600,7 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
     uint64_t topup_rows = 0;
     if (p->host.is_clt) {
         aqe_result r;
-        rc = enqueue_all(p, c->stream, false);
+        rc = run_sync(p, c->stream, false);
         if (rc == AQE_OK) rc = fetch(p, &r, c->stream);
         if (rc != AQE_OK) return rc;
         rounds_used = static_cast<uint32_t>(r.rounds);

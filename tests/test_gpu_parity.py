@@ -176,6 +176,8 @@ CLT_CASES = [
     (1_000_000, 10.0, 0.95, 10, 8, 0.3, 16, 2),    # 15 rounds, stops in the middle, rounds abandoned
     (1_000_000, 20.0, 0.95, 10, 5, 0.2, 100, 3),   # odd thread count: fast and slow regions differ (no pairs)
     (100_007, 20.0, 0.95, 10, 64, 1.0, 8, 2),      # 64 pointers
+    (1_000_000, 20.0, 0.95, 10, 4, 2.0, 10, 1),    # the reference's cadence and defaults: 5000 rounds planned, stops early
+    (200_000, 20.0, 0.95, 10, 4, 0.0, 10, 1),      # ... and never converging: 1000 rounds, launched chunk by chunk
 ]
 
 

@@ -6,7 +6,8 @@ from approximatequeryengine_amd.engine import Engine, make_query
 eng = Engine(0)
 for n, kw in ((1_000_000, dict(clt_round0=16, clt_growth=2, num_threads=8, max_error_percent=0.0)),
               (200_000, dict(max_error_percent=0.0)),            # the reference's cadence: check_interval = 10 per round
-              (10_000_000, dict(clt_round0=4096, clt_growth=4, max_error_percent=0.01))):
+              (10_000_000, dict(clt_round0=4096, clt_growth=4, max_error_percent=0.01)),
+              (10_000_000, dict(max_error_percent=2.0))):        # the mirror API's defaults on a big table: 100 000 rounds planned
     eng.generate_synthetic(n)
     q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, **kw)
     q.flags = nat.Q_NO_PERSIST
