@@ -397,6 +397,14 @@ class CustomBPlusDB:
 
     # ---- fused aggregate entry points (the point of the GPU path) ----
     def _clt_query(self, pct, conf, ci, T, e, round0, growth, agg):
+        # The reference checks every `check_interval` samples per worker (round0 = 0, growth = 1 reproduces that
+        # cadence round for round).  On a big table that is hundreds of thousands of decision points; past 4096 of
+        # them the cadence keeps its first check and doubles from there — it can only stop later than the reference
+        # would (same error test at the stop), and the planner's 2^20-round limit is never hit.
+        if int(round0) == 0 and int(growth) <= 1 and int(ci) > 0 and int(T) > 0:
+            per_worker = self._n * float(pct) / 100.0 / max(1, int(T) // 2)
+            if per_worker / int(ci) > 4096:
+                growth = 2
         return make_query(nat.M_CLT_DUAL_POINTER, pct, agg=agg, confidence_level=conf, check_interval=int(ci),
                           num_threads=int(T), max_error_percent=e, clt_round0=int(round0), clt_growth=int(growth))
 
