@@ -1,0 +1,169 @@
+// host.hpp — what the host-side translation units of libaqe_hip.so share: the context, the plan, and the internal
+// functions behind the C ABI of include/aqe_hip.h.  (table.hip: the table in HBM — staging, files, key columns;
+// plans.hip: planned queries — forms, launches, fetch, batches; capi.hip: the remaining entry points.)
+#pragma once
+
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.hpp"
+#include "planner.hpp"
+
+static_assert(sizeof(aqe_record) == 32, "row layout of DB.hpp:17-27");
+static_assert(sizeof(aqe::QueryState) % 8 == 0, "state is memset as a block");
+
+namespace aqe {
+
+struct LaunchDesc {
+    size_t fam_offset = 0;
+    uint32_t nfam = 0;
+    uint64_t ntiles = 0;
+    uint64_t samples = 0;  // ordinals in this launch's windows (upper bound for the top-up)
+};
+
+constexpr size_t kStageChunkRows = 1u << 21;  // 2 Mi rows: 64 MiB of AoS per pinned buffer
+constexpr size_t kBatchLanes = 3;  // side streams of the batched multi-GPU form (see ensure_lanes)
+constexpr size_t kGraphMinRounds = 4, kGraphMaxRounds = 8192;  // one-launch-per-round plans replayed as a HIP graph
+
+}  // namespace aqe
+
+struct aqe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // table (one shard)
+    double* amount = nullptr;
+    aqe_record* aos = nullptr;
+    bool owns_table = true;
+    bool staged = false;
+    // lazily built, per table: zone variances of adaptive_block_sample, amount-sorted column of stratified_block_sample
+    bool zone_var_valid = false;
+    double zone_var[10] = {0};
+    double* sorted_amount = nullptr;
+    uint32_t* sorted_row = nullptr;
+    // GROUP BY: key columns (SoA int32), extracted from the AoS rows or generated for a synthetic table on first use
+    int32_t* keycol[2] = {nullptr, nullptr};  // [AQE_GROUP_REGION - 1], [AQE_GROUP_PRODUCT - 1]
+    int32_t key_min[2] = {0, 0}, key_max[2] = {-1, -1};
+    bool synthetic = false;  // made by aqe_generate_synthetic: keys follow from the row number
+    std::vector<hipStream_t> lanes;         // side streams of the batched multi-GPU form (aqe_batch), made on first use
+    double* grp_partial = nullptr;          // GROUP BY scratch, grown on demand and kept with the context
+    size_t grp_partial_bytes = 0;
+    aqe_group_result* grp_out = nullptr;    // [aqe::kMaxGroupBins]
+    double* grp_bins = nullptr;             // [aqe::kMaxGroupBins][4] (single-GPU form)
+    bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
+    int64_t first_id = 0;
+    bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
+    uint64_t n_global = 0, shard_lo = 0, n_local = 0;
+    double shift = 0.0;
+    uint64_t hbm_bytes = 0;
+    uint64_t table_epoch = 0;
+    // persistent sweep (persist.hip): fixed grid of one 16-wave workgroup per CU (power of two)
+    unsigned persist_grid = 0;
+    unsigned long long* d_stamps = nullptr;  // diagnostics (env AQE_PERSIST_STAMPS)
+    unsigned long long epoch = 1;
+    // prepared plans of aqe_reduce / aqe_gather, keyed by the query bytes
+    std::vector<std::pair<aqe_query, aqe_plan*>> cache;
+};
+
+// One persistent-sweep form of a plan's rounds (persist.hip): the tile list of all slots, who owns tiles
+// of which slot, and the workgroup-partial buffer.
+struct SweepForm {
+    bool ok = false;
+    uint32_t slots = 0;       // rounds (+ the top-up as an extra slot in the totals form)
+    std::vector<aqe::DevFamily> h_fams;
+    aqe::DevFamily* d_fams = nullptr;
+    double* d_ppart = nullptr;  // flat workgroup partials: [step_begin[slots] + kDecSteps][8][aqe::kVec]
+    uint32_t step_begin[aqe::kMaxPersistRounds + 1] = {0};
+    uint64_t round_begin[aqe::kMaxPersistRounds + 1] = {0};
+    uint32_t round_mod[aqe::kMaxPersistRounds + 1] = {0};
+    uint32_t part_first[aqe::kMaxPersistRounds] = {0}, part_count[aqe::kMaxPersistRounds] = {0};
+    uint64_t ntiles = 0, samples = 0;
+};
+
+struct aqe_plan {
+    aqe_ctx* ctx = nullptr;
+    aqe_query q{};
+    aqe::HostPlan host;
+    uint64_t table_epoch = 0;
+    aqe::DevFamily* d_fams = nullptr;
+    std::vector<aqe::DevFamily> h_fams;
+    std::vector<aqe::LaunchDesc> rounds;
+    aqe::LaunchDesc topup;
+    uint64_t* d_idx = nullptr;
+    aqe::QueryState* d_state = nullptr;
+    // The result lives in pinned host memory mapped into the device: the kernel that finishes the query stores the
+    // 120 bytes across PCIe itself, and fetching is a stream synchronisation — no copy to enqueue.
+    aqe_result* h_result = nullptr;  // pinned, mapped
+    aqe_result* d_result = nullptr;  // the device's address of h_result
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // Scratch of the hand-off protocols.  It belongs to the plan, not the context, so several plans can be
+    // in flight on different streams of one GPU (the tail of one query overlaps the sweep of the next).
+    double* partials = nullptr;   // [kMaxBlocks][aqe::kVec]   k_round / k_indexed
+    unsigned* counter = nullptr;  // sharded tickets, zero between launches
+    aqe::PersistCtl* d_ctl = nullptr;  // persistent sweep: the stop word
+    void* d_rehearsal = nullptr;  // persistent sweep: target of the monitor's rehearsal stores
+    // Persistent single-launch forms (persist.hip).  `decide`: whole table on this GPU, decisions taken in the
+    // kernel (should_stop).  `totals`: any shard, every round plus the top-up swept speculatively, one total per
+    // slot written out — the multi-GPU form: ONE all-reduce of the slot totals, then k_replay decides.
+    bool persist = false;
+    SweepForm decide, totals;
+    hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
+    int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
+    // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
+    bool profile = false;
+    std::vector<hipEvent_t> lev;
+    uint32_t lev_used = 0;
+};
+
+namespace aqe {
+
+extern thread_local std::string g_create_error;  // aqe_create's failures have no context to carry the text
+
+int fail(aqe_ctx* c, int code, const std::string& msg);
+
+#define HIPCHK(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(ctx, AQE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+// table.hip
+void free_table(aqe_ctx* c);
+int alloc_table(aqe_ctx* c, uint64_t n_local, bool keep_aos);
+int ensure_keys(aqe_ctx* c, int column);
+int ensure_zone_variances(aqe_ctx* c);
+int ensure_sorted(aqe_ctx* c);
+
+// plans.hip
+void destroy_plan(aqe_plan* p);
+void drop_cache(aqe_ctx* c);
+SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam);
+FoldParams fold_params(const aqe_plan* p, bool topup);
+FinalizeParams finalize_params(const aqe_plan* p);
+int plan_is_current(aqe_plan* p);
+int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
+int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
+int enqueue_all(aqe_plan* p, hipStream_t s, bool timed);
+int run_sync(aqe_plan* p, hipStream_t s, bool timed);
+int fetch(aqe_plan* p, aqe_result* out, hipStream_t s);
+
+}  // namespace aqe

@@ -1,0 +1,773 @@
+// plans.hip — planned queries: families -> launch descriptors, the persistent-sweep forms, enqueue / fetch, the
+// stepwise and batched multi-GPU entry points, batches of plans.  Host code.
+#include "host.hpp"
+
+using namespace aqe;
+
+namespace aqe {
+
+void destroy_plan(aqe_plan* p) {
+    if (!p) return;
+    if (p->d_fams) (void)hipFree(p->d_fams);
+    if (p->d_idx) (void)hipFree(p->d_idx);
+    if (p->partials) (void)hipFree(p->partials);
+    if (p->counter) (void)hipFree(p->counter);
+    if (p->d_ctl) (void)hipFree(p->d_ctl);
+    if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
+    for (SweepForm* f : {&p->decide, &p->totals}) {
+        if (f->d_fams) (void)hipFree(f->d_fams);
+        if (f->d_ppart) (void)hipFree(f->d_ppart);
+    }
+    if (p->d_state) (void)hipFree(p->d_state);
+    if (p->round_graph) (void)hipGraphExecDestroy(p->round_graph);
+    if (p->h_result) (void)hipHostFree(p->h_result);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (auto e : p->lev) (void)hipEventDestroy(e);
+    delete p;
+}
+
+void drop_cache(aqe_ctx* c) {
+    for (auto& kv : c->cache) destroy_plan(kv.second);
+    c->cache.clear();
+}
+
+namespace {
+
+// Tile decomposition of one family window (kernels.hpp: one wave folds kTileOrdinals per tile).
+void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f, uint64_t& out_pos, bool dense16) {
+    if (f.ord_hi <= f.ord_lo) return;
+    DevFamily d{};
+    d.row0 = f.row0; d.pitch = f.pitch; d.seg_len = f.seg_len; d.step = f.step;
+    d.ord_lo = f.ord_lo; d.ord_hi = f.ord_hi; d.group = f.group; d.flags = f.flags;
+    uint64_t win_lo = f.ord_lo, win_hi = f.ord_hi;  // ordinals the tiles must cover
+    uint64_t size_b = 0;
+    if (f.flags & AQE_F_PAIR) {
+        d.row0_b = f.row0_b; d.ord_lo_b = f.ord_lo_b; d.ord_hi_b = f.ord_hi_b;
+        win_lo = std::min(win_lo, f.ord_lo_b);
+        win_hi = std::max(win_hi, f.ord_hi_b);
+        size_b = f.ord_hi_b - f.ord_lo_b;
+    }
+    const uint64_t tile = dense16 ? tile_ordinals(f.step, f.flags, f.seg_len) : kTileOrdinals;
+    const uint64_t s_lo = win_lo / f.seg_len, s_hi = (win_hi - 1) / f.seg_len;
+    uint64_t ntiles;
+    d.seg_lo = s_lo;
+    if (s_lo == s_hi) {
+        d.tiles_per_seg = 0;
+        d.j_lo = (win_lo % f.seg_len) / tile;
+        ntiles = ((win_hi - 1) % f.seg_len) / tile + 1 - d.j_lo;
+    } else {
+        d.tiles_per_seg = (f.seg_len + tile - 1) / tile;
+        d.j_lo = 0;
+        ntiles = (s_hi - s_lo + 1) * d.tiles_per_seg;
+    }
+    d.tile_begin = L.ntiles;
+    d.out_begin = out_pos;
+    out_pos += f.ord_hi - f.ord_lo;
+    d.out_begin_b = out_pos;
+    out_pos += size_b;
+    L.ntiles += ntiles;
+    L.nfam += 1;
+    L.samples += (f.ord_hi - f.ord_lo) + size_b;
+    out.push_back(d);
+}
+
+}  // namespace
+
+FoldParams fold_params(const aqe_plan* p, bool topup) {
+    FoldParams f{};
+    f.shift = p->ctx->shift;
+    f.z = p->host.clt.z;
+    f.e = p->host.clt.e;
+    f.base = p->host.clt.base;
+    f.is_clt = p->host.is_clt ? 1 : 0;
+    f.is_topup = topup ? 1 : 0;
+    return f;
+}
+
+FinalizeParams finalize_params(const aqe_plan* p) {
+    FinalizeParams f{};
+    f.n_global = p->q.row_hi > p->q.row_lo ? p->q.row_hi - p->q.row_lo : p->ctx->n_global;  // a row window is the table
+    f.pct = p->q.sample_percent;
+    f.shift = p->ctx->shift;
+    f.agg = p->q.agg;
+    f.convention = p->q.convention;
+    f.is_exact = p->q.method == AQE_M_EXACT;
+    f.is_clt = p->host.is_clt;
+    return f;
+}
+
+SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam) {
+    const aqe_ctx* c = p->ctx;
+    SweepCommon s{};
+    s.amount = p->host.on_sorted ? c->sorted_amount : c->amount;
+    s.shard_lo = c->shard_lo;
+    s.fams = fams;
+    s.nfam = nfam;
+    s.has_where = p->q.has_where ? 1 : 0;
+    s.wmin = p->q.where_min;
+    s.wmax = p->q.where_max;
+    s.shift = c->shift;
+    s.dense16 = c->dense16 ? 1 : 0;
+    return s;
+}
+
+namespace {
+
+// `index` is the launch's position in the query: rounds 0..R-1, then the top-up.  The first launch
+// folds into a zeroed state (no memset), later CLT launches test should_stop on entry, and in the fused
+// single-GPU form the last launch also writes the result.
+RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec) {
+    RoundLaunch a{};
+    a.sw = sweep_common(p, p->d_fams ? p->d_fams + L.fam_offset : nullptr, L.nfam);
+    a.ntiles = L.ntiles;
+    a.partials = p->partials;
+    a.counter = p->counter;
+    a.out_vec = out_vec;
+    a.state = p->d_state;
+    a.fused = fused ? 1 : 0;
+    a.check_stop = (p->host.is_clt && index > 0 && !topup) ? 1 : 0;
+    a.reset_state = (index == 0 && !topup) ? 1 : 0;
+    const uint32_t last = static_cast<uint32_t>(p->rounds.size()) - (p->host.has_topup ? 0u : 1u);
+    a.do_finalize = (fused && index == last) ? 1 : 0;
+    a.fold = fold_params(p, topup);
+    a.fin = finalize_params(p);
+    a.result = p->d_result;
+    return a;
+}
+
+}  // namespace
+
+int plan_is_current(aqe_plan* p) {
+    if (!p || !p->ctx) return AQE_ERR_INVALID;
+    if (p->table_epoch != p->ctx->table_epoch)
+        return fail(p->ctx, AQE_ERR_INVALID, "plan was created for a table that has since been replaced");
+    return AQE_OK;
+}
+
+namespace {
+
+hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStream_t>(stream) : p->ctx->stream; }
+
+int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    if (!topup && index == 0) p->last_exec = 0;
+    RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec);
+    const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
+    hipEvent_t e0 = prof ? p->lev[2 * p->lev_used] : nullptr, e1 = prof ? p->lev[2 * p->lev_used + 1] : nullptr;
+    if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s, e0, e1));
+    else HIPCHK(c, launch_round(a, s, e0, e1));
+    if (prof) p->lev_used++;
+    return AQE_OK;
+}
+
+// Lay the plan's rounds (optionally the top-up as one more slot) out as ONE tile list and work out which
+// workgroups own tiles of which slot.
+int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
+    aqe_ctx* c = p->ctx;
+    std::vector<const LaunchDesc*> slots;
+    for (const auto& L : p->rounds) slots.push_back(&L);
+    if (with_topup_slot && p->host.has_topup) slots.push_back(&p->topup);
+    const size_t S = slots.size();
+    uint64_t tiles = 0;
+    for (size_t r = 0; r < S; ++r) {
+        const LaunchDesc& L = *slots[r];
+        F.round_begin[r] = tiles;
+        for (uint32_t i = 0; i < L.nfam; ++i) {
+            DevFamily d = p->h_fams[L.fam_offset + i];
+            d.tile_begin += tiles;
+            d.flags &= ~AQE_F_TOPUP;  // swept whole: the replay decides whether the top-up counts
+            F.h_fams.push_back(d);
+        }
+        tiles += L.ntiles;
+        F.samples += L.samples;
+    }
+    F.round_begin[S] = tiles;
+    F.ntiles = tiles;
+    F.slots = static_cast<uint32_t>(S);
+    // Every wave but the monitor (wave 0 of workgroup 0) is a sweeper: sweeper v (physical wave v + 1) owns
+    // tiles v, v + V, ...  The workgroups that own tiles of a slot form ONE cyclic run of workgroup ids (tiles
+    // are consecutive, sweepers cyclic): find it by enumeration and insist on it — the monitor waits for
+    // exactly these workgroups.
+    const uint64_t G = c->persist_grid, V = G * kPersistWaves - 1;
+    auto sweeper_has = [&](uint64_t v, uint64_t b0, uint64_t b1) { const uint64_t m0 = b0 % V; return b0 + (v >= m0 ? v - m0 : v + V - m0) < b1; };
+    for (size_t r = 0; r < S; ++r) {
+        F.round_mod[r] = static_cast<uint32_t>(F.round_begin[r] % V);
+        std::vector<char> member(G, 0);
+        uint64_t members = 0;
+        for (uint64_t b = 0; b < G; ++b) {
+            for (uint64_t j = 0; j < kPersistWaves && !member[b]; ++j) {
+                const uint64_t phys = b * kPersistWaves + j;
+                if (phys != 0 && sweeper_has(phys - 1, F.round_begin[r], F.round_begin[r + 1])) member[b] = 1;
+            }
+            members += member[b];
+        }
+        uint64_t first = 0;
+        if (members != 0 && members != G) {
+            uint64_t starts = 0;
+            for (uint64_t b = 0; b < G; ++b)
+                if (member[b] && !member[(b + G - 1) % G]) { first = b; ++starts; }
+            if (starts != 1) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation is not one cyclic run");
+        }
+        for (uint64_t i = 0; i < members; ++i)
+            if (!member[(first + i) % G]) return fail(c, AQE_ERR_INVALID, "internal: persistent-sweep participation is not one cyclic run");
+        F.part_first[r] = static_cast<uint32_t>(first);
+        F.part_count[r] = static_cast<uint32_t>(members);
+        F.step_begin[r + 1] = F.step_begin[r] + static_cast<uint32_t>((members + 7) / 8);
+    }
+    F.round_mod[S] = static_cast<uint32_t>(F.round_begin[S] % V);
+    if (!F.h_fams.empty()) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_fams), F.h_fams.size() * sizeof(DevFamily)));
+        HIPCHK(c, hipMemcpy(F.d_fams, F.h_fams.data(), F.h_fams.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
+    }
+    // the monitor reads whole windows of kDecSteps steps: keep one window of slack behind the last slot.
+    // Pad slots (a round's run rounded up to 8) are never written: zero data, flag word "always published".
+    std::vector<uint64_t> init(static_cast<size_t>(kVec) * 8 * (static_cast<size_t>(F.step_begin[S]) + kDecSteps), 0);
+    for (size_t r = 0; r < S; ++r)
+        for (size_t slot = 8 * static_cast<size_t>(F.step_begin[r]) + F.part_count[r]; slot < 8 * static_cast<size_t>(F.step_begin[r + 1]); ++slot)
+            init[slot * kVec + 7] = kSlotAlways;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), init.size() * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    F.ok = true;
+    return AQE_OK;
+}
+
+}  // namespace
+
+int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    if (q->agg < AQE_SUM || q->agg > AQE_COUNT) return fail(c, AQE_ERR_INVALID, "agg must be AQE_SUM, AQE_AVG or AQE_COUNT");
+    if (q->convention < AQE_EST_CLI || q->convention > AQE_EST_RAW) return fail(c, AQE_ERR_INVALID, "convention must be AQE_EST_CLI, AQE_EST_CPP or AQE_EST_RAW");
+    if (q->has_where && (q->where_min != q->where_min || q->where_max != q->where_max)) return fail(c, AQE_ERR_INVALID, "WHERE bound is NaN");
+    std::unique_ptr<aqe_plan, void (*)(aqe_plan*)> p(new aqe_plan(), destroy_plan);
+    p->ctx = c;
+    p->q = *q;
+    p->table_epoch = c->table_epoch;
+    std::string err;
+    const double* zone_var = nullptr;
+    if (q->method == AQE_M_ADAPTIVE_BLOCK || q->method == AQE_M_STRATIFIED_BLOCK) {
+        if (c->shard_lo != 0 || c->n_local != c->n_global)
+            return fail(c, AQE_ERR_UNSUPPORTED, "adaptive/stratified block samplers need the whole table in this context (they need a global variance pass / sort)");
+        int rc0 = q->method == AQE_M_ADAPTIVE_BLOCK ? ensure_zone_variances(c) : ensure_sorted(c);
+        if (rc0 != AQE_OK) return rc0;
+        zone_var = q->method == AQE_M_ADAPTIVE_BLOCK ? c->zone_var : nullptr;
+    }
+    int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err, zone_var);
+    if (rc != AQE_OK) return fail(c, rc, err);
+    uint64_t out_pos = 0;
+    for (const auto& rf : p->host.round_fams) {
+        LaunchDesc L;
+        L.fam_offset = p->h_fams.size();
+        for (const auto& f : rf) add_family(p->h_fams, L, f, out_pos, c->dense16);
+        p->rounds.push_back(L);
+    }
+    if (p->host.is_random) {
+        LaunchDesc L;
+        L.samples = p->host.random_idx.size();
+        p->rounds.assign(1, L);
+    }
+    if (p->host.has_topup) {
+        p->topup.fam_offset = p->h_fams.size();
+        for (const auto& f : p->host.topup_fams) add_family(p->h_fams, p->topup, f, out_pos, c->dense16);
+    }
+    if (!p->h_fams.empty()) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams), p->h_fams.size() * sizeof(DevFamily)));
+        HIPCHK(c, hipMemcpy(p->d_fams, p->h_fams.data(), p->h_fams.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
+    }
+    if (!p->host.random_idx.empty()) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_idx), p->host.random_idx.size() * sizeof(uint64_t)));
+        HIPCHK(c, hipMemcpy(p->d_idx, p->host.random_idx.data(), p->host.random_idx.size() * sizeof(uint64_t),
+                            hipMemcpyHostToDevice));
+    }
+    {   // persistent single-launch forms of the rounds
+        const size_t R = p->rounds.size();
+        const bool multi = !p->host.is_random && R >= 2 && c->persist_grid > 0;
+        const bool whole = c->shard_lo == 0 && c->n_local == c->n_global;
+        bool every_round_has_tiles = true;
+        for (size_t r = 0; r < R; ++r) every_round_has_tiles = every_round_has_tiles && p->rounds[r].ntiles > 0;
+        if (multi && whole && every_round_has_tiles && R <= static_cast<size_t>(kMaxPersistRounds) && !(q->flags & AQE_Q_NO_PERSIST)) {
+            int rc2 = build_sweep_form(p.get(), false, p->decide);
+            if (rc2 != AQE_OK) return rc2;
+            p->persist = true;
+        }
+        if (multi && R <= static_cast<size_t>(kMaxPersistRounds)) {
+            int rc2 = build_sweep_form(p.get(), false, p->totals);
+            if (rc2 != AQE_OK) return rc2;
+        }
+        if (p->decide.ok || p->totals.ok) {
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
+            HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
+            HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
+        }
+    }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
+    HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
+    HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
+    HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), sizeof(aqe_result), hipHostMallocMapped));
+    std::memset(p->h_result, 0, sizeof(aqe_result));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
+    HIPCHK(c, hipEventCreate(&p->ev0));
+    HIPCHK(c, hipEventCreate(&p->ev1));
+    *out = p.release();
+    return AQE_OK;
+}
+
+int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
+    for (auto& kv : c->cache)
+        if (std::memcmp(&kv.first, q, sizeof(aqe_query)) == 0) { *out = kv.second; return AQE_OK; }
+    aqe_plan* p = nullptr;
+    int rc = create_plan(c, q, &p);
+    if (rc != AQE_OK) return rc;
+    if (c->cache.size() >= 64) { destroy_plan(c->cache.front().second); c->cache.erase(c->cache.begin()); }
+    c->cache.emplace_back(*q, p);
+    *out = p;
+    return AQE_OK;
+}
+
+namespace {
+
+int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_totals, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    PersistLaunch a{};
+    a.sw = sweep_common(p, F.d_fams, static_cast<uint32_t>(F.h_fams.size()));
+    a.ntiles = F.ntiles;
+    for (uint32_t r = 0; r <= F.slots; ++r) a.round_begin[r] = F.round_begin[r];
+    for (uint32_t r = 0; r < F.slots; ++r) { a.part_first[r] = F.part_first[r]; a.part_count[r] = F.part_count[r]; }
+    for (uint32_t r = 0; r <= F.slots; ++r) { a.step_begin[r] = F.step_begin[r]; a.round_mod[r] = F.round_mod[r]; }
+    a.rounds = F.slots;
+    a.epoch = c->epoch++;
+    a.ctl = p->d_ctl;
+    a.partials = F.d_ppart;
+    a.state = p->d_state;
+    a.fold = fold_params(p, false);
+    a.fin = finalize_params(p);
+    a.result = p->d_result;
+    a.rehearsal_state = static_cast<QueryState*>(p->d_rehearsal);
+    a.rehearsal_result = reinterpret_cast<aqe_result*>(static_cast<char*>(p->d_rehearsal) + sizeof(QueryState));
+    a.stamps = c->d_stamps;
+    a.finalize_here = p->host.has_topup ? 0u : 1u;
+    a.totals_only = totals_only ? 1u : 0u;
+    p->last_exec = totals_only ? 2 : 1;
+    a.out_totals = out_totals;
+    a.inline_fams = F.h_fams.size() <= static_cast<size_t>(kPersistInlineFams) ? 1u : 0u;
+    if (a.inline_fams) std::copy(F.h_fams.begin(), F.h_fams.end(), a.fams);
+    if (c->d_stamps) {
+        HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds), s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
+    HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
+    if (prof) p->lev_used++;
+    return AQE_OK;
+}
+
+}  // namespace
+
+int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
+    aqe_ctx* c = p->ctx;
+    if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
+    p->lev_used = 0;
+    bool topup_done = false;
+    if (p->rounds.empty()) {  // nothing to sample (empty table / zero target): a zero state, finalized
+        HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
+        HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
+    } else {
+        if (p->persist) {
+            int rc = launch_form(p, p->decide, false, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        } else if (p->rounds.size() >= kGraphMinRounds && p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH")) {
+            // One launch per round is a launch-bound loop (every launch after the stop is a device-side no-op): it is
+            // captured ONCE per plan into a HIP graph — the launches' arguments never change — and replayed.
+            if (!p->round_graph) {
+                hipGraph_t g = nullptr;
+                HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                int rc = AQE_OK;
+                for (uint32_t i = 0; i < p->rounds.size() && rc == AQE_OK; ++i) rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
+                if (rc == AQE_OK && p->host.has_topup)
+                    rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+                hipError_t e = hipStreamEndCapture(s, &g);  // always ends the capture, also after a failed launch
+                if (rc != AQE_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+                if (e == hipSuccess) e = hipGraphInstantiate(&p->round_graph, g, nullptr, nullptr, 0);
+                if (g) (void)hipGraphDestroy(g);
+                if (e != hipSuccess) { p->round_graph = nullptr; return fail(c, AQE_ERR_HIP, std::string("capturing the round launches: ") + hipGetErrorString(e)); }
+            }
+            p->last_exec = 0;
+            HIPCHK(c, hipGraphLaunch(p->round_graph, s));
+            topup_done = true;
+        } else {
+            for (uint32_t i = 0; i < p->rounds.size(); ++i) {
+                int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
+                if (rc != AQE_OK) return rc;
+            }
+        }
+        if (p->host.has_topup && !topup_done) {
+            int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
+    }
+    if (timed) HIPCHK(c, hipEventRecord(p->ev1, s));
+    p->timed = timed;
+    return AQE_OK;
+}
+
+int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    HIPCHK(c, hipStreamSynchronize(s));
+    *out = *p->h_result;
+    if (c->d_stamps && p->persist) {
+        const size_t W = static_cast<size_t>(c->persist_grid) * kPersistWaves;
+        std::vector<unsigned long long> st(8 * W + 8 * kMaxPersistRounds);
+        (void)hipMemcpy(st.data(), c->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = std::fopen(std::getenv("AQE_PERSIST_STAMPS"), "a")) {
+            unsigned long long t0 = ~0ull, s_hi = 0, f_lo = ~0ull, f_hi = 0, l_hi = 0, e_hi = 0, h_hi = 0, p_hi = 0, d_hi = 0;
+            for (size_t w = 0; w < W; ++w) {
+                const unsigned long long* q = &st[8 * w];
+                if (q[0]) { t0 = std::min(t0, q[0]); s_hi = std::max(s_hi, q[0]); }
+                if (q[1]) { f_lo = std::min(f_lo, q[1]); f_hi = std::max(f_hi, q[1]); }
+                l_hi = std::max(l_hi, q[2]);
+                e_hi = std::max(e_hi, q[3]);
+                h_hi = std::max(h_hi, q[4]);
+                p_hi = std::max(p_hi, q[5]);
+                d_hi = std::max(d_hi, q[6]);
+            }
+            auto us = [&](unsigned long long v) { return v == 0 || v == ~0ull ? -1.0 : (static_cast<double>(v) - static_cast<double>(t0)) / 100.0; };
+            std::fprintf(f, "starts ..%.2f first-tile %.2f..%.2f last-tile %.2f handed %.2f stored %.2f drained %.2f end %.2f |", us(s_hi), us(f_lo),
+                         us(f_hi), us(l_hi), us(h_hi), us(p_hi), us(d_hi), us(e_hi));
+            for (size_t r = 0; r < p->rounds.size(); ++r) {
+                const unsigned long long* q = &st[8 * W + 8 * r];
+                if (r == 0 && q[6]) std::fprintf(f, " rehearsal done %.2f |", us(q[6]));
+                if (q[3]) std::fprintf(f, " ..r%zu: seen %.2f folded %.2f judged %.2f |", r, us(q[3]), us(q[4]), us(q[5]));
+            }
+            std::fprintf(f, "\n");
+            std::fclose(f);
+        }
+    }
+    if (out->device_status != 0) {  // the monitor gave up waiting for a workgroup's partial
+        return fail(c, AQE_ERR_HIP, "device-side round protocol timed out");
+    }
+    if (p->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) out->kernel_ms = ms;
+    }
+    return AQE_OK;
+}
+
+// Synchronous callers (aqe_reduce, aqe_gather).  A plan of very many rounds — the reference's own cadence, ten rows
+// per worker and round — would enqueue tens of thousands of launches of which all but the first few are device-side
+// no-ops once should_stop is set.  Here the host enqueues a chunk of rounds, looks at should_stop, and stops
+// launching when it is set.  (aqe_plan_enqueue_all stays fully asynchronous: it enqueues every round.)
+constexpr uint32_t kSyncChunkRounds = 256;
+
+int run_sync(aqe_plan* p, hipStream_t s, bool timed) {
+    aqe_ctx* c = p->ctx;
+    if (p->persist || p->rounds.size() <= kSyncChunkRounds) return enqueue_all(p, s, timed);
+    if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));
+    p->lev_used = 0;
+    p->last_exec = 0;
+    const uint32_t R = static_cast<uint32_t>(p->rounds.size());
+    for (uint32_t i = 0; i < R; i += kSyncChunkRounds) {
+        for (uint32_t j = i; j < std::min(R, i + kSyncChunkRounds); ++j) {
+            int rc = enqueue_launch(p, p->rounds[j], j, false, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
+        if (!p->host.is_clt) continue;
+        // (the result block is pinned host memory the caller has not been handed yet: borrow a word of it)
+        int32_t* peek = &p->h_result->device_status;
+        HIPCHK(c, hipMemcpyAsync(peek, &p->d_state->stop, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (*peek) break;  // every later round would leave at once: do not launch them
+    }
+    if (p->host.has_topup) {
+        int rc = enqueue_launch(p, p->topup, R, true, true, nullptr, s);
+        if (rc != AQE_OK) return rc;
+    } else {
+        // the last round of the plan carries the finalize; after an early break nobody has written the result
+        HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
+    }
+    if (timed) HIPCHK(c, hipEventRecord(p->ev1, s));
+    p->timed = timed;
+    return AQE_OK;
+}
+
+namespace {
+
+// Side streams of the batched form, owned by the context and shared by its batches.  Three, not one per plan: the
+// runtime multiplexes streams onto a handful of hardware queues, and a stream that waits on an event blocks every
+// other stream sharing its queue.  Three lanes plus the caller's stream each get a queue of their own, and two
+// kernels in flight are already enough for one query's hand-off tail to overlap the next query's sweep.
+int ensure_lanes(aqe_ctx* c) {
+    while (c->lanes.size() < kBatchLanes) {
+        hipStream_t s = nullptr;
+        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        c->lanes.push_back(s);
+    }
+    return AQE_OK;
+}
+
+}  // namespace
+}  // namespace aqe
+
+struct aqe_batch {
+    aqe_ctx* ctx = nullptr;
+    std::vector<aqe_plan*> plans;   // plan i runs on lane i % kBatchLanes of the context
+    std::vector<hipEvent_t> swept;  // lane l's sweeps of this batch are enqueued up to here
+    hipEvent_t reduced = nullptr;   // the caller's stream up to (and including) the collective
+};
+
+extern "C" {
+
+// ---- plans --------------------------------------------------------------------------------------
+int aqe_plan_create(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
+    if (!c || !q || !out) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return create_plan(c, q, out);
+}
+
+void aqe_plan_destroy(aqe_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    destroy_plan(p);
+}
+
+int aqe_plan_rounds(const aqe_plan* p, uint32_t* rounds, int32_t* has_topup) {
+    if (!p) return AQE_ERR_INVALID;
+    if (rounds) *rounds = static_cast<uint32_t>(p->rounds.size());
+    if (has_topup) *has_topup = p->host.has_topup ? 1 : 0;
+    return AQE_OK;
+}
+
+int aqe_plan_reset(aqe_plan* p, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    hipStream_t s = pick(p, stream);
+    if (p->rounds.empty()) HIPCHK(p->ctx, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
+    p->timed = false;
+    p->lev_used = 0;
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_round(aqe_plan* p, uint32_t round, double* dev_vec, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!dev_vec) return fail(p->ctx, AQE_ERR_INVALID, "dev_vec is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    const bool topup = round == p->rounds.size() && p->host.has_topup;
+    if (!topup && round >= p->rounds.size()) return fail(p->ctx, AQE_ERR_INVALID, "round out of range");
+    return enqueue_launch(p, topup ? p->topup : p->rounds[round], round, topup, false, dev_vec, pick(p, stream));
+}
+
+int aqe_plan_enqueue_update(aqe_plan* p, uint32_t round, const double* dev_vec, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!dev_vec) return fail(p->ctx, AQE_ERR_INVALID, "dev_vec is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    const bool topup = round == p->rounds.size() && p->host.has_topup;
+    if (!topup && round >= p->rounds.size()) return fail(p->ctx, AQE_ERR_INVALID, "round out of range");
+    HIPCHK(p->ctx, launch_update(p->d_state, dev_vec, fold_params(p, topup), (round == 0 && !topup) ? 1 : 0, pick(p, stream)));
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_finalize(aqe_plan* p, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    HIPCHK(p->ctx, launch_finalize(p->d_state, finalize_params(p), p->d_result, pick(p, stream)));
+    return AQE_OK;
+}
+
+int aqe_plan_totals_len(const aqe_plan* p, uint32_t* n_doubles) {
+    if (!p || !n_doubles) return AQE_ERR_INVALID;
+    *n_doubles = p->totals.ok ? p->totals.slots * kVec : 0;
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_sweep_totals(aqe_plan* p, double* dev_totals, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!p->totals.ok) return fail(p->ctx, AQE_ERR_UNSUPPORTED, "this plan has no batched (totals) form; use the per-round calls");
+    if (!dev_totals) return fail(p->ctx, AQE_ERR_INVALID, "dev_totals is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    p->lev_used = 0;
+    return launch_form(p, p->totals, true, dev_totals, pick(p, stream));
+}
+
+int aqe_plan_enqueue_replay(aqe_plan* p, const double* dev_totals, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!p->totals.ok) return fail(p->ctx, AQE_ERR_UNSUPPORTED, "this plan has no batched (totals) form");
+    if (!dev_totals) return fail(p->ctx, AQE_ERR_INVALID, "dev_totals is null");
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    const uint32_t R = static_cast<uint32_t>(p->rounds.size());
+    HIPCHK(p->ctx, launch_replay(dev_totals, R, p->host.has_topup ? 1u : 0u, fold_params(p, false), finalize_params(p),
+                                 p->d_state, p->d_result, pick(p, stream)));
+    return AQE_OK;
+}
+
+void aqe_batch_destroy(aqe_batch* b) {
+    if (!b) return;
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        for (hipStream_t s : b->ctx->lanes) (void)hipStreamSynchronize(s);
+    }
+    for (hipEvent_t e : b->swept) (void)hipEventDestroy(e);
+    if (b->reduced) (void)hipEventDestroy(b->reduced);
+    delete b;
+}
+
+int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out) {
+    if (!plans || !out || n == 0) return AQE_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!plans[i] || !plans[i]->ctx || plans[i]->ctx != plans[0]->ctx) return AQE_ERR_INVALID;
+        if (!plans[i]->totals.ok) return fail(plans[i]->ctx, AQE_ERR_UNSUPPORTED, "a plan of the batch has no batched (totals) form");
+        for (uint32_t j = 0; j < i; ++j)
+            if (plans[j] == plans[i]) return fail(plans[i]->ctx, AQE_ERR_INVALID, "a plan may appear once in a batch (its hand-off scratch is its own)");
+    }
+    aqe_ctx* c = plans[0]->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_lanes(c);
+    if (rc != AQE_OK) return rc;
+    std::unique_ptr<aqe_batch, void (*)(aqe_batch*)> b(new aqe_batch, aqe_batch_destroy);
+    b->ctx = c;
+    b->plans.assign(plans, plans + n);
+    for (size_t l = 0; l < kBatchLanes; ++l) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->swept.push_back(e);
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&b->reduced, hipEventDisableTiming));
+    *out = b.release();
+    return AQE_OK;
+}
+
+int aqe_batch_enqueue_sweeps(aqe_batch* b, double* dev_totals, uint64_t row_stride) {
+    if (!b || !dev_totals) return AQE_ERR_INVALID;
+    aqe_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        aqe_plan* p = b->plans[i];
+        int rc = plan_is_current(p);
+        if (rc != AQE_OK) return rc;
+        if (row_stride < static_cast<uint64_t>(p->totals.slots) * kVec) return fail(c, AQE_ERR_INVALID, "row_stride shorter than a plan's totals");
+        p->lev_used = 0;
+        // (the plan's previous replay precedes this sweep in its lane: nothing to wait for)
+        rc = launch_form(p, p->totals, true, dev_totals + i * row_stride, c->lanes[i % kBatchLanes]);
+        if (rc != AQE_OK) return rc;
+    }
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipEventRecord(b->swept[l], c->lanes[l]));
+    return AQE_OK;
+}
+
+int aqe_batch_join(aqe_batch* b, void* stream) {
+    if (!b) return AQE_ERR_INVALID;
+    aqe_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(main_s, b->swept[l], 0));
+    return AQE_OK;
+}
+
+int aqe_batch_enqueue_replays(aqe_batch* b, const double* dev_totals, uint64_t row_stride, void* stream) {
+    if (!b || !dev_totals) return AQE_ERR_INVALID;
+    aqe_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    HIPCHK(c, hipEventRecord(b->reduced, main_s));
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->lanes[l], b->reduced, 0));  // every lane waits for the collective
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        aqe_plan* p = b->plans[i];
+        int rc = plan_is_current(p);
+        if (rc != AQE_OK) return rc;
+        HIPCHK(c, launch_replay(dev_totals + i * row_stride, static_cast<uint32_t>(p->rounds.size()), p->host.has_topup ? 1u : 0u,
+                                fold_params(p, false), finalize_params(p), p->d_state, p->d_result, c->lanes[i % kBatchLanes]));
+    }
+    return AQE_OK;
+}
+
+int aqe_batch_fetch(aqe_batch* b, aqe_result* out_n) {
+    if (!b || !out_n) return AQE_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        int rc = plan_is_current(b->plans[i]);
+        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, b->ctx->lanes[i % kBatchLanes]);
+        if (rc != AQE_OK) return rc;
+    }
+    return AQE_OK;
+}
+
+int aqe_plan_enqueue_all(aqe_plan* p, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    return enqueue_all(p, pick(p, stream), p->profile);
+}
+
+int aqe_plan_fetch(aqe_plan* p, aqe_result* out, void* stream) {
+    int rc = plan_is_current(p);
+    if (rc != AQE_OK) return rc;
+    if (!out) return AQE_ERR_INVALID;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    return fetch(p, out, pick(p, stream));
+}
+
+int aqe_plan_last_kernel_ms(aqe_plan* p, float* ms) {
+    if (!p || !ms) return AQE_ERR_INVALID;
+    if (!p->timed) return fail(p->ctx, AQE_ERR_INVALID, "no timed execution yet");
+    HIPCHK(p->ctx, hipEventSynchronize(p->ev1));
+    HIPCHK(p->ctx, hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return AQE_OK;
+}
+
+int aqe_plan_set_profiling(aqe_plan* p, int enable) {
+    if (!p) return AQE_ERR_INVALID;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    p->profile = enable != 0;
+    const size_t want = 2 * (p->rounds.size() + 2);
+    while (p->profile && p->lev.size() < want) {
+        hipEvent_t e;
+        HIPCHK(p->ctx, hipEventCreate(&e));
+        p->lev.push_back(e);
+    }
+    p->lev_used = 0;
+    return AQE_OK;
+}
+
+int aqe_plan_launch_ms(aqe_plan* p, float* ms, uint32_t cap, uint32_t* n_out) {
+    if (!p || !n_out) return AQE_ERR_INVALID;
+    HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+    *n_out = p->lev_used;
+    if (!ms) return AQE_OK;
+    if (cap < p->lev_used) return fail(p->ctx, AQE_ERR_CAPACITY, "launch_ms buffer too small");
+    for (uint32_t i = 0; i < p->lev_used; ++i) {
+        HIPCHK(p->ctx, hipEventSynchronize(p->lev[2 * i + 1]));
+        HIPCHK(p->ctx, hipEventElapsedTime(&ms[i], p->lev[2 * i], p->lev[2 * i + 1]));
+    }
+    return AQE_OK;
+}
+
+int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, uint32_t* n_out) {
+    if (!p || !n_out) return AQE_ERR_INVALID;
+    // reports the launches of the form the plan last executed with (or will: the fused path by default)
+    const int form = p->last_exec ? p->last_exec : (p->persist ? 1 : 0);
+    if (form == 2) {  // batched multi-GPU form: one launch sweeps every slot, top-up included
+        *n_out = 1;
+        if (!samples) return AQE_OK;
+        if (cap < 1) return AQE_ERR_CAPACITY;
+        samples[0] = p->totals.samples;
+        return AQE_OK;
+    }
+    const uint32_t sweeps = form == 1 ? 1u : static_cast<uint32_t>(p->rounds.size());
+    const uint32_t n = sweeps + (p->host.has_topup ? 1u : 0u);
+    *n_out = n;
+    if (!samples) return AQE_OK;
+    if (cap < n) return AQE_ERR_CAPACITY;
+    if (form == 1) samples[0] = p->decide.samples;
+    else for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
+    if (p->host.has_topup) samples[sweeps] = p->topup.samples;
+    return AQE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,487 @@
+// table.hip — the table in HBM: context lifecycle, staging from host rows and files, synthetic tables, the lazily
+// built side structures (key columns, zone variances, the amount-sorted column).  Host code; kernels are in kernels.hip,
+// grouped.hip and sort.hip.
+#include "host.hpp"
+
+using namespace aqe;
+
+namespace aqe {
+
+thread_local std::string g_create_error;
+
+int fail(aqe_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+// Shift c of the shifted moments: the mean of the table's first rows (up to 1024), so that one outlying
+// first row cannot push c outside the data's range.  Every shard of a table must use the same value.
+constexpr uint64_t kShiftRows = 1024;
+double shift_of_rows(const aqe_record* rows, uint64_t n) {
+    const uint64_t m = std::min<uint64_t>(n, kShiftRows);
+    double s = 0.0;
+    for (uint64_t i = 0; i < m; ++i) s += rows[i].amount;
+    return m ? s / static_cast<double>(m) : 0.0;
+}
+
+void free_table(aqe_ctx* c) {
+    if (c->owns_table) {
+        if (c->amount) (void)hipFree(c->amount);
+        if (c->aos) (void)hipFree(c->aos);
+    }
+    if (c->sorted_amount) (void)hipFree(c->sorted_amount);
+    if (c->sorted_row) (void)hipFree(c->sorted_row);
+    for (int k = 0; k < 2; ++k) {
+        if (c->keycol[k]) (void)hipFree(c->keycol[k]);
+        c->keycol[k] = nullptr;
+    }
+    c->synthetic = false;
+    c->sorted_amount = nullptr;
+    c->sorted_row = nullptr;
+    c->zone_var_valid = false;
+    c->amount = nullptr;
+    c->aos = nullptr;
+    c->owns_table = true;
+    c->staged = false;
+    c->ids_dense = false;
+    c->first_id = 0;
+    c->n_global = c->shard_lo = c->n_local = 0;
+    c->hbm_bytes = 0;
+    c->table_epoch++;
+}
+
+int alloc_table(aqe_ctx* c, uint64_t n_local, bool keep_aos) {
+    free_table(c);
+    drop_cache(c);
+    if (n_local == 0) return AQE_OK;
+    // one spare double behind the column: the 16-byte dense loads park masked lanes on rows 0..1
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->amount), (n_local + 1) * sizeof(double)));
+    c->hbm_bytes = (n_local + 1) * sizeof(double);
+    c->dense16 = true;
+    if (keep_aos) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->aos), n_local * sizeof(aqe_record)));
+        c->hbm_bytes += n_local * sizeof(aqe_record);
+    }
+    return AQE_OK;
+}
+
+// GROUP BY needs the key column as SoA int32 on the device: from the resident 32-byte rows, or — for a table made
+// by aqe_generate_synthetic — from the row number.  Built on first use, kept until the table changes.
+int ensure_keys(aqe_ctx* c, int column) {
+    const int k = column - 1;
+    if (c->keycol[k] || c->n_local == 0) return AQE_OK;
+    if (!c->aos && !c->synthetic)
+        return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction needs the key columns: stage the table with AQE_STAGE_KEEP_AOS");
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->keycol[k]), c->n_local * sizeof(int32_t)));
+    c->hbm_bytes += c->n_local * sizeof(int32_t);
+    if (c->aos) HIPCHK(c, launch_extract_key(c->aos, c->keycol[k], c->n_local, column, c->stream));
+    else HIPCHK(c, launch_synth_key(c->keycol[k], c->n_local, c->shard_lo, column, c->stream));
+    int32_t* d_range = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_range), 2 * sizeof(int32_t)));
+    int32_t init[2] = {std::numeric_limits<int32_t>::max(), std::numeric_limits<int32_t>::min()};
+    hipError_t e = hipMemcpyAsync(d_range, init, sizeof init, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_key_range(c->keycol[k], c->n_local, d_range, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(init, d_range, sizeof init, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_range);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("key range: ") + hipGetErrorString(e));
+    c->key_min[k] = init[0];
+    c->key_max[k] = init[1];
+    return AQE_OK;
+}
+
+// adaptive_block_sample's pre-pass (DB.cpp:1291-1308): population variance of each of the ten zones from raw
+// moments, var = Q/n - (S/n)^2 — ten exact window scans on the device, kept until the table changes.
+int ensure_zone_variances(aqe_ctx* c) {
+    if (c->zone_var_valid) return AQE_OK;
+    const uint64_t zone_size = c->n_global / 10;
+    if (zone_size == 0) return fail(c, AQE_ERR_INVALID, "adaptive_block_sample: needs at least 10 rows");
+    for (uint64_t z = 0; z < 10; ++z) {
+        aqe_query q;
+        aqe_query_defaults(&q);
+        q.method = AQE_M_EXACT;
+        q.sample_percent = 100.0;
+        q.row_lo = z * zone_size;
+        q.row_hi = std::min(q.row_lo + zone_size, c->n_global);
+        aqe_plan* p = nullptr;
+        aqe_result r;
+        int rc = cached_plan(c, &q, &p);
+        if (rc == AQE_OK) rc = enqueue_all(p, c->stream, false);
+        if (rc == AQE_OK) rc = fetch(p, &r, c->stream);
+        if (rc != AQE_OK) return rc;
+        const double cnt = static_cast<double>(q.row_hi - q.row_lo), mean = r.sum / cnt;
+        c->zone_var[z] = (r.sumsq / cnt) - (mean * mean);
+    }
+    c->zone_var_valid = true;
+    return AQE_OK;
+}
+
+// stratified_block_sample's pre-pass (DB.cpp:1342-1345): the amount column sorted ascending + its row permutation.
+int ensure_sorted(aqe_ctx* c) {
+    if (c->sorted_amount || c->n_local == 0) return AQE_OK;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->sorted_amount), (c->n_local + 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->sorted_row), c->n_local * sizeof(uint32_t)));
+    hipError_t e = sort_amounts(c->amount, c->n_local, c->sorted_amount, c->sorted_row, c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(c->sorted_amount); (void)hipFree(c->sorted_row);
+        c->sorted_amount = nullptr; c->sorted_row = nullptr;
+        return fail(c, AQE_ERR_HIP, std::string("sorting the amount column: ") + hipGetErrorString(e));
+    }
+    c->hbm_bytes += (c->n_local + 1) * sizeof(double) + c->n_local * sizeof(uint32_t);
+    return AQE_OK;
+}
+
+namespace {
+
+// Worker threads that fill the pinned bounce buffers: one host core reads rows at ~13 GB/s, a fifth of what the
+// PCIe link takes, so the fill of every chunk is split over the host's cores (the loader).
+class FillPool {
+  public:
+    explicit FillPool(unsigned n) {
+        for (unsigned i = 0; i < n; ++i)
+            workers_.emplace_back([this, i, n] {
+                unsigned seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    wake_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                    if (stop_) return;
+                    seen = gen_;
+                    lk.unlock();
+                    job_(i, n);
+                    lk.lock();
+                    if (--pending_ == 0) done_.notify_one();
+                }
+            });
+    }
+    ~FillPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        wake_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    // runs f(part, parts) on every worker and returns when all are done
+    void run(std::function<void(unsigned, unsigned)> f) {
+        std::unique_lock<std::mutex> lk(m_);
+        job_ = std::move(f);
+        pending_ = static_cast<unsigned>(workers_.size());
+        ++gen_;
+        wake_.notify_all();
+        done_.wait(lk, [&] { return pending_ == 0; });
+    }
+
+  private:
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    std::function<void(unsigned, unsigned)> job_;
+    unsigned gen_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64_t shard_lo, uint64_t n_global,
+                    uint32_t flags) {
+    if (shard_lo + n_local > n_global) return fail(c, AQE_ERR_INVALID, "shard exceeds the table");
+    if (n_local && !rows) return fail(c, AQE_ERR_INVALID, "null rows");
+    const bool keep = flags & AQE_STAGE_KEEP_AOS;
+    int rc = alloc_table(c, n_local, keep);
+    if (rc != AQE_OK) return rc;
+    c->n_global = n_global;
+    c->shard_lo = shard_lo;
+    c->n_local = n_local;
+    c->staged = true;
+    c->shift = shift_of_rows(rows, n_local);  // shards other than the first are given the table's value (aqe_set_shift)
+    if (n_local == 0) return AQE_OK;
+    // Double-buffered pinned bounce: the CPU fills buffer b while the DMA engine drains buffer b^1.
+    // Without KEEP_AOS only the amount column crosses PCIe (8 of every 32 bytes).
+    const size_t row_bytes = keep ? sizeof(aqe_record) : sizeof(double);
+    struct Bounce {  // two pinned buffers + their "drained" events, released on every exit path
+        void* pinned[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        ~Bounce() {
+            for (int b = 0; b < 2; ++b) {
+                if (pinned[b]) (void)hipHostFree(pinned[b]);
+                if (done[b]) (void)hipEventDestroy(done[b]);
+            }
+        }
+    } bounce;
+    void** pinned = bounce.pinned;
+    hipEvent_t* done = bounce.done;
+    for (int b = 0; b < 2; ++b) {
+        if (hipHostMalloc(&pinned[b], std::min<uint64_t>(kStageChunkRows, n_local) * row_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) {
+            free_table(c);
+            return fail(c, AQE_ERR_HIP, "staging: cannot allocate pinned bounce buffers");
+        }
+    }
+    int status = AQE_OK;
+    std::atomic<bool> dense_ids{true};
+    const int64_t id0 = rows[0].id;
+    const unsigned hw = std::thread::hardware_concurrency();
+    FillPool pool(n_local < (1u << 18) ? 1u : std::max(1u, std::min(16u, hw ? hw : 4u)));
+    for (uint64_t off = 0, k = 0; off < n_local && status == AQE_OK; off += kStageChunkRows, ++k) {
+        const int b = static_cast<int>(k & 1);
+        const uint64_t m = std::min<uint64_t>(kStageChunkRows, n_local - off);
+        if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) { status = fail(c, AQE_ERR_HIP, "event sync"); break; }
+        hipError_t e;
+        void* const dst_buf = pinned[b];
+        pool.run([&, dst_buf](unsigned part, unsigned parts) {  // rows [lo, hi) of the chunk: fill + dense-id check
+            const uint64_t lo = m * part / parts, hi = m * (part + 1) / parts;
+            bool dense = true;
+            for (uint64_t i = lo; i < hi; ++i) dense = dense && rows[off + i].id == id0 + static_cast<int64_t>(off + i);
+            if (!dense) dense_ids.store(false, std::memory_order_relaxed);
+            if (keep) {
+                std::memcpy(static_cast<aqe_record*>(dst_buf) + lo, rows + off + lo, (hi - lo) * sizeof(aqe_record));
+            } else {
+                double* dst = static_cast<double*>(dst_buf);
+                for (uint64_t i = lo; i < hi; ++i) dst[i] = rows[off + i].amount;
+            }
+        });
+        if (keep) {
+            e = hipMemcpyAsync(c->aos + off, pinned[b], m * sizeof(aqe_record), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_split_amount(c->aos + off, c->amount + off, m, c->stream);
+        } else {
+            e = hipMemcpyAsync(c->amount + off, pinned[b], m * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(done[b], c->stream);
+        if (e != hipSuccess) status = fail(c, AQE_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess && status == AQE_OK) status = fail(c, AQE_ERR_HIP, std::string("staging sync: ") + hipGetErrorString(e));
+    if (status != AQE_OK) { free_table(c); return status; }
+    c->ids_dense = dense_ids.load();
+    c->first_id = id0 - static_cast<int64_t>(shard_lo);  // id of global row 0 when the ids are dense
+    return status;
+}
+
+struct MappedFile {
+    void* base = MAP_FAILED;
+    size_t bytes = 0;
+    int fd = -1;
+    ~MappedFile() {
+        if (base != MAP_FAILED) munmap(base, bytes);
+        if (fd >= 0) close(fd);
+    }
+};
+
+int open_db_file(aqe_ctx* c, const char* path, MappedFile& mf, uint64_t& count) {
+    mf.fd = open(path, O_RDONLY);
+    if (mf.fd < 0) return fail(c, AQE_ERR_IO, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(mf.fd, &st) != 0 || st.st_size < 24) return fail(c, AQE_ERR_IO, std::string("not an aqe database file: ") + path);
+    mf.bytes = static_cast<size_t>(st.st_size);
+    mf.base = mmap(nullptr, mf.bytes, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+    if (mf.base == MAP_FAILED) return fail(c, AQE_ERR_IO, std::string("mmap failed: ") + path);
+    uint64_t hdr[3];  // size_t total | size_t height | size_t count, DB.cpp:669-676
+    std::memcpy(hdr, mf.base, sizeof hdr);
+    count = hdr[2];
+    if (24 + count * sizeof(aqe_record) > mf.bytes) return fail(c, AQE_ERR_IO, std::string("truncated database file: ") + path);
+    return AQE_OK;
+}
+
+}  // namespace
+}  // namespace aqe
+
+extern "C" {
+
+int aqe_create(int device_id, aqe_ctx** out) {
+    if (!out) return fail(nullptr, AQE_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, AQE_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, AQE_ERR_INVALID, "device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, AQE_ERR_NO_DEVICE, "cannot query device");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, AQE_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    std::unique_ptr<aqe_ctx> c(new aqe_ctx());
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(nullptr, AQE_ERR_HIP, "stream creation failed");
+    // one 16-wave workgroup per CU, rounded down to a power of two (the wave->tile map uses masks)
+    c->persist_grid = 16;
+    while (c->persist_grid * 2 <= static_cast<unsigned>(prop.multiProcessorCount) && c->persist_grid * 2 <= kMaxPersistGrid) c->persist_grid *= 2;
+    if (std::getenv("AQE_PERSIST_STAMPS") &&
+        hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds)) != hipSuccess)
+        return fail(nullptr, AQE_ERR_HIP, "stamp buffer allocation failed");
+    *out = c.release();
+    return AQE_OK;
+}
+
+void aqe_destroy(aqe_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_cache(c);
+    free_table(c);
+    if (c->d_stamps) (void)hipFree(c->d_stamps);
+    if (c->grp_partial) (void)hipFree(c->grp_partial);
+    if (c->grp_out) (void)hipFree(c->grp_out);
+    if (c->grp_bins) (void)hipFree(c->grp_bins);
+    for (hipStream_t s : c->lanes) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int aqe_stage_records(aqe_ctx* c, const void* aos32, uint64_t n_local, uint64_t shard_lo, uint64_t n_global, uint32_t flags) {
+    if (!c) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return stage_from_host(c, static_cast<const aqe_record*>(aos32), n_local, shard_lo, n_global, flags);
+}
+
+int aqe_file_rows(const char* path, uint64_t* n_rows) {
+    if (!path || !n_rows) return AQE_ERR_INVALID;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(nullptr, AQE_ERR_IO, std::string("cannot open ") + path);
+    uint64_t hdr[3];
+    size_t got = std::fread(hdr, sizeof hdr, 1, f);
+    std::fclose(f);
+    if (got != 1) return fail(nullptr, AQE_ERR_IO, std::string("not an aqe database file: ") + path);
+    *n_rows = hdr[2];
+    return AQE_OK;
+}
+
+int aqe_stage_file(aqe_ctx* c, const char* path, uint64_t shard_lo, uint64_t n_local, uint32_t flags) {
+    if (!c || !path) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    MappedFile mf;
+    uint64_t count = 0;
+    int rc = open_db_file(c, path, mf, count);
+    if (rc != AQE_OK) return rc;
+    if (shard_lo > count) return fail(c, AQE_ERR_INVALID, "shard_lo beyond the end of the file");
+    if (n_local == 0) n_local = count - shard_lo;
+    if (shard_lo + n_local > count) return fail(c, AQE_ERR_INVALID, "shard exceeds the file");
+    (void)madvise(mf.base, mf.bytes, MADV_SEQUENTIAL);
+    const aqe_record* rows = reinterpret_cast<const aqe_record*>(static_cast<const char*>(mf.base) + 24);
+    rc = stage_from_host(c, rows + shard_lo, n_local, shard_lo, count, flags);
+    if (rc == AQE_OK && count) c->shift = shift_of_rows(rows, count);  // from the table's head: identical on every shard
+    return rc;
+}
+
+int aqe_save_file(aqe_ctx* c, const char* path) {
+    if (!c || !path) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_local && !c->aos) return fail(c, AQE_ERR_UNSUPPORTED, "save needs the rows resident (AQE_STAGE_KEEP_AOS)");
+    if (c->shard_lo != 0 || c->n_local != c->n_global) return fail(c, AQE_ERR_UNSUPPORTED, "save needs the whole table in this context");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(c, AQE_ERR_IO, std::string("cannot create ") + path);
+    uint64_t height = 1;  // informational: the reference rebuilds its tree on load (DB.cpp:703-710)
+    for (uint64_t cap = 254; c->n_global > cap; cap *= 128) ++height;
+    uint64_t hdr[3] = {c->n_global, height, c->n_global};
+    bool ok = std::fwrite(hdr, sizeof hdr, 1, f) == 1;
+    std::vector<aqe_record> buf(std::min<uint64_t>(kStageChunkRows, std::max<uint64_t>(c->n_local, 1)));
+    for (uint64_t off = 0; ok && off < c->n_local; off += buf.size()) {
+        uint64_t m = std::min<uint64_t>(buf.size(), c->n_local - off);
+        if (hipMemcpy(buf.data(), c->aos + off, m * sizeof(aqe_record), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = std::fwrite(buf.data(), sizeof(aqe_record), m, f) == m;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? AQE_OK : fail(c, AQE_ERR_IO, std::string("write failed: ") + path);
+}
+
+int aqe_generate_synthetic(aqe_ctx* c, uint64_t n_local, uint64_t shard_lo, uint64_t n_global, uint64_t seed, uint32_t flags) {
+    if (!c) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (shard_lo + n_local > n_global) return fail(c, AQE_ERR_INVALID, "shard exceeds the table");
+    int rc = alloc_table(c, n_local, flags & AQE_STAGE_KEEP_AOS);
+    if (rc != AQE_OK) return rc;
+    c->n_global = n_global;
+    c->shard_lo = shard_lo;
+    c->n_local = n_local;
+    c->staged = true;
+    {   // shift from the table's first rows, evaluated with the expression the kernel uses (every shard agrees)
+        const uint64_t m = std::min<uint64_t>(n_global, kShiftRows);
+        double acc = 0.0;
+        for (uint64_t i = 0; i < m; ++i) {
+            uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            acc += 1.0 + 999.0 * (static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0));
+        }
+        c->shift = m ? acc / static_cast<double>(m) : 0.0;
+    }
+    c->ids_dense = true;  // id = row + 1
+    c->first_id = 1;
+    c->synthetic = true;
+    HIPCHK(c, launch_synth(c->aos, c->amount, n_local, shard_lo, seed, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AQE_OK;
+}
+
+int aqe_attach_device(aqe_ctx* c, const double* dev_amount, const void* dev_aos32, uint64_t n_local, uint64_t shard_lo,
+                      uint64_t n_global, double shift) {
+    if (!c) return AQE_ERR_INVALID;
+    if (n_local && !dev_amount) return fail(c, AQE_ERR_INVALID, "null amount column");
+    if (shard_lo + n_local > n_global) return fail(c, AQE_ERR_INVALID, "shard exceeds the table");
+    free_table(c);
+    drop_cache(c);
+    c->owns_table = false;
+    c->dense16 = n_local >= 2;  // caller-owned memory has no spare row
+    c->staged = true;
+    c->amount = const_cast<double*>(dev_amount);
+    c->aos = static_cast<aqe_record*>(const_cast<void*>(dev_aos32));
+    c->n_local = n_local;
+    c->shard_lo = shard_lo;
+    c->n_global = n_global;
+    c->shift = shift;
+    return AQE_OK;
+}
+
+int aqe_set_shift(aqe_ctx* c, double shift) {
+    if (!c) return AQE_ERR_INVALID;
+    c->shift = shift;
+    drop_cache(c);
+    return AQE_OK;
+}
+
+int aqe_table_info_get(const aqe_ctx* c, aqe_table_info* out) {
+    if (!c || !out) return AQE_ERR_INVALID;
+    out->global_rows = c->n_global;
+    out->shard_lo = c->shard_lo;
+    out->local_rows = c->n_local;
+    out->shift = c->shift;
+    out->has_aos = c->aos != nullptr;
+    out->device_id = c->device;
+    out->hbm_bytes = c->hbm_bytes;
+    return AQE_OK;
+}
+
+int aqe_key_range_rows(aqe_ctx* c, int64_t id_min, int64_t id_max, uint64_t* row_lo, uint64_t* row_hi) {
+    if (!c || !row_lo || !row_hi) return AQE_ERR_INVALID;
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    HIPCHK(c, hipSetDevice(c->device));
+    *row_lo = *row_hi = 0;
+    if (id_max < id_min || c->n_global == 0) return AQE_OK;
+    if (c->ids_dense) {  // id = first_id + row
+        const int64_t last = c->first_id + static_cast<int64_t>(c->n_global) - 1;
+        if (id_max < c->first_id || id_min > last) return AQE_OK;
+        *row_lo = static_cast<uint64_t>(std::max(id_min, c->first_id) - c->first_id);
+        *row_hi = static_cast<uint64_t>(std::min(id_max, last) - c->first_id) + 1;
+        return AQE_OK;
+    }
+    if (c->shard_lo != 0 || c->n_local != c->n_global) return fail(c, AQE_ERR_UNSUPPORTED, "key bounds on a shard need dense ids");
+    if (!c->aos) return fail(c, AQE_ERR_UNSUPPORTED, "key bounds on non-dense ids need the rows resident (AQE_STAGE_KEEP_AOS)");
+    uint64_t* d_out = nullptr;
+    uint64_t h_out[2] = {0, 0};
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof h_out));
+    hipError_t e = launch_id_bounds(c->aos, c->n_local, id_min, id_max, d_out, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("key bounds: ") + hipGetErrorString(e));
+    *row_lo = h_out[0];
+    *row_hi = std::max(h_out[0], h_out[1]);
+    return AQE_OK;
+}
+
+int aqe_release_table(aqe_ctx* c) {
+    if (!c) return AQE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drop_cache(c);
+    free_table(c);
+    return AQE_OK;
+}
+
+}  // extern "C"
