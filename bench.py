@@ -49,6 +49,7 @@ def parse():
                          "one overlaps the sweep of the next).  N GPUs: one all-reduce serves the whole batch "
                          "(aqe_batch: sweeps on the library's side streams, two host calls per step).")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the early-termination reading (profiling runs: one kind of sweep in the trace)")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     return ap.parse_args()
 
@@ -237,7 +238,7 @@ def main():
         #      converges after the first rounds, should_stop fires, and the reference's top-up (custom_bplus_db.cpp:
         #      1031-1040) supplies most of the sample: the early-termination path.  Reported beside the headline. ----
         other = None
-        if not use_dist and e == 0.01:
+        if not use_dist and e == 0.01 and not args.headline_only:
             e2 = 1.0
             q2 = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, confidence_level=0.95, check_interval=10, num_threads=4,
                             max_error_percent=e2, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
