@@ -126,6 +126,7 @@ struct aqe_plan {
     bool persist = false;
     SweepForm decide, totals;
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
+    bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
     bool profile = false;

@@ -134,7 +134,9 @@ struct PersistLaunch {
     uint32_t step_begin[kMaxPersistRounds + 1];
     uint32_t rounds;
     uint32_t inline_fams;      // 1: use `fams` below (kernel-argument copy of the table)
-    uint32_t finalize_here;    // 1: the monitor also writes the result when it ends the query (no top-up launch follows)
+    uint32_t finalize_here;    // 1: the monitor also writes the result when it ends the query
+    uint32_t topup_gate;       // 1: the plan has a top-up stage: mark the result topup_pending when it is due (DB.cpp:1032)
+    uint32_t pad0;
     uint32_t totals_only;      // 1: no decisions in the kernel; the monitor writes every round's total to out_totals
     unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's
     PersistCtl* ctl;

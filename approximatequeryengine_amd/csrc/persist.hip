@@ -210,7 +210,7 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
             FinalizeParams fin;
             fin.n_global = K->fin.n_global; fin.pct = K->fin.pct; fin.shift = K->fin.shift; fin.agg = K->fin.agg;
             fin.convention = K->fin.convention; fin.is_exact = K->fin.is_exact; fin.is_clt = K->fin.is_clt;
-            const bool with_result = K->finalize_here != 0;  // else the top-up launch that follows writes the result
+            const bool with_result = K->finalize_here != 0;
             QueryState st{};
             st.n_a = tot[0]; st.sd_a = tot[1]; st.qd_a = tot[2];
             st.n_b = tot[3]; st.sd_b = tot[4]; st.qd_b = tot[5];
@@ -236,6 +236,9 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
                     if (with_result && !result_now) res = make_result(st, fin);
                     res.rounds = st.rounds;
                     res.converged = code;
+                    // DB.cpp:1032: too few rows collected -> the top-up is due.  The launch that follows applies it
+                    // and clears the mark; when the host did not enqueue one (it is rarely due), it sees the mark.
+                    res.topup_pending = (K->topup_gate && st.n_p < static_cast<double>(fp.base / 4)) ? 1 : 0;
                     state_store(warm ? K->rehearsal_state : K->state, st);
                     if (with_result) *(warm ? K->rehearsal_result : K->result) = res;
                     if (code != 0 && !warm) {  // waves are still sweeping: state and result are out before should_stop is

@@ -348,7 +348,8 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     a.rehearsal_state = static_cast<QueryState*>(p->d_rehearsal);
     a.rehearsal_result = reinterpret_cast<aqe_result*>(static_cast<char*>(p->d_rehearsal) + sizeof(QueryState));
     a.stamps = c->d_stamps;
-    a.finalize_here = p->host.has_topup ? 0u : 1u;
+    a.finalize_here = 1u;
+    a.topup_gate = p->host.has_topup ? 1u : 0u;
     a.totals_only = totals_only ? 1u : 0u;
     p->last_exec = totals_only ? 2 : 1;
     a.out_totals = out_totals;
@@ -378,6 +379,10 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
         if (p->persist) {
             int rc = launch_form(p, p->decide, false, nullptr, s);
             if (rc != AQE_OK) return rc;
+            // The monitor has written the result.  The top-up (DB.cpp:1031-1040) is rarely due — only when the query
+            // stops with fewer than base/4 rows — so its launch is enqueued only for plans whose last execution
+            // needed it; otherwise the result carries topup_pending if it was due after all, and fetch() runs it.
+            topup_done = !p->expect_topup;
         } else if (p->rounds.size() >= kGraphMinRounds && p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH")) {
             // One launch per round is a launch-bound loop (every launch after the stop is a device-side no-op): it is
             // captured ONCE per plan into a HIP graph — the launches' arguments never change — and replayed.
@@ -416,6 +421,14 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
 int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     aqe_ctx* c = p->ctx;
     HIPCHK(c, hipStreamSynchronize(s));
+    if (p->last_exec == 1 && p->host.has_topup) {
+        if (p->h_result->topup_pending) {  // the top-up was due and its launch had not been enqueued: run it now
+            int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
+        p->expect_topup = p->h_result->topup > 0;  // the next execution enqueues the top-up launch up front, or not
+    }
     *out = *p->h_result;
     if (c->d_stamps && p->persist) {
         const size_t W = static_cast<size_t>(c->persist_grid) * kPersistWaves;
@@ -760,13 +773,14 @@ int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, 
         return AQE_OK;
     }
     const uint32_t sweeps = form == 1 ? 1u : static_cast<uint32_t>(p->rounds.size());
-    const uint32_t n = sweeps + (p->host.has_topup ? 1u : 0u);
+    const bool with_topup = p->host.has_topup && (form != 1 || p->expect_topup);  // the single-launch form enqueues it on demand
+    const uint32_t n = sweeps + (with_topup ? 1u : 0u);
     *n_out = n;
     if (!samples) return AQE_OK;
     if (cap < n) return AQE_ERR_CAPACITY;
     if (form == 1) samples[0] = p->decide.samples;
     else for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
-    if (p->host.has_topup) samples[sweeps] = p->topup.samples;
+    if (with_topup) samples[sweeps] = p->topup.samples;
     return AQE_OK;
 }
 

@@ -250,7 +250,9 @@ def main():
 
             for _ in range(3):
                 step2()
-            r2 = plans2[0].fetch(st)
+            # (fetching tells each plan that its top-up is due: from now on the launch is enqueued with the sweep)
+            r2 = [p.fetch(s_.cuda_stream) for p, s_ in zip(plans2, sides)][0]
+            step2()
             fence()
             k2 = max(10, min(100, args.steps))
             t2 = time.perf_counter()

@@ -324,7 +324,9 @@ AQE_API int aqe_batch_enqueue_sweeps(aqe_batch* batch, double* dev_totals, uint6
 AQE_API int aqe_batch_join(aqe_batch* batch, void* stream);
 AQE_API int aqe_batch_enqueue_replays(aqe_batch* batch, const double* dev_totals, uint64_t row_stride_doubles, void* stream);
 AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
-/* fused single-GPU form: round + update in one launch (the last workgroup to arrive folds) */
+/* fused single-GPU form: the whole query, asynchronously.  A multi-round (CLT) plan is ONE launch with in-kernel
+ * decisions; the reference's top-up (DB.cpp:1031-1040), rarely due, gets its own launch only when the plan's
+ * previous execution needed it — otherwise aqe_plan_fetch runs it if the result turns out to want it. */
 AQE_API int aqe_plan_enqueue_all(aqe_plan* plan, void* stream);
 AQE_API int aqe_plan_reset(aqe_plan* plan, void* stream); /* re-arm a plan for another execution */
 AQE_API int aqe_plan_fetch(aqe_plan* plan, aqe_result* out, void* stream); /* synchronises */
