@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -72,6 +73,7 @@ struct aqe_ctx {
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
     uint64_t n_global = 0, shard_lo = 0, n_local = 0;
     double shift = 0.0;
+    double head_cv = 0.0;  // coefficient of variation of the table's first rows (0: unknown): predicts where a CLT query stops
     uint64_t hbm_bytes = 0;
     uint64_t table_epoch = 0;
     // persistent sweep (persist.hip): fixed grid of one 16-wave workgroup per CU (power of two)
@@ -126,6 +128,7 @@ struct aqe_plan {
     bool persist = false;
     SweepForm decide, totals;
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
+    bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch

@@ -23,6 +23,23 @@ double shift_of_rows(const aqe_record* rows, uint64_t n) {
     for (uint64_t i = 0; i < m; ++i) s += rows[i].amount;
     return m ? s / static_cast<double>(m) : 0.0;
 }
+// Coefficient of variation of the same rows: a rough idea of how many samples a CLT query needs before its error
+// rule can hold, used only to choose between two equivalent launch forms (plans.hip create_plan).
+double cv_of_values(const double* x, uint64_t m) {
+    if (m < 2) return 0.0;
+    double mean = 0.0;
+    for (uint64_t i = 0; i < m; ++i) mean += x[i];
+    mean /= static_cast<double>(m);
+    double ss = 0.0;
+    for (uint64_t i = 0; i < m; ++i) ss += (x[i] - mean) * (x[i] - mean);
+    return mean != 0.0 ? std::sqrt(ss / static_cast<double>(m - 1)) / std::fabs(mean) : 0.0;
+}
+double cv_of_rows(const aqe_record* rows, uint64_t n) {
+    const uint64_t m = std::min<uint64_t>(n, kShiftRows);
+    std::vector<double> x(m);
+    for (uint64_t i = 0; i < m; ++i) x[i] = rows[i].amount;
+    return cv_of_values(x.data(), m);
+}
 
 void free_table(aqe_ctx* c) {
     if (c->owns_table) {
@@ -45,6 +62,7 @@ void free_table(aqe_ctx* c) {
     c->staged = false;
     c->ids_dense = false;
     c->first_id = 0;
+    c->head_cv = 0.0;
     c->n_global = c->shard_lo = c->n_local = 0;
     c->hbm_bytes = 0;
     c->table_epoch++;
@@ -189,6 +207,7 @@ int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64
     c->n_local = n_local;
     c->staged = true;
     c->shift = shift_of_rows(rows, n_local);  // shards other than the first are given the table's value (aqe_set_shift)
+    c->head_cv = cv_of_rows(rows, n_local);
     if (n_local == 0) return AQE_OK;
     // Double-buffered pinned bounce: the CPU fills buffer b while the DMA engine drains buffer b^1.
     // Without KEEP_AOS only the amount column crosses PCIe (8 of every 32 bytes).
@@ -354,7 +373,10 @@ int aqe_stage_file(aqe_ctx* c, const char* path, uint64_t shard_lo, uint64_t n_l
     (void)madvise(mf.base, mf.bytes, MADV_SEQUENTIAL);
     const aqe_record* rows = reinterpret_cast<const aqe_record*>(static_cast<const char*>(mf.base) + 24);
     rc = stage_from_host(c, rows + shard_lo, n_local, shard_lo, count, flags);
-    if (rc == AQE_OK && count) c->shift = shift_of_rows(rows, count);  // from the table's head: identical on every shard
+    if (rc == AQE_OK && count) {  // from the table's head: identical on every shard
+        c->shift = shift_of_rows(rows, count);
+        c->head_cv = cv_of_rows(rows, count);
+    }
     return rc;
 }
 
@@ -392,14 +414,17 @@ int aqe_generate_synthetic(aqe_ctx* c, uint64_t n_local, uint64_t shard_lo, uint
     {   // shift from the table's first rows, evaluated with the expression the kernel uses (every shard agrees)
         const uint64_t m = std::min<uint64_t>(n_global, kShiftRows);
         double acc = 0.0;
+        std::vector<double> head(m);
         for (uint64_t i = 0; i < m; ++i) {
             uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
             z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
             z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
             z ^= z >> 31;
-            acc += 1.0 + 999.0 * (static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0));
+            head[i] = 1.0 + 999.0 * (static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0));
+            acc += head[i];
         }
         c->shift = m ? acc / static_cast<double>(m) : 0.0;
+        c->head_cv = cv_of_values(head.data(), m);
     }
     c->ids_dense = true;  // id = row + 1
     c->first_id = 1;

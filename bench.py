@@ -271,8 +271,9 @@ def main():
                      "closed_loop_latency_us_p50": 1e6 * lat2[len(lat2) // 2],
                      "result": {"avg": r2.value, "ci": [r2.ci_lower, r2.ci_upper], "n": int(r2.n), "converged": int(r2.converged),
                                 "rounds": int(r2.rounds), "topup_rows": int(r2.topup)},
-                     "note": "should_stop raised by the in-kernel monitor after round(s) shown; the rest of the sample is the reference's top-up "
-                             "(a second, device-gated launch: every 20th row)"}
+                     "note": "launched round by round (the plan predicts an early stop from the table's head: cv and the error rule): "
+                             "should_stop is set on the device after the round(s) shown, the later rounds' launches are device-side "
+                             "no-ops, and the rest of the sample is the reference's top-up (a device-gated launch: every 20th row)"}
             for p in plans2:
                 p.close()
 

@@ -122,6 +122,8 @@ typedef struct aqe_query {
 
 #define AQE_Q_NO_TOPUP 1u   /* CLT: skip the systematic top-up of DB.cpp:1031-1040 */
 #define AQE_Q_NO_PERSIST 2u /* run every round as its own launch even on one GPU (same results) */
+#define AQE_Q_FORCE_PERSIST 4u /* take the single-launch form whenever the plan has one, also where the query is
+                                  predicted to stop early (by default such plans are launched round by round) */
 
 /* Everything a caller of the reference computes from a sample, produced on the device. */
 typedef struct aqe_result {

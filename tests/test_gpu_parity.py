@@ -190,10 +190,15 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     assert rc == 0
     q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=conf, check_interval=ci,
                    num_threads=T, max_error_percent=e, clt_round0=R0, clt_growth=g)
-    # the same query as one launch per round must agree with the single persistent launch
+    # the same query as one launch per round must agree with the single persistent launch, and with whichever
+    # of the two the library picks by itself (it predicts whether the query stops early)
     q.flags = nat.Q_NO_PERSIST
     multi = eng.reduce(q)
     q.flags = 0
+    auto = eng.reduce(q)
+    assert (auto.n, auto.visited, auto.converged, auto.rounds, auto.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
+    assert rel(auto.sum, multi.sum) <= 1e-14 and rel(auto.ci_lower, multi.ci_lower) <= 1e-13
+    q.flags = nat.Q_FORCE_PERSIST
     res = eng.reduce(q)
     # (different summation trees: integers and decisions identical, sums to rounding)
     assert (res.n, res.visited, res.converged, res.rounds, res.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
@@ -576,7 +581,7 @@ def test_full_size_properties(nat, oracle, n):
             q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=4096, clt_growth=4)
             q.flags = nat.Q_NO_PERSIST
             multi = eng.reduce(q)
-            q.flags = 0
+            q.flags = nat.Q_FORCE_PERSIST
             res = eng.reduce(q)
             assert (res.n, res.visited, res.converged, res.rounds, res.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
             assert rel(res.sum, multi.sum) <= 1e-13 and rel(res.sumsq, multi.sumsq) <= 1e-13 and rel(res.ci_lower, multi.ci_lower) <= 1e-12
