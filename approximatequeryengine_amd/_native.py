@@ -22,6 +22,7 @@ EST_CLI, EST_CPP, EST_RAW = 0, 1, 2
 Q_NO_TOPUP = 1
 Q_NO_PERSIST = 2
 Q_FORCE_PERSIST = 4
+Q_NO_LAYOUT = 8
 Q_FORCE_PERSIST = 4
 F_TOPUP = 1
 F_PAIR = 2

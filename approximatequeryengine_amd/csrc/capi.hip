@@ -237,7 +237,9 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
     if (c->shard_lo != 0 || c->n_local != c->n_global) return fail(c, AQE_ERR_UNSUPPORTED, "aqe_gather needs the whole table in this context");
     if (q->method == AQE_M_EXACT) return fail(c, AQE_ERR_UNSUPPORTED, "EXACT has no record-returning form");
     aqe_plan* p = nullptr;
-    int rc = cached_plan(c, q, &p);
+    aqe_query in_place = *q;
+    in_place.flags |= AQE_Q_NO_LAYOUT;  // records are gathered from the 32-byte rows: the families must address rows, not view slots
+    int rc = cached_plan(c, &in_place, &p);
     if (rc != AQE_OK) return rc;
     // which launches contributed: all of them, except that the CLT sampler stops at its converged round
     // and appends `topup` rows (DB.cpp:1031-1040) — both known only after running the reduction.

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -59,6 +60,8 @@ struct aqe_ctx {
     double zone_var[10] = {0};
     double* sorted_amount = nullptr;
     uint32_t* sorted_row = nullptr;
+    // stride-major views of the amount column, one per step a CLT plan has asked for (table.hip ensure_stride_view)
+    std::map<uint64_t, double*> stride_views;
     // GROUP BY: key columns (SoA int32), extracted from the AoS rows or generated for a synthetic table on first use
     int32_t* keycol[2] = {nullptr, nullptr};  // [AQE_GROUP_REGION - 1], [AQE_GROUP_PRODUCT - 1]
     int32_t key_min[2] = {0, 0}, key_max[2] = {-1, -1};
@@ -128,6 +131,8 @@ struct aqe_plan {
     bool persist = false;
     SweepForm decide, totals;
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
+    const double* view_rounds = nullptr;  // stride-major view the rounds' families index (nullptr: the column itself)
+    const double* view_topup = nullptr;   // ... and the top-up's
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
@@ -156,11 +161,14 @@ int alloc_table(aqe_ctx* c, uint64_t n_local, bool keep_aos);
 int ensure_keys(aqe_ctx* c, int column);
 int ensure_zone_variances(aqe_ctx* c);
 int ensure_sorted(aqe_ctx* c);
+// The stride-major view of step `step` (built on first use): rows r = row0 + k step are contiguous in it.
+// slot(r) = (r % step) * M + (r / step - q0); M and q0 come back with the pointer.
+int ensure_stride_view(aqe_ctx* c, uint64_t step, const double** view, uint64_t* M, uint64_t* q0);
 
 // plans.hip
 void destroy_plan(aqe_plan* p);
 void drop_cache(aqe_ctx* c);
-SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam);
+SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam, bool topup = false);
 FoldParams fold_params(const aqe_plan* p, bool topup);
 FinalizeParams finalize_params(const aqe_plan* p);
 int plan_is_current(aqe_plan* p);

@@ -321,6 +321,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_split_amount(const aqe_record
         amount[i] = src[2 * i].y;
 }
 
+// Stride-major view of the amount column for step s: row r (global) goes to slot (r % s) * M + (r / s - q0), so
+// that the progression row0, row0 + s, row0 + 2 s, ... of a strided pointer is CONTIGUOUS in the view.
+__global__ __launch_bounds__(kBlockThreads) void k_stride_view(const double* __restrict__ amount, u64 n, u64 shard_lo, u64 step, u64 M,
+                                                               u64 q0, double* __restrict__ out) {
+    for (u64 i = static_cast<u64>(blockIdx.x) * kBlockThreads + threadIdx.x; i < n; i += static_cast<u64>(gridDim.x) * kBlockThreads) {
+        const u64 r = shard_lo + i;
+        out[(r % step) * M + (r / step - q0)] = amount[i];
+    }
+}
+
 __device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 i) {
     u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -417,6 +427,14 @@ hipError_t launch_split_amount(const aqe_record* aos, double* amount, uint64_t n
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_split_amount, dim3(grid_for(n, kBlockThreads * 4)), dim3(kBlockThreads), 0, s, aos, amount,
                        static_cast<u64>(n));
+    return hipGetLastError();
+}
+
+hipError_t launch_stride_view(const double* amount, uint64_t n, uint64_t shard_lo, uint64_t step, uint64_t M, uint64_t q0, double* out,
+                              hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stride_view, dim3(grid_for(n, kBlockThreads * 4)), dim3(kBlockThreads), 0, s, amount, static_cast<u64>(n),
+                       static_cast<u64>(shard_lo), static_cast<u64>(step), static_cast<u64>(M), static_cast<u64>(q0), out);
     return hipGetLastError();
 }
 

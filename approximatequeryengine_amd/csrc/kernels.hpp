@@ -171,6 +171,8 @@ hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const
                                  aqe_record* out, hipStream_t s);
 
 hipError_t launch_id_bounds(const aqe_record* aos, uint64_t n, int64_t id_min, int64_t id_max, uint64_t* out, hipStream_t s);
+hipError_t launch_stride_view(const double* amount, uint64_t n, uint64_t shard_lo, uint64_t step, uint64_t M, uint64_t q0, double* out,
+                              hipStream_t s);
 hipError_t launch_split_amount(const aqe_record* aos, double* amount, uint64_t n, hipStream_t s);
 hipError_t launch_synth(aqe_record* aos_or_null, double* amount, uint64_t n, uint64_t first_row, uint64_t seed,
                         hipStream_t s);

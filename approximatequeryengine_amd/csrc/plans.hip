@@ -97,11 +97,12 @@ FinalizeParams finalize_params(const aqe_plan* p) {
     return f;
 }
 
-SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam) {
+SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam, bool topup) {
     const aqe_ctx* c = p->ctx;
     SweepCommon s{};
-    s.amount = p->host.on_sorted ? c->sorted_amount : c->amount;
-    s.shard_lo = c->shard_lo;
+    const double* view = topup ? p->view_topup : p->view_rounds;
+    s.amount = view ? view : (p->host.on_sorted ? c->sorted_amount : c->amount);
+    s.shard_lo = view ? 0 : c->shard_lo;  // a view's families carry slot numbers, not rows
     s.fams = fams;
     s.nfam = nfam;
     s.has_where = p->q.has_where ? 1 : 0;
@@ -119,7 +120,7 @@ namespace {
 // single-GPU form the last launch also writes the result.
 RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec) {
     RoundLaunch a{};
-    a.sw = sweep_common(p, p->d_fams ? p->d_fams + L.fam_offset : nullptr, L.nfam);
+    a.sw = sweep_common(p, p->d_fams ? p->d_fams + L.fam_offset : nullptr, L.nfam, topup);
     a.ntiles = L.ntiles;
     a.partials = p->partials;
     a.counter = p->counter;
@@ -234,6 +235,53 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
 
 }  // namespace
 
+namespace {
+
+constexpr uint64_t kViewMinSamples = 1u << 16;  // smaller sweeps are launch-bound: not worth a copy of the column
+constexpr uint64_t kViewMaxStep = 1024;
+
+// Rewrites a list of single-segment strided families of one common step into dense families over that step's
+// stride-major view (a PAIR family becomes two: its pointers have different residues, i.e. two streams).
+int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, const double** view) {
+    uint64_t step = 0, total = 0;
+    for (auto* L : lists)
+        for (const aqe_family& f : *L) {
+            if (f.pitch != 0 || f.step < 2 || f.step > kViewMaxStep || (step && f.step != step)) return AQE_OK;  // not this shape
+            step = f.step;
+            total += family_size(f);
+        }
+    if (!step || total < kViewMinSamples) return AQE_OK;
+    uint64_t M = 0, q0 = 0;
+    int rc = ensure_stride_view(c, step, view, &M, &q0);
+    if (rc != AQE_OK) return rc;
+    auto slot0 = [&](uint64_t row0) { return (row0 % step) * M + row0 / step - q0; };  // wraps below the shard: the ordinal window brings it back
+    for (auto* L : lists) {
+        std::vector<aqe_family> out;
+        for (const aqe_family& f : *L) {
+            aqe_family a = f;
+            a.flags &= ~AQE_F_PAIR;
+            a.step = 1;
+            a.row0 = slot0(f.row0);
+            a.seg_len = std::max<uint64_t>(f.seg_len, f.ord_hi);
+            a.row0_b = a.ord_lo_b = a.ord_hi_b = 0;
+            if (a.ord_hi > a.ord_lo) out.push_back(a);
+            if ((f.flags & AQE_F_PAIR) && f.ord_hi_b > f.ord_lo_b) {
+                aqe_family b = a;
+                b.group = 1;
+                b.row0 = slot0(f.row0_b);
+                b.ord_lo = f.ord_lo_b;
+                b.ord_hi = f.ord_hi_b;
+                b.seg_len = std::max<uint64_t>(f.seg_len, f.ord_hi_b);
+                out.push_back(b);
+            }
+        }
+        L->swap(out);
+    }
+    return AQE_OK;
+}
+
+}  // namespace
+
 int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
     if (q->agg < AQE_SUM || q->agg > AQE_COUNT) return fail(c, AQE_ERR_INVALID, "agg must be AQE_SUM, AQE_AVG or AQE_COUNT");
@@ -254,6 +302,14 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     }
     int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err, zone_var);
     if (rc != AQE_OK) return fail(c, rc, err);
+    if (p->host.is_clt && !(q->flags & AQE_Q_NO_LAYOUT) && c->n_local) {
+        // the rounds' pointers (one step) and the top-up (another) read stride-major views of the column: dense streams
+        std::vector<std::vector<aqe_family>*> rounds;
+        for (auto& rf : p->host.round_fams) rounds.push_back(&rf);
+        rc = families_to_view(c, rounds, &p->view_rounds);
+        if (rc == AQE_OK && p->host.has_topup) rc = families_to_view(c, {&p->host.topup_fams}, &p->view_topup);
+        if (rc != AQE_OK) return rc;
+    }
     uint64_t out_pos = 0;
     for (const auto& rf : p->host.round_fams) {
         LaunchDesc L;

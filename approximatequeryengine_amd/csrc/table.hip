@@ -52,6 +52,8 @@ void free_table(aqe_ctx* c) {
         if (c->keycol[k]) (void)hipFree(c->keycol[k]);
         c->keycol[k] = nullptr;
     }
+    for (auto& kv : c->stride_views) (void)hipFree(kv.second);
+    c->stride_views.clear();
     c->synthetic = false;
     c->sorted_amount = nullptr;
     c->sorted_row = nullptr;
@@ -146,6 +148,29 @@ int ensure_sorted(aqe_ctx* c) {
         return fail(c, AQE_ERR_HIP, std::string("sorting the amount column: ") + hipGetErrorString(e));
     }
     c->hbm_bytes += (c->n_local + 1) * sizeof(double) + c->n_local * sizeof(uint32_t);
+    return AQE_OK;
+}
+
+// A CLT pointer reads rows row0, row0 + s, row0 + 2 s, ...: in the column that is 8 bytes of every 8 s, and the
+// memory system moves whole lines (at s = 5, with the fast and the slow pointer, 40 % of every line is wanted and
+// 100 % is moved).  HBM capacity is the cheap resource on this part, so the column is kept a second time in
+// stride-major order per step in use: the same rows, now contiguous — a dense stream, traffic = the sampled bytes.
+int ensure_stride_view(aqe_ctx* c, uint64_t step, const double** view, uint64_t* M_out, uint64_t* q0_out) {
+    const uint64_t M = c->n_local / step + 2, q0 = c->shard_lo / step;
+    *M_out = M;
+    *q0_out = q0;
+    auto it = c->stride_views.find(step);
+    if (it != c->stride_views.end()) { *view = it->second; return AQE_OK; }
+    double* v = nullptr;
+    const size_t bytes = (static_cast<size_t>(step) * M + 2) * sizeof(double);  // + the spare rows the 16-byte loads park on
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&v), bytes));
+    hipError_t e = hipMemsetAsync(v, 0, bytes, c->stream);
+    if (e == hipSuccess) e = launch_stride_view(c->amount, c->n_local, c->shard_lo, step, M, q0, v, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(v); return fail(c, AQE_ERR_HIP, std::string("stride-major view: ") + hipGetErrorString(e)); }
+    c->stride_views[step] = v;
+    c->hbm_bytes += bytes;
+    *view = v;
     return AQE_OK;
 }
 

@@ -122,6 +122,9 @@ typedef struct aqe_query {
 
 #define AQE_Q_NO_TOPUP 1u   /* CLT: skip the systematic top-up of DB.cpp:1031-1040 */
 #define AQE_Q_NO_PERSIST 2u /* run every round as its own launch even on one GPU (same results) */
+#define AQE_Q_NO_LAYOUT 8u /* CLT: sweep the sampled rows where they lie in the column; by default the column is kept a
+                              second time in stride-major order per pointer step in use, where a pointer's rows are
+                              contiguous (same rows, same answer, a fraction of the memory traffic) */
 #define AQE_Q_FORCE_PERSIST 4u /* take the single-launch form whenever the plan has one, also where the query is
                                   predicted to stop early (by default such plans are launched round by round) */
 

@@ -441,13 +441,14 @@ def test_synthetic_generator_matches_oracle(nat, oracle):
         assert rel(r.value, math.fsum(rows["amount"])) <= SUM_TOL
 
 
-def test_sharded_plan_api_single_gpu_virtual_shards(nat, oracle, table):
+@pytest.mark.parametrize("n", [100_007, 1_000_003], ids=["100k", "1M"])
+def test_sharded_plan_api_single_gpu_virtual_shards(nat, oracle, table, n):
     """G virtual shards on one GPU through the stepwise API: per-round partial vectors summed on the host
-    stand in for the all-reduce; result identical to the single-shard query for G in {1,2,3,8}."""
+    stand in for the all-reduce; result identical to the single-shard query for G in {1,2,3,8}.
+    (At 1 M rows the CLT sweeps are large enough to read the shards' stride-major views of the column.)"""
     import ctypes as C
     from approximatequeryengine_amd.engine import Engine, make_query
     import torch
-    n = 100_007
     rows = table(n)
     queries = [
         make_query(nat.M_MEMORY_STRIDE, 1.0),
