@@ -144,7 +144,9 @@ int aqe_grouped_enqueue_bins(aqe_ctx* c, const aqe_query* q, int group_column, i
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     aqe_plan* p = nullptr;
-    rc = cached_plan(c, q, &p);
+    aqe_query in_place = *q;
+    in_place.flags |= AQE_Q_NO_LAYOUT;  // the key column is read beside the amounts: the families must address rows
+    rc = cached_plan(c, &in_place, &p);
     if (rc != AQE_OK) return rc;
     if (p->host.is_random || p->host.is_clt || p->host.on_sorted || p->rounds.size() > 1)
         return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction takes a single-round family sampler (exact, stride, rowid-mod, block, page, pointer, region ...)");

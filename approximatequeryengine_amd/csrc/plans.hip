@@ -254,6 +254,7 @@ int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, co
     uint64_t M = 0, q0 = 0;
     int rc = ensure_stride_view(c, step, view, &M, &q0);
     if (rc != AQE_OK) return rc;
+    if (!*view) return AQE_OK;  // the table holds its quota of views: this step stays in place
     auto slot0 = [&](uint64_t row0) { return (row0 % step) * M + row0 / step - q0; };  // wraps below the shard: the ordinal window brings it back
     for (auto* L : lists) {
         std::vector<aqe_family> out;
@@ -302,8 +303,9 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     }
     int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err, zone_var);
     if (rc != AQE_OK) return fail(c, rc, err);
-    if (p->host.is_clt && !(q->flags & AQE_Q_NO_LAYOUT) && c->n_local) {
-        // the rounds' pointers (one step) and the top-up (another) read stride-major views of the column: dense streams
+    if (!(q->flags & AQE_Q_NO_LAYOUT) && c->n_local && !p->host.is_random && !p->host.on_sorted) {
+        // strided pointers — a CLT query's rounds (one step) and its top-up (another), the strided samplers — read
+        // stride-major views of the column: dense streams
         std::vector<std::vector<aqe_family>*> rounds;
         for (auto& rf : p->host.round_fams) rounds.push_back(&rf);
         rc = families_to_view(c, rounds, &p->view_rounds);

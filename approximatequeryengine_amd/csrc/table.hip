@@ -161,6 +161,8 @@ int ensure_stride_view(aqe_ctx* c, uint64_t step, const double** view, uint64_t*
     *q0_out = q0;
     auto it = c->stride_views.find(step);
     if (it != c->stride_views.end()) { *view = it->second; return AQE_OK; }
+    *view = nullptr;
+    if (c->stride_views.size() >= kMaxStrideViews) return AQE_OK;  // enough copies of the column: this step is swept in place
     double* v = nullptr;
     const size_t bytes = (static_cast<size_t>(step) * M + 2) * sizeof(double);  // + the spare rows the 16-byte loads park on
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&v), bytes));
