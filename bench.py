@@ -329,8 +329,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": "profiles/round1_pmc_raw.json (rocprofv3 --pmc, bytes per launch)" if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms,
-                # what the memory system actually moved per launch, as a rate: the sampled rows are 40 % of every line
-                # they touch (rows 0 and 2 of every 5), so the algorithmic rate cannot exceed 0.4 x the line rate
+                # what the memory system actually moved per launch (PMC), as a rate, and the share of it that was sampled
+                # rows: ~1.0 with the stride-major views of the column (in place the sampled rows — 0 and 2 of every 5
+                # — are 40 % of every line touched, and the whole column passes)
                 "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
                 "line_utilisation": (bytes_per_launch / traffic) if traffic else None,
                 "launches_per_query": launches, "per_launch": per_launch,
