@@ -214,26 +214,6 @@ def main():
             lat.append(time.perf_counter() - t1)
         lat.sort()
 
-        for _ in range(max(args.warmup, 1)):
-            step()
-        batched_dist = use_dist and bool(plan.totals_len)
-        fetch_all = pipe.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
-        firsts = fetch_all()
-        first = firsts[0]
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt = time.perf_counter() - t0
-        lasts = fetch_all()
-        last = lasts[0]
-        assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-
         # ---- the other reading of "--e 0.01" (SURVEY §8d config 2): the FRACTION 0.01 = 1 percent.  That query
         #      converges after the first rounds, should_stop fires, and the reference's top-up (custom_bplus_db.cpp:
         #      1031-1040) supplies most of the sample: the early-termination path.  Reported beside the headline. ----
@@ -276,6 +256,26 @@ def main():
                              "no-ops, and the rest of the sample is the reference's top-up (a device-gated launch: every 20th row)"}
             for p in plans2:
                 p.close()
+
+        for _ in range(max(args.warmup, 1)):
+            step()
+        batched_dist = use_dist and bool(plan.totals_len)
+        fetch_all = pipe.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
+        firsts = fetch_all()
+        first = firsts[0]
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        lasts = fetch_all()
+        last = lasts[0]
+        assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
 
     # the separate top-up launch never fires in this workload: not a sweep (the batched form has no such launch)
     sweeps = len(samples) - (1 if (plan.has_topup and len(samples) > 1) else 0)
