@@ -23,6 +23,7 @@ Q_NO_TOPUP = 1
 Q_NO_PERSIST = 2
 Q_FORCE_PERSIST = 4
 Q_NO_LAYOUT = 8
+Q_SHARE_GPU = 16
 Q_FORCE_PERSIST = 4
 F_TOPUP = 1
 F_PAIR = 2

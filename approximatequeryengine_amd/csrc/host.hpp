@@ -134,6 +134,7 @@ struct aqe_plan {
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
     const double* view_rounds = nullptr;  // stride-major view the rounds' families index (nullptr: the column itself)
     const double* view_topup = nullptr;   // ... and the top-up's
+    unsigned grid = 0;          // workgroups of the persistent sweep for this plan (the context's, or half of it)
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals

@@ -190,7 +190,7 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
     // tiles v, v + V, ...  The workgroups that own tiles of a slot form ONE cyclic run of workgroup ids (tiles
     // are consecutive, sweepers cyclic): find it by enumeration and insist on it — the monitor waits for
     // exactly these workgroups.
-    const uint64_t G = c->persist_grid, V = G * kPersistWaves - 1;
+    const uint64_t G = p->grid, V = G * kPersistWaves - 1;
     auto sweeper_has = [&](uint64_t v, uint64_t b0, uint64_t b1) { const uint64_t m0 = b0 % V; return b0 + (v >= m0 ? v - m0 : v + V - m0) < b1; };
     for (size_t r = 0; r < S; ++r) {
         F.round_mod[r] = static_cast<uint32_t>(F.round_begin[r] % V);
@@ -339,7 +339,11 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     }
     {   // persistent single-launch forms of the rounds
         const size_t R = p->rounds.size();
-        const bool multi = !p->host.is_random && R >= 2 && c->persist_grid > 0;
+        // A query that will run beside others (AQE_Q_SHARE_GPU) takes half the compute units: two such launches then sit
+        // side by side on the chip and one's hand-off tail hides behind the other's sweep — 133 k against 107 k
+        // aggregates/s with 32 in flight — at the price of a longer launch when it runs alone (19.4 against 16.4 us).
+        p->grid = (q->flags & AQE_Q_SHARE_GPU) ? std::max(16u, c->persist_grid / 2) : c->persist_grid;
+        const bool multi = !p->host.is_random && R >= 2 && p->grid > 0;
         const bool whole = c->shard_lo == 0 && c->n_local == c->n_global;
         bool every_round_has_tiles = true;
         for (size_t r = 0; r < R; ++r) every_round_has_tiles = every_round_has_tiles && p->rounds[r].ntiles > 0;
@@ -432,7 +436,7 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
         HIPCHK(c, hipStreamSynchronize(s));
     }
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
-    HIPCHK(c, launch_sweep_persist(a, c->persist_grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
+    HIPCHK(c, launch_sweep_persist(a, p->grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
     if (prof) p->lev_used++;
     return AQE_OK;
 }
@@ -503,7 +507,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     }
     *out = *p->h_result;
     if (c->d_stamps && p->persist) {
-        const size_t W = static_cast<size_t>(c->persist_grid) * kPersistWaves;
+        const size_t W = static_cast<size_t>(p->grid) * kPersistWaves;
         std::vector<unsigned long long> st(8 * W + 8 * kMaxPersistRounds);
         (void)hipMemcpy(st.data(), c->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* f = std::fopen(std::getenv("AQE_PERSIST_STAMPS"), "a")) {

@@ -141,17 +141,22 @@ def main():
     # go into one [B, totals] buffer, ONE RCCL all-reduce per step, then k_replay decides each query; two such
     # batches alternate, software-pipelined, so that one step's collective runs under the next step's sweeps.
     B = max(1, args.batch)
-    plans = [eng.plan(q) for _ in range(B)]
+    # Queries that run beside others take half the compute units each (AQE_Q_SHARE_GPU): two launches then sit side by
+    # side on the chip.  The one-in-flight measurements (roofline, closed loop) use a plan of the same query without it.
+    q_batch = type(q).from_buffer_copy(q)
+    if B > 1:
+        q_batch.flags |= nat.Q_SHARE_GPU
+    plans = [eng.plan(q_batch) for _ in range(B)]
     pipe = None
     sides = [torch.cuda.Stream() for _ in range(1 if use_dist else B)]
-    plan, side = plans[0], sides[0]
+    plan, side = eng.plan(q), sides[0]
     st = side.cuda_stream
     n_streams = len(sides)
 
     with torch.cuda.stream(side):
         if use_dist:
             if plan.totals_len:
-                plans = plans + [eng.plan(q) for _ in range(B)]  # the second batch of the pipeline
+                plans = plans + [eng.plan(q_batch) for _ in range(B)]  # the second batch of the pipeline
                 natives, sbs = [], []
                 for half in (plans[:B], plans[B:]):
                     buf = torch.zeros(B, plan.totals_len, dtype=torch.float64, device="cuda")
@@ -205,6 +210,17 @@ def main():
             for i, ms in enumerate(plan.launch_ms()):
                 sum_ms[i] += ms
         plan.set_profiling(False)
+        shared_launch_us = None
+        if B > 1 and not use_dist:  # the same launch on half the compute units (the form the batch runs), alone
+            ps = plans[0]
+            ps.set_profiling(True)
+            acc = 0.0
+            for _ in range(prof_steps):
+                ps.enqueue_all(st)
+                torch.cuda.synchronize()
+                acc += ps.launch_ms()[0]
+            ps.set_profiling(False)
+            shared_launch_us = 1e3 * acc / prof_steps
         # closed-loop latency (enqueue + fetch per query)
         lat = []
         for _ in range(50):
@@ -222,6 +238,8 @@ def main():
             e2 = 1.0
             q2 = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, confidence_level=0.95, check_interval=10, num_threads=4,
                             max_error_percent=e2, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
+            if B > 1:
+                q2.flags |= nat.Q_SHARE_GPU
             plans2 = [eng.plan(q2) for _ in range(B)]
 
             def step2():
@@ -335,6 +353,7 @@ def main():
                 "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
                 "line_utilisation": (bytes_per_launch / traffic) if traffic else None,
                 "launches_per_query": launches, "per_launch": per_launch,
+                "batch_form_launch_us": shared_launch_us,
                 "note": "8 B per sampled row (SoA f64 amount column) / mean sweep-kernel duration, one query in flight; the "
                         "duration is the dispatch's own begin/end timestamps, taken by HIP events attached to the launch "
                         "(hipExtLaunchKernelGGL) on the launch stream - the same clock rocprofv3 reports "
@@ -354,7 +373,7 @@ def main():
     if pipe is not None:
         for nb in natives:
             nb.close()
-    for p in plans:
+    for p in plans + [plan]:
         p.close()
     eng.close()
     if use_dist:

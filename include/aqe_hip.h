@@ -125,6 +125,8 @@ typedef struct aqe_query {
 #define AQE_Q_NO_LAYOUT 8u /* CLT: sweep the sampled rows where they lie in the column; by default the column is kept a
                               second time in stride-major order per pointer step in use, where a pointer's rows are
                               contiguous (same rows, same answer, a fraction of the memory traffic) */
+#define AQE_Q_SHARE_GPU 16u /* this query will run beside others (several plans in flight on different streams): its
+                               single-launch sweep takes half the compute units, so that two fit the chip side by side */
 #define AQE_Q_FORCE_PERSIST 4u /* take the single-launch form whenever the plan has one, also where the query is
                                   predicted to stop early (by default such plans are launched round by round) */
 

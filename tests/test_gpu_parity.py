@@ -198,6 +198,10 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     auto = eng.reduce(q)
     assert (auto.n, auto.visited, auto.converged, auto.rounds, auto.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
     assert rel(auto.sum, multi.sum) <= 1e-14 and rel(auto.ci_lower, multi.ci_lower) <= 1e-13
+    q.flags = nat.Q_FORCE_PERSIST | nat.Q_SHARE_GPU | nat.Q_NO_LAYOUT  # half the compute units, column swept in place
+    alt = eng.reduce(q)
+    assert (alt.n, alt.visited, alt.converged, alt.rounds, alt.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
+    assert rel(alt.sum, multi.sum) <= 1e-14 and rel(alt.sumsq, multi.sumsq) <= 1e-14 and rel(alt.ci_lower, multi.ci_lower) <= 1e-13
     q.flags = nat.Q_FORCE_PERSIST
     res = eng.reduce(q)
     # (different summation trees: integers and decisions identical, sums to rounding)
