@@ -307,13 +307,32 @@ __device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u6
     const bool group_b = F.group != 0;
     double v[kTileUnroll];
     bool ok[kTileUnroll];
+    if (F.flags & kFamLinear) {
+        // short segments, tiled along the ordinal axis: ordinal o = T0 + x sits in segment (T0 + x) / seg_len.  One
+        // 64-bit division per tile for T0; x + (T0 mod seg_len) stays below 1024, where a float reciprocal is exact
+        const u64 T0 = j * kTileOrdinals;
+        const u64 seg0 = T0 / seg_len;
+        const unsigned r0 = static_cast<unsigned>(T0 - seg0 * seg_len), sl = static_cast<unsigned>(seg_len);
+        const float inv = 1.0f / static_cast<float>(sl);
+        const double* const col = a.amount + (F.row0 - a.shard_lo);
 #pragma unroll
-    for (int k = 0; k < kTileUnroll; ++k) {
-        const u64 oi = oi0 + static_cast<u64>(k) * 64;
-        const u64 o = seg_ord0 + oi;
-        ok[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
-        const double* p = ok[k] ? base + oi * step : a.amount;
-        v[k] = *p;
+        for (int k = 0; k < kTileUnroll; ++k) {
+            const unsigned x = r0 + static_cast<unsigned>(lane) + 64u * static_cast<unsigned>(k);
+            const unsigned qx = static_cast<unsigned>((static_cast<float>(x) + 0.5f) * inv);
+            const u64 o = T0 + static_cast<unsigned>(lane) + 64u * static_cast<unsigned>(k);
+            ok[k] = o >= ord_lo && o < ord_hi;
+            const double* p = ok[k] ? col + (seg0 + qx) * F.pitch + static_cast<u64>(x - qx * sl) * step : a.amount;
+            v[k] = *p;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) {
+            const u64 oi = oi0 + static_cast<u64>(k) * 64;
+            const u64 o = seg_ord0 + oi;
+            ok[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
+            const double* p = ok[k] ? base + oi * step : a.amount;
+            v[k] = *p;
+        }
     }
     TileAcc ta;
 #pragma unroll

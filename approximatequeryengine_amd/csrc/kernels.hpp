@@ -19,6 +19,9 @@ constexpr int kDenseTileOrdinals = 2 * kTileOrdinals;
 // (short segments — pages of 128 rows — keep the 512-ordinal tile: a long tile would idle most of the wave)
 __host__ __device__ inline bool is_dense16(uint64_t step, uint32_t flags, uint64_t seg_len) { return step == 1 && !(flags & AQE_F_PAIR) && seg_len >= static_cast<uint64_t>(kTileOrdinals); }
 inline uint64_t tile_ordinals(uint64_t step, uint32_t flags, uint64_t seg_len) { return is_dense16(step, flags, seg_len) ? kDenseTileOrdinals : kTileOrdinals; }
+// Internal family flag (beside the ABI's AQE_F_*): short segments (pages of 128 rows) are tiled along the ORDINAL axis,
+// a tile spanning several segments, instead of one mostly idle tile per segment.
+constexpr uint32_t kFamLinear = 1u << 8;
 constexpr int kMaxBlocks = 2048;            // 8 workgroups per CU on 256 CUs
 constexpr int kVec = AQE_MOMENT_VEC;
 // Arrival tickets are sharded: a same-address device atomic costs ~20 ns and serialises, so 2048

@@ -35,7 +35,7 @@ void drop_cache(aqe_ctx* c) {
 namespace {
 
 // Tile decomposition of one family window (kernels.hpp: one wave folds kTileOrdinals per tile).
-void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f, uint64_t& out_pos, bool dense16) {
+void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f, uint64_t& out_pos, bool dense16, bool linear_ok = false) {
     if (f.ord_hi <= f.ord_lo) return;
     DevFamily d{};
     d.row0 = f.row0; d.pitch = f.pitch; d.seg_len = f.seg_len; d.step = f.step;
@@ -52,7 +52,14 @@ void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f,
     const uint64_t s_lo = win_lo / f.seg_len, s_hi = (win_hi - 1) / f.seg_len;
     uint64_t ntiles;
     d.seg_lo = s_lo;
-    if (s_lo == s_hi) {
+    if (linear_ok && s_lo != s_hi && tile == static_cast<uint64_t>(kTileOrdinals) && f.seg_len < tile && !(f.flags & AQE_F_PAIR)) {
+        // many short segments (pages): tile j covers ordinals [(j_lo + j) tile, + tile) across segment boundaries
+        d.flags |= kFamLinear;
+        d.tiles_per_seg = 0;
+        d.seg_lo = 0;
+        d.j_lo = win_lo / tile;
+        ntiles = (win_hi - 1) / tile + 1 - d.j_lo;
+    } else if (s_lo == s_hi) {
         d.tiles_per_seg = 0;
         d.j_lo = (win_lo % f.seg_len) / tile;
         ntiles = ((win_hi - 1) % f.seg_len) / tile + 1 - d.j_lo;
@@ -316,7 +323,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     for (const auto& rf : p->host.round_fams) {
         LaunchDesc L;
         L.fam_offset = p->h_fams.size();
-        for (const auto& f : rf) add_family(p->h_fams, L, f, out_pos, c->dense16);
+        for (const auto& f : rf) add_family(p->h_fams, L, f, out_pos, c->dense16, !(q->flags & AQE_Q_NO_LAYOUT));
         p->rounds.push_back(L);
     }
     if (p->host.is_random) {
