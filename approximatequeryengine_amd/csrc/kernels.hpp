@@ -110,7 +110,7 @@ constexpr int kMaxPersistRounds = 32;
 constexpr int kPersistThreads = 1024;  // one workgroup of 16 waves per CU
 constexpr int kPersistWaves = kPersistThreads / 64;
 constexpr int kMaxPersistGrid = 256;   // workgroups (a power of two <= CU count)
-constexpr int kPersistInlineFams = 16; // family tables up to this size travel in the kernel arguments
+constexpr int kPersistInlineFams = 22; // family tables up to this size travel in the kernel arguments (4 KB of them at most)
 constexpr int kDecSteps = 32;          // monitor: steps (8 workgroup partials each) per batch of loads
 
 static_assert(kMaxPersistGrid / 8 <= kDecSteps, "a round's slots fit the monitor's window");
@@ -156,6 +156,7 @@ struct PersistLaunch {
 };
 
 // ev0/ev1 (optional): events that receive the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL)
+static_assert(sizeof(PersistLaunch) <= 4096, "kernel arguments are limited to 4 KB");
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);
