@@ -186,10 +186,8 @@ __global__ void k_update(QueryState* s, const double* vec, FoldParams p, int res
 // Multi-GPU form: `totals` holds the all-reduced total of every round, in order.  Replays the folds in round
 // order — lane q keeps the state after round q and judges that round's stop rule, all rounds at once — takes
 // the first stopping round (or the last) and writes the state and the result; a due top-up is marked, not run.
-__global__ void k_replay(const double* __restrict__ totals, unsigned rounds, unsigned has_topup, FoldParams fp,
-                         FinalizeParams fin, QueryState* state, aqe_result* result) {
-    const int lane = threadIdx.x & 63;
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+__device__ __forceinline__ void replay_one(const double* __restrict__ totals, unsigned rounds, unsigned has_topup, const FoldParams& fp,
+                                           const FinalizeParams& fin, QueryState* state, aqe_result* result, int lane) {
     const bool have = static_cast<unsigned>(lane) < rounds;
     double tot_q[7];
 #pragma unroll
@@ -225,6 +223,19 @@ __global__ void k_replay(const double* __restrict__ totals, unsigned rounds, uns
     // second pass over the table for a rare case): the caller runs it as one more step when it sees the mark.
     r.topup_pending = (has_topup && st.n_p < static_cast<double>(fp.base / 4)) ? 1 : 0;
     *result = r;
+}
+
+__global__ void k_replay(const double* __restrict__ totals, unsigned rounds, unsigned has_topup, FoldParams fp,
+                         FinalizeParams fin, QueryState* state, aqe_result* result) {
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    replay_one(totals, rounds, has_topup, fp, fin, state, result, threadIdx.x & 63);
+}
+
+// A batch of plans after ONE all-reduce: workgroup i replays plan i from row i of the reduced buffer.
+__global__ __launch_bounds__(64) void k_replay_batch(const ReplayItem* __restrict__ items, const double* __restrict__ totals, u64 row_stride) {
+    const ReplayItem it = items[blockIdx.x];
+    replay_one(totals + static_cast<size_t>(blockIdx.x) * row_stride, it.rounds, it.has_topup, it.fp, it.fin, it.state, it.result,
+               threadIdx.x & 63);
 }
 
 __global__ void k_finalize(const QueryState* s, FinalizeParams p, aqe_result* out) {
@@ -391,6 +402,11 @@ hipError_t launch_update(QueryState* state, const double* vec, const FoldParams&
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s) {
     hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, s, totals, rounds, has_topup, fp, fin, state, result);
+    return hipGetLastError();
+}
+
+hipError_t launch_replay_batch(const ReplayItem* items, uint32_t n, const double* totals, uint64_t row_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_replay_batch, dim3(n), dim3(64), 0, s, items, totals, static_cast<u64>(row_stride));
     return hipGetLastError();
 }
 

@@ -161,6 +161,16 @@ hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);
 
+// one plan of a batch, for k_replay_batch
+struct ReplayItem {
+    uint32_t rounds, has_topup;
+    FoldParams fp;
+    FinalizeParams fin;
+    QueryState* state;
+    aqe_result* result;
+};
+hipError_t launch_replay_batch(const ReplayItem* items, uint32_t n, const double* totals, uint64_t row_stride, hipStream_t s);
+
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s, hipEvent_t ev0 = nullptr,
                           hipEvent_t ev1 = nullptr);

@@ -610,7 +610,8 @@ struct aqe_batch {
     aqe_ctx* ctx = nullptr;
     std::vector<aqe_plan*> plans;   // plan i runs on lane i % kBatchLanes of the context
     std::vector<hipEvent_t> swept;  // lane l's sweeps of this batch are enqueued up to here
-    hipEvent_t reduced = nullptr;   // the caller's stream up to (and including) the collective
+    hipEvent_t reduced = nullptr;   // the caller's stream up to (and including) the collective and the replays
+    ReplayItem* d_items = nullptr;  // one entry per plan, for the single replay launch
 };
 
 extern "C" {
@@ -711,6 +712,7 @@ void aqe_batch_destroy(aqe_batch* b) {
     }
     for (hipEvent_t e : b->swept) (void)hipEventDestroy(e);
     if (b->reduced) (void)hipEventDestroy(b->reduced);
+    if (b->d_items) (void)hipFree(b->d_items);
     delete b;
 }
 
@@ -735,6 +737,14 @@ int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out) {
         b->swept.push_back(e);
     }
     HIPCHK(c, hipEventCreateWithFlags(&b->reduced, hipEventDisableTiming));
+    std::vector<ReplayItem> items(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        aqe_plan* p = plans[i];
+        items[i] = ReplayItem{static_cast<uint32_t>(p->rounds.size()), p->host.has_topup ? 1u : 0u, fold_params(p, false), finalize_params(p),
+                              p->d_state, p->d_result};
+    }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&b->d_items), n * sizeof(ReplayItem)));
+    HIPCHK(c, hipMemcpy(b->d_items, items.data(), n * sizeof(ReplayItem), hipMemcpyHostToDevice));
     *out = b.release();
     return AQE_OK;
 }
@@ -771,15 +781,15 @@ int aqe_batch_enqueue_replays(aqe_batch* b, const double* dev_totals, uint64_t r
     aqe_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    HIPCHK(c, hipEventRecord(b->reduced, main_s));
-    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->lanes[l], b->reduced, 0));  // every lane waits for the collective
-    for (size_t i = 0; i < b->plans.size(); ++i) {
-        aqe_plan* p = b->plans[i];
+    for (aqe_plan* p : b->plans) {
         int rc = plan_is_current(p);
         if (rc != AQE_OK) return rc;
-        HIPCHK(c, launch_replay(dev_totals + i * row_stride, static_cast<uint32_t>(p->rounds.size()), p->host.has_topup ? 1u : 0u,
-                                fold_params(p, false), finalize_params(p), p->d_state, p->d_result, c->lanes[i % kBatchLanes]));
     }
+    // ONE launch replays every plan of the batch on the caller's stream, right behind the collective; the side
+    // streams then wait for it before they sweep again (their plans' state, result and buffer row are read here)
+    HIPCHK(c, launch_replay_batch(b->d_items, static_cast<uint32_t>(b->plans.size()), dev_totals, row_stride, main_s));
+    HIPCHK(c, hipEventRecord(b->reduced, main_s));
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->lanes[l], b->reduced, 0));
     return AQE_OK;
 }
 
