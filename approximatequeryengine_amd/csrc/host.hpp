@@ -101,6 +101,9 @@ struct SweepForm {
     uint32_t round_mod[aqe::kMaxPersistRounds + 1] = {0};
     uint32_t part_first[aqe::kMaxPersistRounds] = {0}, part_count[aqe::kMaxPersistRounds] = {0};
     uint64_t ntiles = 0, samples = 0;
+    uint32_t grid = 0;        // workgroups of the launch (a power of two)
+    uint32_t more_rounds = 0; // the form ends before the plan's last round (the head form)
+    uint32_t topup_slot = 0;  // the last slot is the plan's top-up
 };
 
 struct aqe_plan {
@@ -135,6 +138,7 @@ struct aqe_plan {
     const double* view_rounds = nullptr;  // stride-major view the rounds' families index (nullptr: the column itself)
     const double* view_topup = nullptr;   // ... and the top-up's
     unsigned grid = 0;          // workgroups of the persistent sweep for this plan (the context's, or half of it)
+    SweepForm head;             // the first rounds only, on a few workgroups: the single launch of a query predicted to stop early
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals

@@ -147,6 +147,9 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
     const unsigned rounds = K->rounds;
     const unsigned long long epoch = K->epoch;
     const bool totals_only = K->totals_only != 0;
+    const bool tslot = K->topup_slot != 0;              // the last slot is the top-up: summed on its own, never judged
+    const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
+    const bool own_sum = totals_only ? lane < rounds : (tslot && lane == rounds - 1u);
     const unsigned ql = lane < rounds ? lane : rounds - 1u;
     const unsigned sb_lo = K->step_begin[ql], sb_hi = K->step_begin[ql + 1u];  // lane q: the steps of round q
     for (;;) {
@@ -162,7 +165,7 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
         for (int m = 0; m < kDecSteps; ++m) {
             if (static_cast<unsigned>(m) < E) {
                 // totals form: every round is summed on its own
-                if (totals_only && __ballot(lane < rounds && sb_hi > sb_lo && sb_lo == S + static_cast<unsigned>(m)) != 0) run = 0.0;
+                if ((totals_only || tslot) && __ballot(own_sum && sb_hi > sb_lo && sb_lo == S + static_cast<unsigned>(m)) != 0) run = 0.0;
                 run += x[m];
             }
             lds_run[m][lane] = run;
@@ -218,27 +221,41 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
             st.visited = tot[6];
             aqe_result res{};
             // (only when this fold is certain to end the query; an early stop works its result out afterwards)
-            const bool result_now = with_result && (p_new == rounds || warm);
+            const bool result_now = with_result && ((p_new == rounds && !tslot) || warm);
+            double tup[7] = {0, 0, 0, 0, 0, 0, 0};  // the top-up slot's own total
+            if (tslot) {
+#pragma unroll
+                for (int cc = 0; cc < 7; ++cc) tup[cc] = read_lane_f64(tot[cc], static_cast<int>(rounds - 1u));
+            }
             if (fresh) {
-                if (fp.is_clt) code = clt_rules(tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], fp);
+                if (fp.is_clt && lane < rounds_j) code = clt_rules(tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], fp);
                 if (result_now) res = make_result(st, fin);
             }
             const unsigned long long stops = __ballot(code != 0);
             unsigned last_round = ~0u;
             if (warm) last_round = 0u;
             else if (stops) last_round = static_cast<unsigned>(__builtin_ctzll(stops));  // the rule is satisfied after this round
-            else if (p_new == rounds) last_round = rounds - 1u;                            // samples exhausted
+            else if (p_new == rounds) last_round = rounds_j - 1u;                          // samples exhausted
             if (last_round != ~0u) {
                 if (lane == last_round) {
                     st.rounds = static_cast<int32_t>(last_round + 1u);
                     st.converged = code;
                     st.stop = code != 0;
+                    // DB.cpp:1032: too few rows collected -> the top-up is due.  Swept with the rounds (head form): it is
+                    // added here.  Otherwise the launch that follows applies it and clears the mark; when the host did
+                    // not enqueue one (it is rarely due), it sees the mark.
+                    const bool goes_on = code == 0 && K->more_rounds;  // head form: out of rounds, not out of samples
+                    bool due = K->topup_gate && st.n_p < static_cast<double>(fp.base / 4);
+                    if (tslot && due && !goes_on) {  // the fold of a top-up vector (device_common.hpp, fold)
+                        st.n_p += tup[0]; st.sd_p += tup[1]; st.qd_p += tup[2];
+                        st.topup += tup[0];
+                        st.visited += tup[6];
+                        due = false;
+                    }
                     if (with_result && !result_now) res = make_result(st, fin);
                     res.rounds = st.rounds;
                     res.converged = code;
-                    // DB.cpp:1032: too few rows collected -> the top-up is due.  The launch that follows applies it
-                    // and clears the mark; when the host did not enqueue one (it is rarely due), it sees the mark.
-                    res.topup_pending = (K->topup_gate && st.n_p < static_cast<double>(fp.base / 4)) ? 1 : 0;
+                    res.topup_pending = goes_on ? 2 : due ? 1 : 0;  // 2: the host launches the plan's remaining rounds
                     state_store(warm ? K->rehearsal_state : K->state, st);
                     if (with_result) *(warm ? K->rehearsal_result : K->result) = res;
                     if (code != 0 && !warm) {  // waves are still sweeping: state and result are out before should_stop is
@@ -309,7 +326,8 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
     // nothing can be complete yet: rehearse the fold, so that the real one finds its code in the instruction cache
     (void)monitor_fold(K, 0u, 0u, 0.0, true);
     for (;;) {
-        const unsigned complete = monitor_poll(K, judged);
+        unsigned complete = monitor_poll(K, judged);
+        if (K->topup_slot != 0 && complete != K->rounds) complete = judged;  // that form is judged once, when everything is in
         if (complete > judged) {
             const FoldOut o = monitor_fold(K, judged, complete, run, false);  // does not return if the query ends here
             run = o.run;

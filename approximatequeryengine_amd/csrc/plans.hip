@@ -14,7 +14,7 @@ void destroy_plan(aqe_plan* p) {
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
-    for (SweepForm* f : {&p->decide, &p->totals}) {
+    for (SweepForm* f : {&p->decide, &p->totals, &p->head}) {
         if (f->d_fams) (void)hipFree(f->d_fams);
         if (f->d_ppart) (void)hipFree(f->d_ppart);
     }
@@ -171,18 +171,28 @@ int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup,
 
 // Lay the plan's rounds (optionally the top-up as one more slot) out as ONE tile list and work out which
 // workgroups own tiles of which slot.
-int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
+int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t grid, size_t nrounds) {
     aqe_ctx* c = p->ctx;
     std::vector<const LaunchDesc*> slots;
-    for (const auto& L : p->rounds) slots.push_back(&L);
+    for (size_t r = 0; r < nrounds; ++r) slots.push_back(&p->rounds[r]);
+    F.grid = grid;
+    F.more_rounds = nrounds < p->rounds.size() ? 1u : 0u;
+    F.topup_slot = with_topup_slot && p->host.has_topup ? 1u : 0u;
     if (with_topup_slot && p->host.has_topup) slots.push_back(&p->topup);
     const size_t S = slots.size();
     uint64_t tiles = 0;
+    // One launch has one column base (SweepCommon::amount), and the top-up may live in another copy of the column
+    // than the rounds (its own stride-major view): its families' row numbers are then re-based — the distance
+    // between the two allocations, in rows, is added (64-bit wrap-around; both are 256-byte aligned, so alignment
+    // of every access is unchanged).
+    const SweepCommon sw_r = sweep_common(p, nullptr, 0, false), sw_t = sweep_common(p, nullptr, 0, true);
+    const uint64_t topup_rebase = static_cast<uint64_t>(sw_t.amount - sw_r.amount) - sw_t.shard_lo + sw_r.shard_lo;
     for (size_t r = 0; r < S; ++r) {
         const LaunchDesc& L = *slots[r];
         F.round_begin[r] = tiles;
         for (uint32_t i = 0; i < L.nfam; ++i) {
             DevFamily d = p->h_fams[L.fam_offset + i];
+            if (slots[r] == &p->topup) { d.row0 += topup_rebase; d.row0_b += topup_rebase; }
             d.tile_begin += tiles;
             d.flags &= ~AQE_F_TOPUP;  // swept whole: the replay decides whether the top-up counts
             F.h_fams.push_back(d);
@@ -197,7 +207,7 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F) {
     // tiles v, v + V, ...  The workgroups that own tiles of a slot form ONE cyclic run of workgroup ids (tiles
     // are consecutive, sweepers cyclic): find it by enumeration and insist on it — the monitor waits for
     // exactly these workgroups.
-    const uint64_t G = p->grid, V = G * kPersistWaves - 1;
+    const uint64_t G = grid, V = G * kPersistWaves - 1;
     auto sweeper_has = [&](uint64_t v, uint64_t b0, uint64_t b1) { const uint64_t m0 = b0 % V; return b0 + (v >= m0 ? v - m0 : v + V - m0) < b1; };
     for (size_t r = 0; r < S; ++r) {
         F.round_mod[r] = static_cast<uint32_t>(F.round_begin[r] % V);
@@ -355,7 +365,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         bool every_round_has_tiles = true;
         for (size_t r = 0; r < R; ++r) every_round_has_tiles = every_round_has_tiles && p->rounds[r].ntiles > 0;
         if (multi && whole && every_round_has_tiles && R <= static_cast<size_t>(kMaxPersistRounds) && !(q->flags & AQE_Q_NO_PERSIST)) {
-            int rc2 = build_sweep_form(p.get(), false, p->decide);
+            int rc2 = build_sweep_form(p.get(), false, p->decide, p->grid, R);
             if (rc2 != AQE_OK) return rc2;
             p->persist = true;
             // Two equivalent forms now exist: the single launch that sweeps every round speculatively, and one
@@ -369,12 +379,38 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                 const double root = p->host.clt.z * c->head_cv * 100.0 / q->max_error_percent;
                 const double n_stop = std::max(50.0, root * root);  // samples before rule A can hold (n >= 50, DB.cpp:958)
                 double swept = 0.0;
-                for (size_t r = 0; r < R && swept < n_stop; ++r) swept += static_cast<double>(p->rounds[r].samples);
+                size_t r_stop = 0;  // rounds swept when the rule is predicted to hold
+                for (; r_stop < R && swept < n_stop; ++r_stop) swept += static_cast<double>(p->rounds[r_stop].samples);
                 p->per_round = swept * 4.0 <= static_cast<double>(p->decide.samples);
+                if (p->per_round) {
+                    // The HEAD form: ONE launch that sweeps the predicted rounds plus one of margin (four times the rows:
+                    // twice the predicted cv) on just enough workgroups for them — a few microseconds on a corner of the
+                    // chip, so dozens of such queries run side by side.  If the query has not stopped by then, the result
+                    // says so (topup_pending == 2) and fetch() launches the remaining rounds one by one.
+                    // A query that stops this early is short of rows and takes the reference's top-up (DB.cpp:1031-1040):
+                    // the head form sweeps it along with the rounds, as one more slot, and the monitor adds it when due.
+                    const size_t r_head = std::min(R, r_stop + 1);
+                    for (int with_topup = p->host.has_topup ? 1 : 0; with_topup >= 0 && !p->head.ok; --with_topup) {
+                        uint64_t tiles = with_topup ? p->topup.ntiles : 0;
+                        for (size_t r = 0; r < r_head; ++r) tiles += p->rounds[r].ntiles;
+                        uint32_t g = 1;
+                        while (g < p->grid && static_cast<uint64_t>(g) * kPersistWaves * 2 < tiles) g *= 2;
+                        SweepForm F;
+                        rc2 = build_sweep_form(p.get(), with_topup != 0, F, g, r_head);
+                        // (with the top-up the monitor judges once, from one window of steps)
+                        if (rc2 == AQE_OK && !(with_topup && F.step_begin[F.slots] > static_cast<uint32_t>(kDecSteps))) {
+                            p->head = std::move(F);
+                            break;
+                        }
+                        if (F.d_fams) (void)hipFree(F.d_fams);
+                        if (F.d_ppart) (void)hipFree(F.d_ppart);
+                        if (rc2 != AQE_OK) return rc2;
+                    }
+                }
             }
         }
         if (multi && R <= static_cast<size_t>(kMaxPersistRounds)) {
-            int rc2 = build_sweep_form(p.get(), false, p->totals);
+            int rc2 = build_sweep_form(p.get(), false, p->totals, p->grid, R);
             if (rc2 != AQE_OK) return rc2;
         }
         if (p->decide.ok || p->totals.ok) {
@@ -432,6 +468,8 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     a.rehearsal_result = reinterpret_cast<aqe_result*>(static_cast<char*>(p->d_rehearsal) + sizeof(QueryState));
     a.stamps = c->d_stamps;
     a.finalize_here = 1u;
+    a.more_rounds = F.more_rounds;
+    a.topup_slot = totals_only ? 0u : F.topup_slot;
     a.topup_gate = p->host.has_topup ? 1u : 0u;
     a.totals_only = totals_only ? 1u : 0u;
     p->last_exec = totals_only ? 2 : 1;
@@ -443,7 +481,7 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
         HIPCHK(c, hipStreamSynchronize(s));
     }
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
-    HIPCHK(c, launch_sweep_persist(a, p->grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
+    HIPCHK(c, launch_sweep_persist(a, F.grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
     if (prof) p->lev_used++;
     return AQE_OK;
 }
@@ -459,13 +497,14 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
         HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
         HIPCHK(c, launch_finalize(p->d_state, finalize_params(p), p->d_result, s));
     } else {
-        if (p->persist && !p->per_round) {
-            int rc = launch_form(p, p->decide, false, nullptr, s);
+        if (p->persist && (!p->per_round || p->head.ok)) {
+            const SweepForm& F = p->per_round ? p->head : p->decide;
+            int rc = launch_form(p, F, false, nullptr, s);
             if (rc != AQE_OK) return rc;
             // The monitor has written the result.  The top-up (DB.cpp:1031-1040) is rarely due — only when the query
             // stops with fewer than base/4 rows — so its launch is enqueued only for plans whose last execution
             // needed it; otherwise the result carries topup_pending if it was due after all, and fetch() runs it.
-            topup_done = !p->expect_topup;
+            topup_done = F.topup_slot || !p->expect_topup;
         } else if (p->rounds.size() >= kGraphMinRounds && p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH")) {
             // One launch per round is a launch-bound loop (every launch after the stop is a device-side no-op): it is
             // captured ONCE per plan into a HIP graph — the launches' arguments never change — and replayed.
@@ -504,7 +543,21 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
 int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     aqe_ctx* c = p->ctx;
     HIPCHK(c, hipStreamSynchronize(s));
-    if (p->last_exec == 1 && p->host.has_topup) {
+    if (p->last_exec == 1 && p->h_result->topup_pending == 2) {
+        // the head form ran out of rounds before the query stopped (the prediction failed): the remaining rounds go
+        // out one launch each, the top-up behind them — and from now on this plan takes the full single launch
+        for (uint32_t i = p->head.slots - p->head.topup_slot; i < p->rounds.size(); ++i) {
+            int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
+        if (p->host.has_topup) {
+            int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
+        HIPCHK(c, hipStreamSynchronize(s));
+        p->per_round = false;
+        p->expect_topup = p->h_result->topup > 0;
+    } else if (p->last_exec == 1 && p->host.has_topup) {
         if (p->h_result->topup_pending) {  // the top-up was due and its launch had not been enqueued: run it now
             int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
             if (rc != AQE_OK) return rc;
@@ -559,7 +612,7 @@ constexpr uint32_t kSyncChunkRounds = 256;
 
 int run_sync(aqe_plan* p, hipStream_t s, bool timed) {
     aqe_ctx* c = p->ctx;
-    if ((p->persist && !p->per_round) || p->rounds.size() <= kSyncChunkRounds) return enqueue_all(p, s, timed);
+    if ((p->persist && (!p->per_round || p->head.ok)) || p->rounds.size() <= kSyncChunkRounds) return enqueue_all(p, s, timed);
     if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));
     p->lev_used = 0;
     p->last_exec = 0;

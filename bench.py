@@ -269,9 +269,10 @@ def main():
                      "closed_loop_latency_us_p50": 1e6 * lat2[len(lat2) // 2],
                      "result": {"avg": r2.value, "ci": [r2.ci_lower, r2.ci_upper], "n": int(r2.n), "converged": int(r2.converged),
                                 "rounds": int(r2.rounds), "topup_rows": int(r2.topup)},
-                     "note": "launched round by round (the plan predicts an early stop from the table's head: cv and the error rule): "
-                             "should_stop is set on the device after the round(s) shown, the later rounds' launches are device-side "
-                             "no-ops, and the rest of the sample is the reference's top-up (a device-gated launch: every 20th row)"}
+                     "note": "ONE launch on a few workgroups (the plan predicts an early stop from the table's head: cv and the "
+                             "error rule, and sweeps only the first rounds plus the reference's top-up, every 20th row, as one more "
+                             "slot): the monitor wave judges the rounds shown, finds the sample short (DB.cpp:1032) and adds the "
+                             "top-up; had the query not stopped there, fetch() would launch the remaining rounds"}
             for p in plans2:
                 p.close()
 

@@ -221,6 +221,35 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     assert np.array_equal(np.sort(got["id"] - 1), np.sort(idx.astype(np.int64)))
 
 
+def test_clt_head_form_misprediction_is_continued(nat, oracle, table):
+    """A query predicted to stop early runs as ONE small launch over the first rounds (the head form).  When the
+    prediction fails — here the table's head is nearly constant, the rest is not — fetch() launches the remaining
+    rounds, and the plan takes the full single launch from then on: all three agree with the round-by-round form
+    and with the oracle (DB.cpp:885-1043 semantics)."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 1_000_000
+    rows = table(n).copy()
+    rows["amount"][:4096] = 500.0 + 1e-3 * (np.arange(4096) % 7)
+    eng = Engine(0)
+    try:
+        eng.stage_records(rows, keep_aos=True)
+        for e, R0, g in ((1.0, 256, 2), (0.05, 1024, 4), (1.0, 4096, 4)):
+            rc, want, _ = oracle.clt_run(rows, 20.0, 0.95, 10, 4, e, R0=R0, growth=g, want_idx=True)
+            assert rc == 0
+            q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, num_threads=4, max_error_percent=e, clt_round0=R0, clt_growth=g)
+            q.flags = nat.Q_NO_PERSIST
+            multi = eng.reduce(q)
+            q.flags = 0
+            for _ in range(3):  # head + continuation, then the full launch twice
+                r = eng.reduce(q)
+                assert (r.n, r.visited, r.converged, r.rounds, r.topup, r.topup_pending) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup, 0)
+                assert rel(r.sum, multi.sum) <= 1e-14 and rel(r.ci_lower, multi.ci_lower) <= 1e-13 and rel(r.value, multi.value) <= 1e-13
+            assert (r.converged, r.rounds, r.topup, r.n) == (want.converged, want.rounds, want.topup, want.final.n)
+            assert rel(r.sum, want.final.sum) <= SUM_TOL
+    finally:
+        eng.close()
+
+
 def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
     """Where the reference divides by zero (DB.cpp:927, 985, 993) the C ABI returns AQE_ERR_INVALID."""
     from approximatequeryengine_amd.engine import make_query
