@@ -139,6 +139,7 @@ struct aqe_plan {
     const double* view_topup = nullptr;   // ... and the top-up's
     unsigned grid = 0;          // workgroups of the persistent sweep for this plan (the context's, or half of it)
     SweepForm head;             // the first rounds only, on a few workgroups: the single launch of a query predicted to stop early
+    uint32_t last_grid = 0;     // workgroups of the last persistent launch (diagnostics)
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals

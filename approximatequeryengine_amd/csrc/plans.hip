@@ -368,13 +368,11 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             int rc2 = build_sweep_form(p.get(), false, p->decide, p->grid, R);
             if (rc2 != AQE_OK) return rc2;
             p->persist = true;
-            // Two equivalent forms now exist: the single launch that sweeps every round speculatively, and one
-            // launch per round where everything after the stop is a no-op.  The first wins when the query runs (almost)
-            // to the end; the second when it stops early and most of the sweep would have been for nothing (measured,
-            // 10 M rows, e = 1 %: 63.7 k against 43.5 k aggregates/s).  Which one applies depends on the data, so
-            // it is PREDICTED — from the coefficient of variation of the table's head and the error rule
-            // (DB.cpp:936-961: stop once z cv / sqrt(n) <= e/100) — a fixed function of table and query, so the same
-            // query always takes the same path and repeats bit for bit.  AQE_Q_NO_PERSIST / AQE_Q_FORCE_PERSIST override.
+            // The single launch sweeps every round speculatively: right when the query runs (almost) to the end, a waste
+            // when it stops early and most of the sweep would have been for nothing.  Which one applies depends on the
+            // data, so it is PREDICTED — from the coefficient of variation of the table's head and the error rule
+            // (DB.cpp:936-961: stop once z cv / sqrt(n) <= e/100) — a fixed function of table and query.  A query
+            // predicted to stop early gets the HEAD form below.  AQE_Q_NO_PERSIST / AQE_Q_FORCE_PERSIST override.
             if (p->host.is_clt && !(q->flags & AQE_Q_FORCE_PERSIST) && c->head_cv > 0.0 && q->max_error_percent > 0.0) {
                 const double root = p->host.clt.z * c->head_cv * 100.0 / q->max_error_percent;
                 const double n_stop = std::max(50.0, root * root);  // samples before rule A can hold (n >= 50, DB.cpp:958)
@@ -384,17 +382,21 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                 p->per_round = swept * 4.0 <= static_cast<double>(p->decide.samples);
                 if (p->per_round) {
                     // The HEAD form: ONE launch that sweeps the predicted rounds plus one of margin (four times the rows:
-                    // twice the predicted cv) on just enough workgroups for them — a few microseconds on a corner of the
-                    // chip, so dozens of such queries run side by side.  If the query has not stopped by then, the result
-                    // says so (topup_pending == 2) and fetch() launches the remaining rounds one by one.
+                    // twice the predicted cv) on just enough workgroups for one tile per wave.  If the query has not
+                    // stopped by then, the result says so (topup_pending == 2), fetch() launches the remaining rounds one
+                    // by one, and the plan takes the full single launch from then on.
                     // A query that stops this early is short of rows and takes the reference's top-up (DB.cpp:1031-1040):
                     // the head form sweeps it along with the rounds, as one more slot, and the monitor adds it when due.
+                    // (Measured, bench query at e = 1 %: 230 k aggregates/s and 14 us per launch, against 76-100 k for
+                    // one launch per round replayed as a graph, which is what such plans used before.)
                     const size_t r_head = std::min(R, r_stop + 1);
                     for (int with_topup = p->host.has_topup ? 1 : 0; with_topup >= 0 && !p->head.ok; --with_topup) {
                         uint64_t tiles = with_topup ? p->topup.ntiles : 0;
                         for (size_t r = 0; r < r_head; ++r) tiles += p->rounds[r].ntiles;
                         uint32_t g = 1;
-                        while (g < p->grid && static_cast<uint64_t>(g) * kPersistWaves * 2 < tiles) g *= 2;
+                        // one tile per sweeper wave: the sweep is a few microseconds of latency, not of bandwidth (measured, bench
+                        // query at e = 1 %: 14 us per launch and 230 k aggregates/s so, 23 us and 173 k with two tiles per wave)
+                        while (g < p->grid && static_cast<uint64_t>(g) * kPersistWaves < tiles) g *= 2;
                         SweepForm F;
                         rc2 = build_sweep_form(p.get(), with_topup != 0, F, g, r_head);
                         // (with the top-up the monitor judges once, from one window of steps)
@@ -473,6 +475,7 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     a.topup_gate = p->host.has_topup ? 1u : 0u;
     a.totals_only = totals_only ? 1u : 0u;
     p->last_exec = totals_only ? 2 : 1;
+    p->last_grid = F.grid;
     a.out_totals = out_totals;
     a.inline_fams = F.h_fams.size() <= static_cast<size_t>(kPersistInlineFams) ? 1u : 0u;
     if (a.inline_fams) std::copy(F.h_fams.begin(), F.h_fams.end(), a.fams);
@@ -567,7 +570,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     }
     *out = *p->h_result;
     if (c->d_stamps && p->persist) {
-        const size_t W = static_cast<size_t>(p->grid) * kPersistWaves;
+        const size_t W = static_cast<size_t>(p->last_grid) * kPersistWaves;
         std::vector<unsigned long long> st(8 * W + 8 * kMaxPersistRounds);
         (void)hipMemcpy(st.data(), c->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* f = std::fopen(std::getenv("AQE_PERSIST_STAMPS"), "a")) {

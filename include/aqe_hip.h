@@ -333,7 +333,11 @@ AQE_API int aqe_batch_enqueue_replays(aqe_batch* batch, const double* dev_totals
 AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
 /* fused single-GPU form: the whole query, asynchronously.  A multi-round (CLT) plan is ONE launch with in-kernel
  * decisions; the reference's top-up (DB.cpp:1031-1040), rarely due, gets its own launch only when the plan's
- * previous execution needed it — otherwise aqe_plan_fetch runs it if the result turns out to want it. */
+ * previous execution needed it — otherwise aqe_plan_fetch runs it if the result turns out to want it.
+ * A query PREDICTED to stop early (from the coefficient of variation of the table's first rows and the error rule)
+ * is launched on a few workgroups over its first rounds and the top-up only; if it has not stopped by then,
+ * aqe_plan_fetch launches the remaining rounds and the plan uses the full launch from its next execution on.
+ * Either way the answer is the one the round-by-round form gives (sums to rounding). */
 AQE_API int aqe_plan_enqueue_all(aqe_plan* plan, void* stream);
 AQE_API int aqe_plan_reset(aqe_plan* plan, void* stream); /* re-arm a plan for another execution */
 AQE_API int aqe_plan_fetch(aqe_plan* plan, aqe_result* out, void* stream); /* synchronises */

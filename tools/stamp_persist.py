@@ -10,7 +10,9 @@ e = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
 eng = Engine(0)
 eng.generate_synthetic(10_000_000)
 q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=4096, clt_growth=4)
-q.flags = nat.Q_FORCE_PERSIST  # the timeline of the single-launch form, also where the library would launch round by round
+# argv[2] = "auto": the form the library picks (the head form for a query predicted to stop early);
+# default: the timeline of the full single-launch form
+q.flags = 0 if (len(sys.argv) > 2 and sys.argv[2] == "auto") else nat.Q_FORCE_PERSIST
 for _ in range(6):
     r = eng.reduce(q)
 print(r.n, r.rounds, r.converged, r.kernel_ms)
