@@ -93,9 +93,9 @@ __device__ __forceinline__ void mean_m2(double n, double sd, double qd, double c
 
 // The monitor's decision on the moments gathered so far (fast group a, slow group b, pooled a+b):
 // 1 = error rule (DB.cpp:936-961 on the pooled, all-reduced triple), 2 = cross-validation rule
-// (DB.cpp:993-1016), 0 = go on.
-__device__ __forceinline__ int clt_rules(double n_a, double sd_a, double qd_a, double n_b, double sd_b, double qd_b,
-                                         const FoldParams& p) {
+// (DB.cpp:993-1016), 0 = go on.  The reference's own expressions:
+__device__ __forceinline__ int clt_rules_exact(double n_a, double sd_a, double qd_a, double n_b, double sd_b, double qd_b,
+                                               const FoldParams& p) {
     const double n = n_a + n_b;
     if (n >= 30.0) {
         double mean, m2;
@@ -113,6 +113,44 @@ __device__ __forceinline__ int clt_rules(double n_a, double sd_a, double qd_a, d
         }
     }
     return 0;
+}
+
+// The decision sits on the critical path of every query (the monitor wave's tail), and the expressions above are a
+// chain of four f64 divisions and a square root — about 0.6 us on this part.  Both rules are comparisons, so they
+// are first evaluated cleared of divisions and roots:
+//   rule A   100 z sqrt(m2 / ((n-1) n)) / mean <= e   <=>   1e4 z^2 Q <= e^2 M^2 (n-1),   M = n mean = n c + Sd,  Q = n m2 = n Qd - Sd^2
+//   rule B   |mean_b - mean_a| / mean_a <= e/100      <=>   |M_b n_a - M_a n_b| <= (e/100) M_a n_b
+// (valid for mean > 0, e >= 0: both sides non-negative).  Only when a comparison falls within a guard band of its
+// threshold — far wider than the rounding of either side — or outside that domain do the reference's expressions
+// decide; the decision is therefore the same one, a dozen multiplications away instead of five divisions.
+__device__ __forceinline__ int clt_rules(double n_a, double sd_a, double qd_a, double n_b, double sd_b, double qd_b,
+                                         const FoldParams& p) {
+    const double n = n_a + n_b, sd = sd_a + sd_b, qd = qd_a + qd_b, c = p.shift;
+    int a = 0, b = 0;  // 1/2: holds, 0: does not, -1: too close to call
+    if (n >= 30.0) {
+        const double M = n * c + sd, Q = qd * n - sd * sd;
+        if (M > 0.0 && Q >= 0.0 && p.e >= 0.0) {
+            const double zz = 1e4 * p.z * p.z;
+            const double A = zz * Q, B = p.e * p.e * M * M * (n - 1.0);
+            const double tol = 1e-6 * fmax(A, B) + zz * 1e-12 * (qd * n);
+            a = A < B - tol ? (n >= 50.0 ? 1 : 0) : A > B + tol ? 0 : -1;
+        } else {
+            a = -1;
+        }
+    }
+    if (a == 1) return 1;
+    if (n_b >= 20.0 && n_a >= 30.0 && n_a >= static_cast<double>(p.base / 2)) {
+        const double Ma = n_a * c + sd_a, Mb = n_b * c + sd_b;
+        if (Ma > 0.0 && p.e >= 0.0) {
+            const double L = fabs(Mb * n_a - Ma * n_b), R = (p.e / 100.0) * Ma * n_b;
+            const double tol = 1e-6 * fmax(L, R) + 1e-12 * (fabs(Mb) * n_a + Ma * n_b);
+            b = L < R - tol ? 2 : L > R + tol ? 0 : -1;
+        } else {
+            b = -1;
+        }
+    }
+    if (a < 0 || b < 0) return clt_rules_exact(n_a, sd_a, qd_a, n_b, sd_b, qd_b, p);
+    return b;
 }
 
 // Fold one launch's reduced vector into the query state and take the CLT decision.
@@ -159,7 +197,7 @@ __device__ __forceinline__ aqe_result make_result(const QueryState& s, const Fin
     r.topup_pending = 0;
 
     double moe = 0.0;  // CLI:279-282: two-pass variance, fixed 1.96
-    if (n > 1.0) moe = 1.96 * sqrt(m2 / (n - 1.0)) / sqrt(n);
+    if (n > 1.0) moe = 1.96 * sqrt(m2 / ((n - 1.0) * n));  // = 1.96 sqrt(var) / sqrt(n), one division and one root shorter
     double value = 0.0, margin = 0.0;
     if (p.is_exact) {  // DB.cpp:242-274
         value = p.agg == AQE_SUM ? S : p.agg == AQE_AVG ? (N > 0.0 ? S / N : 0.0) : (visited > n ? n : N);
@@ -230,14 +268,19 @@ __device__ __forceinline__ const DevFamily* stage_families(const SweepCommon& a,
 // Every load of the tile is issued before the first use; out-of-window lanes load row 0 of the shard
 // instead of branching around the load (a per-element branch would serialise the round trips:
 // cdna_hip_programming.md §5 item 4c).
+// the family that owns tile t (tile_begin ascending)
 template <typename FamPtr>
-__device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u64 t, int lane, u64 ord_limit, Acc& acc) {
-    unsigned lo = 0, hi = a.nfam;
+__device__ __forceinline__ unsigned find_family(FamPtr fams, unsigned nfam, u64 t) {
+    unsigned lo = 0, hi = nfam;
     while (hi - lo > 1) {
         unsigned mid = (lo + hi) >> 1;
         if (fams[mid].tile_begin <= t) lo = mid; else hi = mid;
     }
-    const auto& F = fams[lo];
+    return lo;
+}
+
+template <typename Fam>
+__device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F, u64 t, int lane, u64 ord_limit, Acc& acc) {
     const u64 lt = t - F.tile_begin;
     u64 seg, j;
     if (F.tiles_per_seg == 0) { seg = F.seg_lo; j = F.j_lo + lt; }
@@ -338,6 +381,11 @@ __device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u6
 #pragma unroll
     for (int k = 0; k < kTileUnroll; ++k) accumulate(ta, v[k], ok[k], a);
     merge_tile(acc, ta, group_b);
+}
+
+template <typename FamPtr>
+__device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u64 t, int lane, u64 ord_limit, Acc& acc) {
+    sweep_family(a, fams[find_family(fams, a.nfam, t)], t, lane, ord_limit, acc);
 }
 
 }  // namespace

@@ -43,6 +43,10 @@ struct DevFamily {
     uint64_t row0_b, ord_lo_b, ord_hi_b;  // AQE_F_PAIR: the slow pointer sharing this sweep (group 1)
     uint64_t out_begin_b;
     uint32_t group, flags;
+    // persistent sweep only: the round (slot) the family belongs to and that round's end tile — a wave learns
+    // both with the family it has to load anyway, instead of walking round_begin[] load by dependent load
+    uint64_t round_end;
+    uint32_t round, pad_;
 };
 
 // Running state of one query on the device: moment triples folded round by round, the CLT
@@ -110,7 +114,7 @@ constexpr int kMaxPersistRounds = 32;
 constexpr int kPersistThreads = 1024;  // one workgroup of 16 waves per CU
 constexpr int kPersistWaves = kPersistThreads / 64;
 constexpr int kMaxPersistGrid = 256;   // workgroups (a power of two <= CU count)
-constexpr int kPersistInlineFams = 22; // family tables up to this size travel in the kernel arguments (4 KB of them at most)
+constexpr int kPersistInlineFams = 20; // family tables up to this size travel in the kernel arguments (4 KB of them at most)
 constexpr int kDecSteps = 32;          // monitor: steps (8 workgroup partials each) per batch of loads
 
 static_assert(kMaxPersistGrid / 8 <= kDecSteps, "a round's slots fit the monitor's window");
@@ -154,6 +158,9 @@ struct PersistLaunch {
     QueryState* rehearsal_state;     // where the monitor's rehearsal writes (never read)
     aqe_result* rehearsal_result;
     unsigned long long* stamps;  // diagnostics only (AQE_PERSIST_STAMPS): s_memrealtime marks, else null
+    // first tile of family i (0xffffffff past the table): a sweeper finds a tile's family by comparing against these
+    // — kernel arguments at fixed offsets, in registers after the prologue's one batch of loads; no search through memory
+    uint32_t fam_begin[kPersistInlineFams];
     DevFamily fams[kPersistInlineFams];
 };
 

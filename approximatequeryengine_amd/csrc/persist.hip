@@ -136,9 +136,10 @@ struct FoldOut {
 // Inlined into monitor_main: as a called function it would save and restore callee-saved registers through
 // scratch — a memory round trip on the way out.
 //
-// warm != 0: a rehearsal while the monitor has nothing to do — same instructions, nothing folded, results
+// warm != 0 (1: the estimate worked out beside the rules, 2: worked out after the decision — an early stop, the
+// head form): a rehearsal while the monitor has nothing to do — same instructions, nothing folded, results
 // written to a scratch area — so that the real call finds its code in the instruction cache.
-__device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigned p_newv, double run, bool warm) {
+__device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigned p_newv, double run, unsigned warm) {
     u64 kbits = uniform64(reinterpret_cast<u64>(Kv));
     asm volatile("" : "+s"(kbits));
     const KargPtr K = (KargPtr)kbits;
@@ -221,7 +222,7 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
             st.visited = tot[6];
             aqe_result res{};
             // (only when this fold is certain to end the query; an early stop works its result out afterwards)
-            const bool result_now = with_result && ((p_new == rounds && !tslot) || warm);
+            const bool result_now = with_result && ((p_new == rounds && !tslot) || warm == 1u);  // (warm == 2 rehearses the late estimate below)
             double tup[7] = {0, 0, 0, 0, 0, 0, 0};  // the top-up slot's own total
             if (tslot) {
 #pragma unroll
@@ -231,6 +232,7 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
                 if (fp.is_clt && lane < rounds_j) code = clt_rules(tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], fp);
                 if (result_now) res = make_result(st, fin);
             }
+            stamp_round(K->stamps, warm ? 0u : p_new - 1u, 7, lane);
             const unsigned long long stops = __ballot(code != 0);
             unsigned last_round = ~0u;
             if (warm) last_round = 0u;
@@ -324,12 +326,13 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
     unsigned judged = 0, polls = 0;  // rounds [0, judged) are folded and judged
     double run = 0.0;                // this lane's running sum over every step folded so far
     // nothing can be complete yet: rehearse the fold, so that the real one finds its code in the instruction cache
-    (void)monitor_fold(K, 0u, 0u, 0.0, true);
+#pragma nounroll
+    for (unsigned wm = 1; wm <= 2u; ++wm) (void)monitor_fold(K, 0u, 0u, 0.0, wm);
     for (;;) {
         unsigned complete = monitor_poll(K, judged);
         if (K->topup_slot != 0 && complete != K->rounds) complete = judged;  // that form is judged once, when everything is in
         if (complete > judged) {
-            const FoldOut o = monitor_fold(K, judged, complete, run, false);  // does not return if the query ends here
+            const FoldOut o = monitor_fold(K, judged, complete, run, 0u);  // does not return if the query ends here
             run = o.run;
             judged = o.judged;
         } else if (++polls > (1u << 21)) {  // cannot happen: every workgroup publishes every round it owns tiles of
@@ -375,11 +378,12 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
     // sweep's registers for the loads).  Sweeper v owns tiles v, v + V, v + 2 V, ...
     Acc acc;
     unsigned r = 0;
+    u64 round_end = 0;  // end tile of round r
     bool open = false;  // the wave has swept at least one tile of round r and not yet left it
     u64 t = w - 1u;
     for (;;) {
         const bool have = t < P.ntiles;
-        if (open && (!have || t >= K->round_begin[r + 1])) {  // round r is finished for this wave
+        if (open && (!have || t >= round_end)) {  // round r is finished for this wave
             if (!synced) { __syncthreads(); synced = true; }
             leave_round(P, K, r, acc, lane, wave, lds_part, lds_cnt);
             acc = Acc{};
@@ -387,10 +391,26 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
             continue;
         }
         if (!have) break;
-        while (t >= K->round_begin[r + 1]) ++r;  // move to tile t's round
         // should_stop (DB.cpp:930/987): one sc1 load issued beside the tile's own loads
         const unsigned long long sw = __hip_atomic_load(&P.ctl->stop_word, AQE_RLX);
-        if (lfams) sweep_tile(P.sw, lfams, t, lane, ~0ull, acc); else sweep_tile(P.sw, kfams, t, lane, ~0ull, acc);
+        // Which family owns tile t, and which round is that?  Every dependent load here is a round trip on the
+        // wave's critical path (the sweep of a 10 M-row table is a handful of them), so: the families' first tiles
+        // are compared out of kernel-argument registers, and the family record itself names its round.
+        if (lfams) {
+            const DevFamily& F = lfams[find_family(lfams, P.sw.nfam, t)];
+            r = __builtin_amdgcn_readfirstlane(F.round);
+            round_end = uniform64(F.round_end);
+            sweep_family(P.sw, F, t, lane, ~0ull, acc);
+        } else {
+            const unsigned t32 = static_cast<unsigned>(t);
+            unsigned i = 0;
+#pragma unroll
+            for (int k = 1; k < kPersistInlineFams; ++k) i += t32 >= P.fam_begin[k] ? 1u : 0u;
+            const auto& F = kfams[i];
+            r = F.round;
+            round_end = F.round_end;
+            sweep_family(P.sw, F, t, lane, ~0ull, acc);
+        }
         if (t + 1u == w) stamp_wave(P, 1, lane);
         stamp_wave(P, 2, lane);
         open = true;

@@ -202,6 +202,11 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
     }
     F.round_begin[S] = tiles;
     F.ntiles = tiles;
+    {   // every family names its round and where that round ends
+        size_t i = 0;
+        for (size_t r = 0; r < S; ++r)
+            for (uint32_t k = 0; k < slots[r]->nfam; ++k, ++i) { F.h_fams[i].round = static_cast<uint32_t>(r); F.h_fams[i].round_end = F.round_begin[r + 1]; }
+    }
     F.slots = static_cast<uint32_t>(S);
     // Every wave but the monitor (wave 0 of workgroup 0) is a sweeper: sweeper v (physical wave v + 1) owns
     // tiles v, v + V, ...  The workgroups that own tiles of a slot form ONE cyclic run of workgroup ids (tiles
@@ -477,8 +482,12 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     p->last_exec = totals_only ? 2 : 1;
     p->last_grid = F.grid;
     a.out_totals = out_totals;
-    a.inline_fams = F.h_fams.size() <= static_cast<size_t>(kPersistInlineFams) ? 1u : 0u;
-    if (a.inline_fams) std::copy(F.h_fams.begin(), F.h_fams.end(), a.fams);
+    a.inline_fams = (F.h_fams.size() <= static_cast<size_t>(kPersistInlineFams) && F.ntiles < 0xffffffffull) ? 1u : 0u;
+    if (a.inline_fams) {
+        std::copy(F.h_fams.begin(), F.h_fams.end(), a.fams);
+        for (size_t i = 0; i < static_cast<size_t>(kPersistInlineFams); ++i)
+            a.fam_begin[i] = i < F.h_fams.size() ? static_cast<uint32_t>(F.h_fams[i].tile_begin) : 0xffffffffu;
+    }
     if (c->d_stamps) {
         HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds), s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -591,7 +600,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
             for (size_t r = 0; r < p->rounds.size(); ++r) {
                 const unsigned long long* q = &st[8 * W + 8 * r];
                 if (r == 0 && q[6]) std::fprintf(f, " rehearsal done %.2f |", us(q[6]));
-                if (q[3]) std::fprintf(f, " ..r%zu: seen %.2f folded %.2f judged %.2f |", r, us(q[3]), us(q[4]), us(q[5]));
+                if (q[3]) std::fprintf(f, " ..r%zu: seen %.2f folded %.2f rules %.2f judged %.2f |", r, us(q[3]), us(q[4]), us(q[7]), us(q[5]));
             }
             std::fprintf(f, "\n");
             std::fclose(f);
