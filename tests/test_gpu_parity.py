@@ -250,6 +250,74 @@ def test_clt_head_form_misprediction_is_continued(nat, oracle, table):
         eng.close()
 
 
+def test_clt_decision_table_near_the_thresholds(nat, oracle, engines):
+    """The device decides both rules (DB.cpp:936-961, 993-1016) by comparisons cleared of divisions and falls back
+    to the reference's expressions inside a guard band.  Crafted moment vectors are folded through the stepwise
+    API (k_update) at relative distances 1e-2 ... 1e-15 on either side of each threshold: well outside the band the
+    oracle's decision function is the expectation; everywhere the literal expressions, evaluated on the very
+    moments the device sees, are."""
+    import torch
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(100_000)
+    c = eng.info().shift
+    z = oracle.lib.aqo_clt_zscore(0.95)
+
+    def literal(n_a, sd_a, qd_a, n_b, sd_b, qd_b, e, base):
+        n, sd, qd = n_a + n_b, sd_a + sd_b, qd_a + qd_b
+        if n >= 30:
+            mean, m2 = c + sd / n, max(qd - sd * sd / n, 0.0)
+            err = (z * math.sqrt(m2 / (n - 1.0) / n) / mean) * 100.0
+            if err <= e and n >= 50:
+                return 1
+        if n_b >= 20 and n_a >= 30:
+            ma, mb = c + sd_a / n_a, c + sd_b / n_b
+            if ma > 0 and abs(mb - ma) / ma <= e / 100.0 and n_a >= base // 2:
+                return 2
+        return 0
+
+    def vec(n_a, mean_a, var_a, n_b, mean_b, var_b):
+        out = []
+        for n, mean, var in ((n_a, mean_a, var_a), (n_b, mean_b, var_b)):
+            sd = n * (mean - c)
+            out += [float(n), sd, var * (n - 1) + sd * sd / n if n else 0.0]
+        return out + [float(n_a + n_b), 0.0]
+
+    e = 2.0
+    q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=1024, clt_growth=2)
+    plan = eng.plan(q)
+    base = int(100_000 * 20.0 / 100)
+    dev = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
+    cases = []
+    for n in (40, 60, 5000):
+        mean = 500.0
+        var0 = (e * mean / (100.0 * z)) ** 2 * n  # err == e exactly (in exact arithmetic)
+        for d in (0.0, 1e-15, 1e-13, 1e-10, 1e-8, 1e-5, 1e-2):
+            for sgn in (-1.0, 1.0):
+                cases.append(("A", d, vec(n // 2, mean, var0 * (1 + sgn * d), n - n // 2, mean, var0 * (1 + sgn * d))))
+    for n_a in (base // 2 - 1, base // 2, base):
+        mean_a = 480.0
+        for d in (0.0, 1e-15, 1e-12, 1e-9, 1e-5, 1e-2):
+            for sgn in (-1.0, 1.0):
+                mean_b = mean_a * (1 + (e / 100.0) * (1 + sgn * d))
+                cases.append(("B", d, vec(n_a, mean_a, 1e7, 25, mean_b, 1e7)))  # huge variance: rule A stays off
+    cases.append(("neg", 1.0, vec(40, -5.0, 1.0, 40, -5.0, 1.0)))  # mean < 0: err < 0 <= e in the reference's expression
+    seen = set()
+    for kind, d, v in cases:
+        dev.copy_(torch.tensor(v, dtype=torch.float64))
+        torch.cuda.synchronize()
+        plan.enqueue_update(0, dev.data_ptr())
+        plan.enqueue_finalize()
+        got = plan.fetch().converged
+        assert got == literal(*v[:6], e, base), (kind, d, v)
+        seen.add((kind, got))
+        if kind == "A" and d >= 1e-5:
+            n = int(v[0] + v[3])
+            mean, m2 = c + (v[1] + v[4]) / n, (v[2] + v[5]) - (v[1] + v[4]) ** 2 / n
+            assert (got == 1) == bool(oracle.lib.aqo_clt_fast_rule(n, mean, m2 / (n - 1), z, e)) or n < 50
+    assert {("A", 0), ("A", 1), ("B", 0), ("B", 2), ("neg", 1)} <= seen
+    plan.close()
+
+
 def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
     """Where the reference divides by zero (DB.cpp:927, 985, 993) the C ABI returns AQE_ERR_INVALID."""
     from approximatequeryengine_amd.engine import make_query
