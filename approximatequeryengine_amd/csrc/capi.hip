@@ -136,26 +136,21 @@ int aqe_group_key_range(aqe_ctx* c, int group_column, int32_t* key_min, int32_t*
     return AQE_OK;
 }
 
-int aqe_grouped_enqueue_bins(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, double* dev_bins, void* stream) {
-    if (!c) return AQE_ERR_INVALID;
-    int rc = grouped_args(c, q, group_column);
-    if (rc != AQE_OK) return rc;
-    if (!dev_bins || nbins == 0 || nbins > static_cast<uint32_t>(kMaxGroupBins)) return fail(c, AQE_ERR_INVALID, "dev_bins null or nbins outside 1..1024");
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+namespace {
+// The sweep of a grouped reduction: this shard's sampled rows binned per workgroup into c->grp_partial
+// ([*grid][nbins][4]); *grid == 0 when nothing of the sample lies in this shard.
+int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, hipStream_t s, unsigned* grid_out) {
+    *grid_out = 0;
     aqe_plan* p = nullptr;
     aqe_query in_place = *q;
     in_place.flags |= AQE_Q_NO_LAYOUT;  // the key column is read beside the amounts: the families must address rows
-    rc = cached_plan(c, &in_place, &p);
+    int rc = cached_plan(c, &in_place, &p);
     if (rc != AQE_OK) return rc;
     if (p->host.is_random || p->host.is_clt || p->host.on_sorted || p->rounds.size() > 1)
         return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction takes a single-round family sampler (exact, stride, rowid-mod, block, page, pointer, region ...)");
     for (const DevFamily& f : p->h_fams)
         if (f.flags & AQE_F_PAIR) return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction does not take pair families");
-    if (p->rounds.empty() || c->n_local == 0 || p->rounds[0].ntiles == 0) {  // nothing of the sample in this shard
-        HIPCHK(c, hipMemsetAsync(dev_bins, 0, static_cast<size_t>(nbins) * 4 * sizeof(double), s));
-        return AQE_OK;
-    }
+    if (p->rounds.empty() || c->n_local == 0 || p->rounds[0].ntiles == 0) return AQE_OK;  // nothing of the sample in this shard
     rc = ensure_keys(c, group_column);
     if (rc != AQE_OK) return rc;
     const int k = group_column - 1;
@@ -172,7 +167,44 @@ int aqe_grouped_enqueue_bins(aqe_ctx* c, const aqe_query* q, int group_column, i
         c->grp_partial_bytes = need;
     }
     HIPCHK(c, launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, c->keycol[k], key_min, nbins, c->grp_partial, grid, s));
-    HIPCHK(c, launch_grouped_sum(c->grp_partial, grid, nbins, dev_bins, s));
+    *grid_out = grid;
+    return AQE_OK;
+}
+
+// results leave through a pinned host buffer the device writes directly (no copy launch on the way out)
+int ensure_group_out(aqe_ctx* c) {
+    if (c->grp_out) return AQE_OK;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->grp_out_host), kMaxGroupBins * sizeof(aqe_group_result), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->grp_out), c->grp_out_host, 0));
+    return AQE_OK;
+}
+
+int collect_groups(aqe_ctx* c, uint32_t nbins, aqe_group_result* out, uint32_t cap, uint32_t* n_groups) {
+    uint32_t g = 0;
+    for (uint32_t b = 0; b < nbins; ++b) {
+        const aqe_group_result& r = c->grp_out_host[b];
+        if (r.visited == 0) continue;  // a key nobody sampled
+        if (g < cap) out[g] = r;
+        ++g;
+    }
+    *n_groups = g;
+    if (g > cap) return fail(c, AQE_ERR_CAPACITY, "more groups than the caller's buffer holds (n_groups has the count)");
+    return AQE_OK;
+}
+}  // namespace
+
+int aqe_grouped_enqueue_bins(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, double* dev_bins, void* stream) {
+    if (!c) return AQE_ERR_INVALID;
+    int rc = grouped_args(c, q, group_column);
+    if (rc != AQE_OK) return rc;
+    if (!dev_bins || nbins == 0 || nbins > static_cast<uint32_t>(kMaxGroupBins)) return fail(c, AQE_ERR_INVALID, "dev_bins null or nbins outside 1..1024");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    unsigned grid = 0;
+    rc = grouped_sweep(c, q, group_column, key_min, nbins, s, &grid);
+    if (rc != AQE_OK) return rc;
+    if (grid == 0) HIPCHK(c, hipMemsetAsync(dev_bins, 0, static_cast<size_t>(nbins) * 4 * sizeof(double), s));
+    else HIPCHK(c, launch_grouped_sum(c->grp_partial, grid, nbins, dev_bins, s));
     return AQE_OK;
 }
 
@@ -184,20 +216,11 @@ int aqe_grouped_finish(aqe_ctx* c, const aqe_query* q, int32_t key_min, uint32_t
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     *n_groups = 0;
-    if (!c->grp_out) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_out), kMaxGroupBins * sizeof(aqe_group_result)));
-    std::vector<aqe_group_result> host(nbins);
+    int rc = ensure_group_out(c);
+    if (rc != AQE_OK) return rc;
     HIPCHK(c, launch_grouped_finish(dev_bins, nbins, key_min, c->shift, q->sample_percent, q->agg, c->grp_out, s));
-    HIPCHK(c, hipMemcpyAsync(host.data(), c->grp_out, nbins * sizeof(aqe_group_result), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    uint32_t g = 0;
-    for (const aqe_group_result& r : host) {
-        if (r.visited == 0) continue;  // a key nobody sampled
-        if (g < cap) out[g] = r;
-        ++g;
-    }
-    *n_groups = g;
-    if (g > cap) return fail(c, AQE_ERR_CAPACITY, "more groups than the caller's buffer holds (n_groups has the count)");
-    return AQE_OK;
+    return collect_groups(c, nbins, out, cap, n_groups);
 }
 
 int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_group_result* out, uint32_t cap, uint32_t* n_groups) {
@@ -213,10 +236,19 @@ int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_gro
     const int64_t span = static_cast<int64_t>(kmax) - kmin + 1;
     if (span > kMaxGroupBins) return fail(c, AQE_ERR_UNSUPPORTED, "group column spans more than 1024 distinct values");
     const uint32_t nbins = static_cast<uint32_t>(span);
-    if (!c->grp_bins) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_bins), static_cast<size_t>(kMaxGroupBins) * 4 * sizeof(double)));
-    rc = aqe_grouped_enqueue_bins(c, q, group_column, kmin, nbins, c->grp_bins, c->stream);
+    if (q->agg < AQE_SUM || q->agg > AQE_COUNT) return fail(c, AQE_ERR_INVALID, "bad agg");
+    HIPCHK(c, hipSetDevice(c->device));
+    // a world of one needs no all-reduce between the sums and the estimates: sweep, then ONE launch that adds the
+    // workgroups' bins and works every group out, straight into the pinned result buffer
+    unsigned grid = 0;
+    rc = grouped_sweep(c, q, group_column, kmin, nbins, c->stream, &grid);
     if (rc != AQE_OK) return rc;
-    return aqe_grouped_finish(c, q, kmin, nbins, c->grp_bins, c->stream, out, cap, n_groups);
+    if (grid == 0) return AQE_OK;  // nothing sampled: no groups
+    rc = ensure_group_out(c);
+    if (rc != AQE_OK) return rc;
+    HIPCHK(c, launch_grouped_sum_finish(c->grp_partial, grid, nbins, kmin, c->shift, q->sample_percent, q->agg, c->grp_out, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return collect_groups(c, nbins, out, cap, n_groups);
 }
 
 int aqe_reduce(aqe_ctx* c, const aqe_query* q, aqe_result* out) {

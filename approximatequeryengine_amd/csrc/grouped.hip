@@ -6,8 +6,10 @@
 //
 //   * keys are dense small integers (region 0..3, product_id 0..99): bin = key - key_min, at most kMaxGroupBins;
 //   * a workgroup accumulates into LDS-privatised bins.  With up to kRegBins bins (region) every lane keeps its own
-//     bins in registers and adds them to LDS once at the end — 64 lanes hammering 4 LDS addresses with atomics would
-//     serialise; with more bins (product_id) lanes add straight to LDS (ds_add_f64), where collisions are rare;
+//     bins in registers (counts as integers), the wave sums them with VALU cross-lane moves (wave_sum7) and ONE lane
+//     per value adds the wave's total to LDS — 64 lanes hammering 4 LDS addresses with atomics serialise (the
+//     first version did that in its epilogue: 23 us for a 100 k-row sample); with more bins (product_id) lanes add
+//     straight to LDS (ds_add_f64), where collisions are rare;
 //   * workgroups write their bins to a [workgroup][bin][4] buffer, k_grouped_sum adds them per bin in workgroup
 //     order (this is what ranks all-reduce in the multi-GPU form: the bins are additive), and k_grouped_finish
 //     works out mean, variance, estimate and interval (executor.cpp:277-296).
@@ -70,7 +72,9 @@ struct GroupLaunch {
 // One wave folds one tile of the family table (the decomposition add_family made: kDenseTileOrdinals for dense
 // families, kTileOrdinals otherwise; PAIR families do not occur in single-round samplers).
 __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
-    extern __shared__ double bins[];  // [nbins][4]
+    // [4][nbins], component-major: the lanes of a wave mostly hold consecutive keys (product_id = row % 100), and
+    // consecutive f64 words spread over all LDS banks — [nbins][4] put them 32 bytes apart, on a quarter of the banks
+    extern __shared__ double bins[];
     __shared__ DevFamily lds_fams[kMaxLdsFams];
     for (unsigned i = threadIdx.x; i < a.nbins * 4; i += kBlockThreads) bins[i] = 0.0;
     const DevFamily* fams = stage_families(a.sw, lds_fams);
@@ -79,9 +83,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
     const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
     const bool in_regs = a.nbins <= kRegBins;
-    double rn[kRegBins], rs[kRegBins], rq[kRegBins], rv[kRegBins];
+    const unsigned nb = a.nbins;  // uniform: bins past it cost nothing
+    double rs[kRegBins], rq[kRegBins];
+    unsigned cn[kRegBins], cv[kRegBins];
 #pragma unroll
-    for (unsigned b = 0; b < kRegBins; ++b) rn[b] = rs[b] = rq[b] = rv[b] = 0.0;
+    for (unsigned b = 0; b < kRegBins; ++b) { rs[b] = rq[b] = 0.0; cn[b] = cv[b] = 0u; }
 
     for (u64 t = wave_id; t < a.ntiles; t += wave_stride) {
         unsigned lo = 0, hi = a.sw.nfam;
@@ -118,37 +124,47 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
                 if (in_regs) {
 #pragma unroll
                     for (unsigned g = 0; g < kRegBins; ++g) {
-                        const bool mine = ok[k] && b == g;
-                        rv[g] += mine ? 1.0 : 0.0;
-                        rn[g] += (mine && pass) ? 1.0 : 0.0;
-                        rs[g] += (mine && pass) ? d : 0.0;
-                        rq[g] += (mine && pass) ? d * d : 0.0;
+                        if (g < nb) {
+                            const bool mine = ok[k] && b == g, counted = mine && pass;
+                            cv[g] += mine ? 1u : 0u;
+                            cn[g] += counted ? 1u : 0u;
+                            rs[g] += counted ? d : 0.0;
+                            rq[g] += counted ? d * d : 0.0;
+                        }
                     }
                 } else if (ok[k] && b < a.nbins) {
-                    atomicAdd(&bins[b * 4 + 3], 1.0);
+                    atomicAdd(&bins[3 * nb + b], 1.0);
                     if (pass) {
-                        atomicAdd(&bins[b * 4 + 0], 1.0);
-                        atomicAdd(&bins[b * 4 + 1], d);
-                        atomicAdd(&bins[b * 4 + 2], d * d);
+                        atomicAdd(&bins[b], 1.0);
+                        atomicAdd(&bins[nb + b], d);
+                        atomicAdd(&bins[2 * nb + b], d * d);
                     }
                 }
             }
         }
     }
     if (in_regs) {
+        // the wave's totals, seven values at a time (value i = bins[i]: bin i / 4, component i % 4); lane 8 c of a
+        // batch holds its c-th total and adds it to the workgroup's bin
+        constexpr unsigned kVals = kRegBins * 4;
 #pragma unroll
-        for (unsigned g = 0; g < kRegBins; ++g) {
-            if (g < a.nbins && rv[g] != 0.0) {
-                atomicAdd(&bins[g * 4 + 0], rn[g]);
-                atomicAdd(&bins[g * 4 + 1], rs[g]);
-                atomicAdd(&bins[g * 4 + 2], rq[g]);
-                atomicAdd(&bins[g * 4 + 3], rv[g]);
+        for (unsigned i0 = 0; i0 < kVals; i0 += 7) {
+            if (i0 < nb * 4) {
+                double v[7];
+#pragma unroll
+                for (unsigned c7 = 0; c7 < 7; ++c7) {
+                    const unsigned i = i0 + c7, g = i / 4, comp = i % 4;  // compile-time after unrolling
+                    v[c7] = i >= kVals ? 0.0 : comp == 0 ? static_cast<double>(cn[g]) : comp == 1 ? rs[g] : comp == 2 ? rq[g] : static_cast<double>(cv[g]);
+                }
+                const double total = wave_sum7(v, lane);
+                const unsigned i = i0 + (static_cast<unsigned>(lane) >> 3);
+                if ((lane & 7) == 0 && lane < 56 && i < nb * 4 && total != 0.0) atomicAdd(&bins[(i % 4) * nb + i / 4], total);
             }
         }
     }
     __syncthreads();
     double* out = a.partial + static_cast<size_t>(blockIdx.x) * a.nbins * 4;
-    for (unsigned i = threadIdx.x; i < a.nbins * 4; i += kBlockThreads) out[i] = bins[i];
+    for (unsigned i = threadIdx.x; i < a.nbins * 4; i += kBlockThreads) out[i] = bins[(i % 4) * nb + i / 4];  // out: [nbins][4]
 }
 
 // One wave per (bin, component): lane l adds the workgroups l, l + 64, ... in order, then a fixed xor butterfly
@@ -163,14 +179,10 @@ __global__ __launch_bounds__(64) void k_grouped_sum(const double* __restrict__ p
     if (lane == 0) bins[i] = t;
 }
 
-// One thread per bin: estimate and interval of the group from its (all-reduced) sums.
-__global__ __launch_bounds__(64) void k_grouped_finish(const double* __restrict__ bins, unsigned nbins, int32_t key_min, double shift, double pct,
-                                                       int agg, aqe_group_result* __restrict__ out) {
-    const unsigned b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= nbins) return;
-    const double n = bins[b * 4 + 0], sd = bins[b * 4 + 1], qd = bins[b * 4 + 2], visited = bins[b * 4 + 3];
+// Estimate and interval of one group from its sums (executor.cpp:277-296).
+__device__ __forceinline__ aqe_group_result group_result(double n, double sd, double qd, double visited, int64_t key, double shift, double pct, int agg) {
     aqe_group_result r;
-    r.key = static_cast<int64_t>(key_min) + b;
+    r.key = key;
     r.n = static_cast<uint64_t>(n);
     r.visited = static_cast<uint64_t>(visited);
     const double c = shift;
@@ -189,7 +201,32 @@ __global__ __launch_bounds__(64) void k_grouped_finish(const double* __restrict_
     r.value = value;
     r.ci_lower = value - margin;
     r.ci_upper = value + margin;
-    out[b] = r;
+    return r;
+}
+
+// One thread per bin: estimate and interval of the group from its (all-reduced) sums.
+__global__ __launch_bounds__(64) void k_grouped_finish(const double* __restrict__ bins, unsigned nbins, int32_t key_min, double shift, double pct,
+                                                       int agg, aqe_group_result* __restrict__ out) {
+    const unsigned b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nbins) return;
+    out[b] = group_result(bins[b * 4 + 0], bins[b * 4 + 1], bins[b * 4 + 2], bins[b * 4 + 3], static_cast<int64_t>(key_min) + b, shift, pct, agg);
+}
+
+// Single-GPU form: sum and finish in one launch.  One wave per bin: lane l adds the workgroups l, l + 64, ... of each
+// of the bin's four components (the same order and butterfly as k_grouped_sum), then lane 0 works the group out.
+__global__ __launch_bounds__(64) void k_grouped_sum_finish(const double* __restrict__ partial, unsigned nblocks, unsigned nbins, int32_t key_min,
+                                                           double shift, double pct, int agg, aqe_group_result* __restrict__ out) {
+    const unsigned b = blockIdx.x, lane = threadIdx.x;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (unsigned w = lane; w < nblocks; w += 64) {
+        const double* p = partial + (static_cast<size_t>(w) * nbins + b) * 4;
+#pragma unroll
+        for (int cmp = 0; cmp < 4; ++cmp) t[cmp] += p[cmp];
+    }
+#pragma unroll
+    for (int cmp = 0; cmp < 4; ++cmp)
+        for (int off = 32; off > 0; off >>= 1) t[cmp] += __shfl_xor(t[cmp], off, 64);
+    if (lane == 0) out[b] = group_result(t[0], t[1], t[2], t[3], static_cast<int64_t>(key_min) + b, shift, pct, agg);
 }
 
 inline unsigned blocks_for(u64 work, u64 per_block, unsigned cap) {
@@ -230,6 +267,12 @@ hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t*
 
 hipError_t launch_grouped_sum(const double* partial, unsigned nblocks, uint32_t nbins, double* bins, hipStream_t s) {
     hipLaunchKernelGGL(k_grouped_sum, dim3(nbins * 4), dim3(64), 0, s, partial, nblocks, nbins, bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_grouped_sum_finish(const double* partial, unsigned nblocks, uint32_t nbins, int32_t key_min, double shift, double pct, int agg,
+                                     aqe_group_result* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_grouped_sum_finish, dim3(nbins), dim3(64), 0, s, partial, nblocks, nbins, key_min, shift, pct, agg, out);
     return hipGetLastError();
 }
 

@@ -70,8 +70,8 @@ struct aqe_ctx {
     std::vector<hipStream_t> lanes;         // side streams of the batched multi-GPU form (aqe_batch), made on first use
     double* grp_partial = nullptr;          // GROUP BY scratch, grown on demand and kept with the context
     size_t grp_partial_bytes = 0;
-    aqe_group_result* grp_out = nullptr;    // [aqe::kMaxGroupBins]
-    double* grp_bins = nullptr;             // [aqe::kMaxGroupBins][4] (single-GPU form)
+    aqe_group_result* grp_out = nullptr;    // [aqe::kMaxGroupBins]: device address of grp_out_host
+    aqe_group_result* grp_out_host = nullptr;  // pinned, mapped: the finishing kernel writes the groups here
     bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
     int64_t first_id = 0;
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)

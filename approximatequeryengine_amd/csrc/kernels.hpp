@@ -210,6 +210,8 @@ unsigned grouped_grid(uint64_t ntiles);
 hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t* keys, int32_t key_min, uint32_t nbins, double* partial,
                           unsigned grid, hipStream_t s);
 hipError_t launch_grouped_sum(const double* partial, unsigned nblocks, uint32_t nbins, double* bins, hipStream_t s);
+hipError_t launch_grouped_sum_finish(const double* partial, unsigned nblocks, uint32_t nbins, int32_t key_min, double shift, double pct, int agg,
+                                     aqe_group_result* out, hipStream_t s);
 hipError_t launch_grouped_finish(const double* bins, uint32_t nbins, int32_t key_min, double shift, double pct, int agg, aqe_group_result* out,
                                  hipStream_t s);
 

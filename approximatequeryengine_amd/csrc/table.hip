@@ -362,8 +362,7 @@ void aqe_destroy(aqe_ctx* c) {
     free_table(c);
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->grp_partial) (void)hipFree(c->grp_partial);
-    if (c->grp_out) (void)hipFree(c->grp_out);
-    if (c->grp_bins) (void)hipFree(c->grp_bins);
+    if (c->grp_out_host) (void)hipHostFree(c->grp_out_host);
     for (hipStream_t s : c->lanes) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
