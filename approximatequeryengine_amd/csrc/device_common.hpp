@@ -16,6 +16,10 @@ namespace {
 
 typedef unsigned long long u64;
 
+// kernel arguments read through the kernarg segment pointer (constant address space): dynamic indexing stays in
+// scalar loads instead of making hipcc copy the by-value parameter's arrays to scratch
+#define AQE_KARG __attribute__((address_space(4)))
+
 __device__ __forceinline__ u64 uniform64(u64 x) {
     unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(x));
     unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(x >> 32));

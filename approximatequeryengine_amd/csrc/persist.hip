@@ -41,7 +41,6 @@ namespace {
 // The launch descriptor is indexed dynamically (round_begin[r], fams[i]).  Indexing the by-value kernel
 // parameter would make hipcc copy the arrays to scratch; reading them through the kernarg segment pointer
 // (constant address space) keeps them in scalar loads.
-#define AQE_KARG __attribute__((address_space(4)))
 typedef const AQE_KARG PersistLaunch* KargPtr;
 typedef const AQE_KARG DevFamily* KargFams;
 
