@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -139,6 +140,8 @@ struct aqe_plan {
     const double* view_topup = nullptr;   // ... and the top-up's
     unsigned grid = 0;          // workgroups of the persistent sweep for this plan (the context's, or half of it)
     SweepForm head;             // the first rounds only, on a few workgroups: the single launch of a query predicted to stop early
+    volatile unsigned long long* h_seq = nullptr;  // behind h_result: the epoch of the launch whose result is there
+    unsigned long long poll_epoch = 0;  // != 0: the last execution ends with a persistent launch of this epoch: fetch() may poll h_seq
     uint32_t last_grid = 0;     // workgroups of the last persistent launch (diagnostics)
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front

@@ -120,6 +120,23 @@ constexpr int kDecSteps = 32;          // monitor: steps (8 workgroup partials e
 static_assert(kMaxPersistGrid / 8 <= kDecSteps, "a round's slots fit the monitor's window");
 constexpr unsigned long long kSlotAlways = ~0ull;  // flag word of a pad slot: always "published"
 
+// The word a persistent launch writes beside its result in pinned host memory: a hash of the launch's epoch and of
+// every field of the result.  The stores of the result and of this word may become visible to the host in any order
+// (they leave through different memory channels), so the host does not wait for a flag: it reads result and word
+// until they agree — which they do exactly when all of this launch's stores have landed.
+__host__ __device__ inline unsigned long long result_check(const aqe_result& r, unsigned long long epoch) {
+    unsigned long long h = epoch;
+    auto mix = [&h](unsigned long long w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
+    auto bits = [](double d) { unsigned long long u; __builtin_memcpy(&u, &d, 8); return u; };
+    mix(bits(r.value)); mix(bits(r.ci_lower)); mix(bits(r.ci_upper)); mix(bits(r.margin));
+    mix(bits(r.sum)); mix(bits(r.sumsq)); mix(bits(r.mean)); mix(bits(r.m2));
+    mix(r.n); mix(r.visited); mix(r.topup);
+    mix(static_cast<unsigned long long>(static_cast<uint32_t>(r.converged)) | (static_cast<unsigned long long>(static_cast<uint32_t>(r.rounds)) << 32));
+    mix(bits(r.kernel_ms)); mix(r.bytes_algorithmic);
+    mix(static_cast<unsigned long long>(static_cast<uint32_t>(r.device_status)) | (static_cast<unsigned long long>(static_cast<uint32_t>(r.topup_pending)) << 32));
+    return h;
+}
+
 // Control block in device memory (zeroed once per plan).
 struct PersistCtl {
     unsigned long long stop_word;  // (epoch << 8) | 1 once the monitor has ended the query
@@ -157,6 +174,7 @@ struct PersistLaunch {
     aqe_result* result;
     QueryState* rehearsal_state;     // where the monitor's rehearsal writes (never read)
     aqe_result* rehearsal_result;
+    unsigned long long* result_seq;  // beside the result (pinned host memory): receives result_check(result, epoch) — what fetch() polls
     unsigned long long* stamps;  // diagnostics only (AQE_PERSIST_STAMPS): s_memrealtime marks, else null
     // first tile of family i (0xffffffff past the table): a sweeper finds a tile's family by comparing against these
     // — kernel arguments at fixed offsets, in registers after the prologue's one batch of loads; no search through memory

@@ -259,10 +259,15 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
                     res.topup_pending = goes_on ? 2 : due ? 1 : 0;  // 2: the host launches the plan's remaining rounds
                     state_store(warm ? K->rehearsal_state : K->state, st);
                     if (with_result) *(warm ? K->rehearsal_result : K->result) = res;
-                    if (code != 0 && !warm) {  // waves are still sweeping: state and result are out before should_stop is
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_store(&K->ctl->stop_word, (epoch << 8) | 1ull, AQE_RLX);
-                    }  // (samples exhausted: nobody is left to stop, and the end of the launch publishes the stores)
+                    if (!warm) {
+                        // the host polls the pinned result instead of waiting for the end of the launch, several
+                        // microseconds later: the check word tells it when every field has landed (kernels.hpp)
+                        if (with_result) __hip_atomic_store(K->result_seq, result_check(res, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (code != 0) {  // waves are still sweeping: state and result are out before should_stop is
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __hip_atomic_store(&K->ctl->stop_word, (epoch << 8) | 1ull, AQE_RLX);
+                        }  // (samples exhausted: nobody is left to stop, and the end of the launch publishes the stores)
+                    }
                 }
                 if (!warm) {
                     stamp_round(K->stamps, p_new - 1u, 5, lane);
