@@ -39,6 +39,14 @@ __device__ __forceinline__ void block_sum7(double (&v)[7], double (*red)[kVec]) 
     }
 }
 
+// The launch that finishes a query writes the result and, for a host that polls the pinned result instead of waiting
+// for the end of the launch, the check word beside it (kernels.hpp, result_check).
+__device__ __forceinline__ void publish_result(const QueryState& st, const RoundLaunch& a) {
+    const aqe_result r = make_result(st, a.fin);
+    *a.result = r;
+    if (a.result_seq) __hip_atomic_store(a.result_seq, result_check(r, a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Thread 0 of the folding workgroup: write the reduced vector, fold it into the running state
 // (starting from zero on a query's first launch), and finish the query on its last launch.
 __device__ __forceinline__ void fold_and_finish(const double (&tot)[7], const RoundLaunch& a) {
@@ -55,7 +63,7 @@ __device__ __forceinline__ void fold_and_finish(const double (&tot)[7], const Ro
         if (a.reset_state) st = QueryState{}; else st = *a.state;
         fold(st, vec, a.fold);
         *a.state = st;
-        if (a.do_finalize) finalize(st, a.fin, a.result);
+        if (a.do_finalize) publish_result(st, a);
     }
 }
 
@@ -127,7 +135,7 @@ __device__ __forceinline__ bool launch_is_live(const RoundLaunch& a, u64& ord_li
     }
     if (!live && a.fused && a.do_finalize && blockIdx.x == 0 && threadIdx.x == 0) {
         QueryState st = *a.state;
-        finalize(st, a.fin, a.result);
+        publish_result(st, a);
     }
     return live;
 }

@@ -107,6 +107,8 @@ struct RoundLaunch {
     FoldParams fold;
     FinalizeParams fin;
     aqe_result* result;
+    unsigned long long epoch;        // with result_seq: the launch that finishes the query also writes result_check(result, epoch)
+    unsigned long long* result_seq;  // beside the (pinned) result, or null
 };
 
 // ---- persistent single-launch sweep of a multi-round (CLT) query: persist.hip ------------------

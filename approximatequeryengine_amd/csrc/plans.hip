@@ -126,7 +126,7 @@ namespace {
 // `index` is the launch's position in the query: rounds 0..R-1, then the top-up.  The first launch
 // folds into a zeroed state (no memset), later CLT launches test should_stop on entry, and in the fused
 // single-GPU form the last launch also writes the result.
-RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec) {
+RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, unsigned long long epoch = 0) {
     RoundLaunch a{};
     a.sw = sweep_common(p, p->d_fams ? p->d_fams + L.fam_offset : nullptr, L.nfam, topup);
     a.ntiles = L.ntiles;
@@ -142,6 +142,10 @@ RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index,
     a.fold = fold_params(p, topup);
     a.fin = finalize_params(p);
     a.result = p->d_result;
+    if (epoch) {  // the host will poll for this execution's result (never for a captured launch: its arguments are frozen)
+        a.epoch = epoch;
+        a.result_seq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p->d_result) + (reinterpret_cast<const volatile char*>(p->h_seq) - reinterpret_cast<const char*>(p->h_result)));
+    }
     return a;
 }
 
@@ -158,10 +162,11 @@ namespace {
 
 hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStream_t>(stream) : p->ctx->stream; }
 
-int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, hipStream_t s) {
+int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, hipStream_t s, unsigned long long epoch = 0) {
     aqe_ctx* c = p->ctx;
     if (!topup && index == 0) p->last_exec = 0;
-    RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec);
+    if (!epoch) p->poll_epoch = 0;  // this launch writes no check word: whatever it finishes is fetched the ordinary way
+    RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec, epoch);
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
     hipEvent_t e0 = prof ? p->lev[2 * p->lev_used] : nullptr, e1 = prof ? p->lev[2 * p->lev_used + 1] : nullptr;
     if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s, e0, e1));
@@ -510,6 +515,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
     if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
     p->lev_used = 0;
     p->poll_epoch = 0;
+    unsigned long long plain_epoch = 0;
     bool topup_done = false;
     if (p->rounds.empty()) {  // nothing to sample (empty table / zero target): a zero state, finalized
         HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), s));
@@ -543,15 +549,17 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             HIPCHK(c, hipGraphLaunch(p->round_graph, s));
             topup_done = true;
         } else {
+            plain_epoch = c->epoch++;  // launch by launch: the one that finishes the query writes the check word
             for (uint32_t i = 0; i < p->rounds.size(); ++i) {
-                int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
+                int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s, plain_epoch);
                 if (rc != AQE_OK) return rc;
             }
+            p->poll_epoch = plain_epoch;
         }
         if (p->host.has_topup && !topup_done) {
-            int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+            int rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s, plain_epoch);
             if (rc != AQE_OK) return rc;
-            p->poll_epoch = 0;  // the result comes from the top-up launch
+            p->poll_epoch = plain_epoch;  // the result comes from the top-up launch (behind a persistent launch: no check word)
         }
     }
     if (timed || c->d_stamps) p->poll_epoch = 0;  // timings and stamps are read after the launch has ended
@@ -567,7 +575,8 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     // launch to drain and its completion signal to travel (5 us of a 30 us closed loop).  Anything else — and a
     // result that never shows up — takes the stream.
     bool landed = false;
-    if (p->poll_epoch != 0 && p->last_exec == 1) {
+    static const bool no_poll = std::getenv("AQE_NO_POLL") != nullptr;  // diagnostics: always wait for the stream
+    if (p->poll_epoch != 0 && !no_poll) {
         const auto t0 = std::chrono::steady_clock::now();
         const volatile unsigned long long* src = reinterpret_cast<const volatile unsigned long long*>(p->h_result);
         static_assert(sizeof(aqe_result) % 8 == 0, "the result is read word by word");
@@ -581,6 +590,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
         }
         landed = landed && snap.topup_pending == 0 && snap.device_status == 0;  // more to launch, or to report: the ordinary way
     }
+    p->poll_epoch = 0;  // consumed: only aqe_plan_enqueue_all arms it
     if (!landed) HIPCHK(c, hipStreamSynchronize(s));
     if (p->last_exec == 1 && p->h_result->topup_pending == 2) {
         // the head form ran out of rounds before the query stopped (the prediction failed): the remaining rounds go
