@@ -340,7 +340,11 @@ AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
  * Either way the answer is the one the round-by-round form gives (sums to rounding). */
 AQE_API int aqe_plan_enqueue_all(aqe_plan* plan, void* stream);
 AQE_API int aqe_plan_reset(aqe_plan* plan, void* stream); /* re-arm a plan for another execution */
-AQE_API int aqe_plan_fetch(aqe_plan* plan, aqe_result* out, void* stream); /* synchronises */
+/* Waits for the plan's last execution and returns its result.  After aqe_plan_enqueue_all the result is taken from
+ * the plan's pinned result block as soon as the finishing launch has written all of it (a check word over every field
+ * says when) — a few microseconds before that launch has drained, so `stream` need not be idle on return; any other
+ * way of running the plan, and AQE_NO_POLL=1 in the environment, waits for the stream. */
+AQE_API int aqe_plan_fetch(aqe_plan* plan, aqe_result* out, void* stream);
 /* device time between the first and last kernel of the most recent execution (HIP events) */
 AQE_API int aqe_plan_last_kernel_ms(aqe_plan* plan, float* ms);
 /* Per-launch timing for roofline reports: with profiling on, every sweep launch (rounds, top-up) of the
