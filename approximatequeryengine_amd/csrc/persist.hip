@@ -50,7 +50,7 @@ static_assert(kDecSteps == 32, "the monitor keeps one bit per step of its window
 // Diagnostics: with a stamp buffer attached, every wave marks its own slots with plain stores (no
 // contention), in 100 MHz s_memrealtime ticks.  Layout: [wave][8] then, per round r, [8] monitor slots.
 // wave slots: 0 start, 1 first tile swept, 2 last tile swept, 3 end, 4 handed to the workgroup, 5 workgroup
-// partial stored, 6 drained; round slots: 3 seen complete, 4 partials read, 5 judged, 6 (round 0) rehearsal.
+// partial stored, 6 drained; round slots: 3 seen complete, 4 partials read, 7 rules evaluated, 5 judged (state and result stored), 6 (round 0) rehearsal.
 __device__ __forceinline__ void stamp_wave(const PersistLaunch& P, unsigned slot, int lane) {
     if (P.stamps && lane == 0) {
         const u64 w = static_cast<u64>(blockIdx.x) * kPersistWaves + (threadIdx.x >> 6);
