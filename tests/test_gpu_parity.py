@@ -318,6 +318,35 @@ def test_clt_decision_table_near_the_thresholds(nat, oracle, engines):
     plan.close()
 
 
+def test_fetch_polls_the_pinned_result_while_the_stream_is_busy(nat, engines):
+    """aqe_plan_fetch takes a result from the plan's pinned block as soon as the finishing launch has written all of
+    it (check word over every field, kernels.hpp result_check) — also while later launches of other plans are still
+    queued on the same stream, and in any order."""
+    import torch
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(1_000_000)
+    qs = [make_query(nat.M_MEMORY_STRIDE, 1.0), make_query(nat.M_BLOCK, 5.0, where=(250.0, 750.0)),
+          make_query(nat.M_RANDOM_POINTER, 1.0, seed=7),
+          make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.0, clt_round0=1024, clt_growth=4),
+          make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=1.0, clt_round0=1024, clt_growth=4)]
+    want = [eng.reduce(q) for q in qs]
+    plans = [eng.plan(q) for q in qs]
+    st = torch.cuda.Stream().cuda_stream
+    key = lambda r: (r.n, r.visited, r.converged, r.rounds, r.topup, r.topup_pending, r.device_status)
+    for it in range(60):
+        order = list(range(len(plans)))
+        if it % 2:
+            order.reverse()
+        for i in order:
+            plans[i].enqueue_all(st)
+        for i in (reversed(order) if it % 3 == 0 else order):
+            r = plans[i].fetch(st)
+            assert key(r) == key(want[i]), (it, i)
+            assert rel(r.sum, want[i].sum) <= 1e-14 and rel(r.value, want[i].value) <= 1e-13 and rel(r.ci_upper, want[i].ci_upper) <= 1e-13
+    for p in plans:
+        p.close()
+
+
 def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
     """Where the reference divides by zero (DB.cpp:927, 985, 993) the C ABI returns AQE_ERR_INVALID."""
     from approximatequeryengine_amd.engine import make_query
