@@ -192,7 +192,8 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
     // between the two allocations, in rows, is added (64-bit wrap-around; both are 256-byte aligned, so alignment
     // of every access is unchanged).
     const SweepCommon sw_r = sweep_common(p, nullptr, 0, false), sw_t = sweep_common(p, nullptr, 0, true);
-    const uint64_t topup_rebase = static_cast<uint64_t>(sw_t.amount - sw_r.amount) - sw_t.shard_lo + sw_r.shard_lo;
+    const int64_t base_gap = static_cast<int64_t>(reinterpret_cast<uintptr_t>(sw_t.amount) - reinterpret_cast<uintptr_t>(sw_r.amount)) / 8;  // rows
+    const uint64_t topup_rebase = static_cast<uint64_t>(base_gap) - sw_t.shard_lo + sw_r.shard_lo;
     for (size_t r = 0; r < S; ++r) {
         const LaunchDesc& L = *slots[r];
         F.round_begin[r] = tiles;
