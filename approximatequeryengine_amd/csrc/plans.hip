@@ -402,17 +402,28 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                     // (Measured, bench query at e = 1 %: 230 k aggregates/s and 14 us per launch, against 76-100 k for
                     // one launch per round replayed as a graph, which is what such plans used before.)
                     const size_t r_head = std::min(R, r_stop + 1);
-                    for (int with_topup = p->host.has_topup ? 1 : 0; with_topup >= 0 && !p->head.ok; --with_topup) {
-                        uint64_t tiles = with_topup ? p->topup.ntiles : 0;
+                    // Attempts, in order: rounds + top-up on one tile per wave; the same on half the largest grid when that many
+                    // workgroups' partials would not fit the monitor's one window of steps and the top-up is small enough
+                    // (<= 64 MB) for half the chip to sweep it faster than a second launch would start; the rounds alone.
+                    struct Attempt { bool topup; uint32_t cap; };
+                    std::vector<Attempt> attempts;
+                    if (p->host.has_topup) {
+                        attempts.push_back({true, p->grid});
+                        if (p->grid > static_cast<uint32_t>(kMaxPersistGrid) / 2 && p->topup.samples * 8 <= (64ull << 20))
+                            attempts.push_back({true, static_cast<uint32_t>(kMaxPersistGrid) / 2});
+                    }
+                    attempts.push_back({false, p->grid});
+                    for (const Attempt& at : attempts) {
+                        uint64_t tiles = at.topup ? p->topup.ntiles : 0;
                         for (size_t r = 0; r < r_head; ++r) tiles += p->rounds[r].ntiles;
                         uint32_t g = 1;
                         // one tile per sweeper wave: the sweep is a few microseconds of latency, not of bandwidth (measured, bench
                         // query at e = 1 %: 14 us per launch and 230 k aggregates/s so, 23 us and 173 k with two tiles per wave)
-                        while (g < p->grid && static_cast<uint64_t>(g) * kPersistWaves < tiles) g *= 2;
+                        while (g < at.cap && static_cast<uint64_t>(g) * kPersistWaves < tiles) g *= 2;
                         SweepForm F;
-                        rc2 = build_sweep_form(p.get(), with_topup != 0, F, g, r_head);
+                        rc2 = build_sweep_form(p.get(), at.topup, F, g, r_head);
                         // (with the top-up the monitor judges once, from one window of steps)
-                        if (rc2 == AQE_OK && !(with_topup && F.step_begin[F.slots] > static_cast<uint32_t>(kDecSteps))) {
+                        if (rc2 == AQE_OK && !(at.topup && F.step_begin[F.slots] > static_cast<uint32_t>(kDecSteps))) {
                             p->head = std::move(F);
                             break;
                         }
