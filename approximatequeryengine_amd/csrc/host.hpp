@@ -124,6 +124,8 @@ struct aqe_plan {
     aqe_result* d_result = nullptr;  // the device's address of h_result
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool tick_timed = false;    // the timed execution was timed by the device clock (result.kernel_ms), not by events
+    bool want_ticks = false;    // the launches being enqueued note the device clock
     // Scratch of the hand-off protocols.  It belongs to the plan, not the context, so several plans can be
     // in flight on different streams of one GPU (the tail of one query overlaps the sweep of the next).
     double* partials = nullptr;   // [kMaxBlocks][aqe::kVec]   k_round / k_indexed

@@ -39,10 +39,23 @@ __device__ __forceinline__ void block_sum7(double (&v)[7], double (*red)[kVec]) 
     }
 }
 
+// Device-clock timing of a query (RoundLaunch::want_ticks): workgroup 0 — dispatched first — notes the clock when the
+// query's FIRST launch starts, in a spare word behind the arrival counters; the workgroup that folds that launch (the
+// last to arrive: workgroup 0's store is long out) carries it into the state, and whoever finishes the query reads
+// the clock again.
+__device__ __forceinline__ u64* t0_word(const RoundLaunch& a) { return reinterpret_cast<u64*>(a.counter + kShards * kShardStride + 8); }
+__device__ __forceinline__ void note_start(const RoundLaunch& a) {
+    if (a.want_ticks && a.reset_state && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(t0_word(a), static_cast<u64>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The launch that finishes a query writes the result and, for a host that polls the pinned result instead of waiting
 // for the end of the launch, the check word beside it (kernels.hpp, result_check).
 __device__ __forceinline__ void publish_result(const QueryState& st, const RoundLaunch& a) {
-    const aqe_result r = make_result(st, a.fin);
+    aqe_result r = make_result(st, a.fin);
+    // (timed on the device — 10 ns ticks — so that the host can pick the result up by polling instead of waiting for
+    // two event records around the launches to complete)
+    if (a.want_ticks) r.kernel_ms = static_cast<double>(__builtin_amdgcn_s_memrealtime() - st.t0) * 1e-5;
     *a.result = r;
     if (a.result_seq) __hip_atomic_store(a.result_seq, result_check(r, a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -60,7 +73,12 @@ __device__ __forceinline__ void fold_and_finish(const double (&tot)[7], const Ro
     }
     if (a.fused) {
         QueryState st;
-        if (a.reset_state) st = QueryState{}; else st = *a.state;
+        if (a.reset_state) {
+            st = QueryState{};
+            if (a.want_ticks) st.t0 = __hip_atomic_load(t0_word(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            st = *a.state;
+        }
         fold(st, vec, a.fold);
         *a.state = st;
         if (a.do_finalize) publish_result(st, a);
@@ -144,6 +162,7 @@ __device__ __forceinline__ bool launch_is_live(const RoundLaunch& a, u64& ord_li
 __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
     __shared__ DevFamily lds_fams[kMaxLdsFams];
     u64 ord_limit;
+    note_start(a);
     if (!launch_is_live(a, ord_limit)) return;
     const int lane = threadIdx.x & 63;
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
@@ -159,6 +178,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
 // random_pointer_sample (DB.cpp:856-882): explicit ascending row list built on the host.
 __global__ __launch_bounds__(kBlockThreads) void k_indexed(RoundLaunch a, const uint64_t* __restrict__ idx, u64 n_idx) {
     u64 ord_limit;
+    note_start(a);
     if (!launch_is_live(a, ord_limit)) return;
     Acc acc;
     constexpr u64 kChunk = static_cast<u64>(kBlockThreads) * kTileUnroll;

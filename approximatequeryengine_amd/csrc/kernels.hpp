@@ -62,6 +62,7 @@ struct QueryState {
     int32_t converged;         // 0 none, 1 error rule, 2 cross-validation rule
     int32_t rounds;            // rounds folded
     int32_t error;             // device protocol error (persistent sweep timed out waiting for a decision)
+    unsigned long long t0;     // device clock (s_memrealtime, 100 MHz) when the query's first launch started, if it was asked to note it
 };
 
 struct FoldParams {
@@ -109,6 +110,8 @@ struct RoundLaunch {
     aqe_result* result;
     unsigned long long epoch;        // with result_seq: the launch that finishes the query also writes result_check(result, epoch)
     unsigned long long* result_seq;  // beside the (pinned) result, or null
+    uint32_t want_ticks;             // 1: time the query on the device clock (first launch's start -> result written) into result.kernel_ms
+    uint32_t pad_;
 };
 
 // ---- persistent single-launch sweep of a multi-round (CLT) query: persist.hip ------------------

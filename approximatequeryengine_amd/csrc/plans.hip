@@ -142,6 +142,7 @@ RoundLaunch round_launch(const aqe_plan* p, const LaunchDesc& L, uint32_t index,
     a.fold = fold_params(p, topup);
     a.fin = finalize_params(p);
     a.result = p->d_result;
+    a.want_ticks = p->want_ticks ? 1u : 0u;
     if (epoch) {  // the host will poll for this execution's result (never for a captured launch: its arguments are frozen)
         a.epoch = epoch;
         a.result_seq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p->d_result) + (reinterpret_cast<const volatile char*>(p->h_seq) - reinterpret_cast<const char*>(p->h_result)));
@@ -524,7 +525,14 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
 
 int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
     aqe_ctx* c = p->ctx;
-    if (timed) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
+    // Launch-by-launch queries are timed on the device clock (k_round notes its start in the state, the finishing
+    // launch writes the elapsed ticks into the result): no event records in the queue, and the result can be polled.
+    // The persistent launch, a replayed graph (frozen arguments) and a profiled plan keep the two event records.
+    const bool launch_by_launch = !(p->persist && (!p->per_round || p->head.ok)) &&
+                                  !(p->rounds.size() >= kGraphMinRounds && p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH"));
+    const bool tick_timing = timed && !p->profile && launch_by_launch && !p->rounds.empty();
+    p->want_ticks = tick_timing;
+    if (timed && !tick_timing) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
     // (taking the first launch's begin and the last launch's end from the dispatches themselves — hipExtLaunchKernelGGL —
     // was tried instead of the two records: the reported time loses the records' 3 us, the call gains 8 us of host work)
     p->lev_used = 0;
@@ -576,9 +584,11 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             p->poll_epoch = plain_epoch;  // the result comes from the top-up launch (behind a persistent launch: no check word)
         }
     }
-    if (timed || c->d_stamps) p->poll_epoch = 0;  // timings and stamps are read after the launch has ended
-    if (timed) HIPCHK(c, hipEventRecord(p->ev1, s));
+    if ((timed && !tick_timing) || c->d_stamps) p->poll_epoch = 0;  // event timings and stamps are read after the launch has ended
+    if (timed && !tick_timing) HIPCHK(c, hipEventRecord(p->ev1, s));
+    p->want_ticks = false;
     p->timed = timed;
+    p->tick_timed = tick_timing;
     return AQE_OK;
 }
 
@@ -660,7 +670,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     if (out->device_status != 0) {  // the monitor gave up waiting for a workgroup's partial
         return fail(c, AQE_ERR_HIP, "device-side round protocol timed out");
     }
-    if (p->timed) {
+    if (p->timed && !p->tick_timed) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) out->kernel_ms = ms;
     }
@@ -701,6 +711,7 @@ int run_sync(aqe_plan* p, hipStream_t s, bool timed) {
     }
     if (timed) HIPCHK(c, hipEventRecord(p->ev1, s));
     p->timed = timed;
+    p->tick_timed = false;
     return AQE_OK;
 }
 
@@ -938,6 +949,10 @@ int aqe_plan_fetch(aqe_plan* p, aqe_result* out, void* stream) {
 int aqe_plan_last_kernel_ms(aqe_plan* p, float* ms) {
     if (!p || !ms) return AQE_ERR_INVALID;
     if (!p->timed) return fail(p->ctx, AQE_ERR_INVALID, "no timed execution yet");
+    if (p->tick_timed) {  // timed by the device clock: the figure is in the fetched result
+        *ms = static_cast<float>(p->h_result->kernel_ms);
+        return AQE_OK;
+    }
     HIPCHK(p->ctx, hipEventSynchronize(p->ev1));
     HIPCHK(p->ctx, hipEventElapsedTime(ms, p->ev0, p->ev1));
     return AQE_OK;
