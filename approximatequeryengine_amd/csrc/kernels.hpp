@@ -167,7 +167,7 @@ struct PersistLaunch {
     uint32_t topup_gate;       // 1: the plan has a top-up stage: mark the result topup_pending when it is due (DB.cpp:1032)
     uint32_t more_rounds;      // 1: the plan has rounds behind this launch's last: running out of rounds here does not end the query
     uint32_t topup_slot;       // 1: the LAST slot is the top-up, swept with the rounds: the monitor judges once everything is in and adds it when due
-    uint32_t pad1;
+    uint32_t want_ticks;       // 1: the monitor times the query on the device clock into result.kernel_ms (and state.t0)
     uint32_t totals_only;      // 1: no decisions in the kernel; the monitor writes every round's total to out_totals
     unsigned long long epoch;  // distinguishes this launch's flags from the previous launch's
     PersistCtl* ctl;

@@ -80,6 +80,7 @@ __device__ __forceinline__ void state_store(QueryState* g, const QueryState& st)
 
 // Monitor scratch: the running per-lane sums of one window of steps (used by wave 0 of workgroup 0 only).
 __shared__ double lds_run[kDecSteps][64];
+__shared__ unsigned long long lds_t0;  // device clock at the monitor's start (PersistLaunch::want_ticks), parked here, not in a register
 
 // The monitor's poll reads the flag words of a window of kDecSteps steps that starts at a round boundary S:
 // lane L takes the flags of slots L, L + 64, L + 128, L + 192 of the window (4 loads, 8 registers).
@@ -254,6 +255,10 @@ __device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigne
                         due = false;
                     }
                     if (with_result && !result_now) res = make_result(st, fin);
+                    if (K->want_ticks && !warm) {
+                        st.t0 = lds_t0;
+                        res.kernel_ms = static_cast<double>(__builtin_amdgcn_s_memrealtime() - st.t0) * 1e-5;
+                    }
                     res.rounds = st.rounds;
                     res.converged = code;
                     res.topup_pending = goes_on ? 2 : due ? 1 : 0;  // 2: the host launches the plan's remaining rounds
@@ -327,6 +332,7 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_s_setprio(3);
     stamp_wave(P, 0, lane);
+    if (K->want_ticks && lane == 0) lds_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned judged = 0, polls = 0;  // rounds [0, judged) are folded and judged
     double run = 0.0;                // this lane's running sum over every step folded so far
     // nothing can be complete yet: rehearse the fold, so that the real one finds its code in the instruction cache

@@ -499,6 +499,7 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     a.stamps = c->d_stamps;
     a.finalize_here = 1u;
     a.more_rounds = F.more_rounds;
+    a.want_ticks = (p->want_ticks && !totals_only) ? 1u : 0u;
     a.topup_slot = totals_only ? 0u : F.topup_slot;
     a.topup_gate = p->host.has_topup ? 1u : 0u;
     a.totals_only = totals_only ? 1u : 0u;
@@ -525,12 +526,13 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
 
 int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
     aqe_ctx* c = p->ctx;
-    // Launch-by-launch queries are timed on the device clock (k_round notes its start in the state, the finishing
-    // launch writes the elapsed ticks into the result): no event records in the queue, and the result can be polled.
-    // The persistent launch, a replayed graph (frozen arguments) and a profiled plan keep the two event records.
-    const bool launch_by_launch = !(p->persist && (!p->per_round || p->head.ok)) &&
-                                  !(p->rounds.size() >= kGraphMinRounds && p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH"));
-    const bool tick_timing = timed && !p->profile && launch_by_launch && !p->rounds.empty();
+    // Queries are timed on the device clock (the first launch notes its start — k_round in the state, the monitor of a
+    // persistent launch in LDS — and whoever finishes the query writes the elapsed ticks into the result): no event
+    // records in the queue, and the result can be polled.  A replayed graph (frozen arguments) and a profiled plan
+    // keep the two event records.
+    const bool graph_launch = !(p->persist && (!p->per_round || p->head.ok)) && p->rounds.size() >= kGraphMinRounds &&
+                              p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH");
+    const bool tick_timing = timed && !p->profile && !graph_launch && !p->rounds.empty();
     p->want_ticks = tick_timing;
     if (timed && !tick_timing) HIPCHK(c, hipEventRecord(p->ev0, s));  // an event record is a queue packet: off the throughput path
     // (taking the first launch's begin and the last launch's end from the dispatches themselves — hipExtLaunchKernelGGL —
@@ -616,6 +618,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     }
     p->poll_epoch = 0;  // consumed: only aqe_plan_enqueue_all arms it
     if (!landed) HIPCHK(c, hipStreamSynchronize(s));
+    p->want_ticks = p->timed && p->tick_timed;  // launches made from here continue the device-clock timing
     if (p->last_exec == 1 && p->h_result->topup_pending == 2) {
         // the head form ran out of rounds before the query stopped (the prediction failed): the remaining rounds go
         // out one launch each, the top-up behind them — and from now on this plan takes the full single launch
@@ -638,6 +641,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
         }
         p->expect_topup = p->h_result->topup > 0;  // the next execution enqueues the top-up launch up front, or not
     }
+    p->want_ticks = false;
     *out = *p->h_result;
     if (c->d_stamps && p->persist) {
         const size_t W = static_cast<size_t>(p->last_grid) * kPersistWaves;

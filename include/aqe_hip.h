@@ -145,9 +145,9 @@ typedef struct aqe_result {
     uint64_t topup;    /* CLT: rows added by the top-up                                      */
     int32_t converged; /* CLT: 0 no, 1 error rule (DB.cpp:958), 2 cross-validation (DB.cpp:1009) */
     int32_t rounds;    /* CLT: rounds folded before the stop                                 */
-    double kernel_ms;  /* aqe_reduce / timed executions: device time of the query — launch by launch, the device's
-                          100 MHz clock from the first launch starting to the result being written; a persistent
-                          launch or a replayed graph, two events around it on the stream (about 3 us more) */
+    double kernel_ms;  /* aqe_reduce / timed executions: device time of the query by the device's own 100 MHz clock,
+                          from its first launch starting (the monitor wave, for a persistent launch) to the result
+                          being written; a replayed graph of launches is timed by two events around it instead */
     uint64_t bytes_algorithmic; /* 8 B per visited sample (SoA amount column)                 */
     int32_t device_status; /* 0 ok; nonzero: the device-side round protocol reported an error   */
     int32_t topup_pending; /* batched multi-GPU form only: 1 = the top-up (DB.cpp:1031-1040) is due and has
