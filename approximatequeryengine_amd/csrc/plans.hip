@@ -452,7 +452,8 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
     HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
     constexpr size_t kSeqOffset = (sizeof(aqe_result) + 63) / 64 * 64;  // the sequence word on its own cache line
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped));
+    // (coherent, i.e. fine-grained: the device's stores must reach host memory while the launch is still running — fetch() polls)
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(p->h_result, 0, kSeqOffset + 64);
     p->h_seq = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(p->h_result) + kSeqOffset);
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
