@@ -48,7 +48,22 @@ constexpr size_t kGraphMinRounds = 4, kGraphMaxRounds = 8192;  // one-launch-per
 
 }  // namespace aqe
 
+// What every plan needs on the device besides its families: workgroup partials, arrival counters, the query state, the
+// pinned result block, two events.  Allocating these costs more than planning and running a query (hipHostMalloc
+// alone ~100 us), so a destroyed plan hands them back to its context and the next plan takes them over as they are:
+// the arrival counters reset themselves, the first launch of a query overwrites the state, partials are written
+// before they are read, and the result block's check word carries a launch epoch that is never reused.
+struct PlanScratch {
+    double* partials = nullptr;
+    unsigned* counter = nullptr;
+    aqe::QueryState* d_state = nullptr;
+    aqe_result* h_result = nullptr;
+    aqe_result* d_result = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
 struct aqe_ctx {
+    std::vector<PlanScratch> scratch_pool;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;

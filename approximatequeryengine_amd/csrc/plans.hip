@@ -11,6 +11,11 @@ void destroy_plan(aqe_plan* p) {
     (void)hipDeviceSynchronize();  // fetch() may have returned before the plan's last launch had ended
     if (p->d_fams) (void)hipFree(p->d_fams);
     if (p->d_idx) (void)hipFree(p->d_idx);
+    if (p->ctx && p->partials && p->counter && p->d_state && p->h_result && p->ev0 && p->ev1 && p->ctx->scratch_pool.size() < 128) {
+        // (the device is idle — synchronised above — so the counters are back at zero and nothing is in flight)
+        p->ctx->scratch_pool.push_back(PlanScratch{p->partials, p->counter, p->d_state, p->h_result, p->d_result, p->ev0, p->ev1});
+        p->partials = nullptr; p->counter = nullptr; p->d_state = nullptr; p->h_result = nullptr; p->ev0 = p->ev1 = nullptr;
+    }
     if (p->partials) (void)hipFree(p->partials);
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
@@ -445,20 +450,27 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
         }
     }
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
-    HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
-    HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
-    HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
     constexpr size_t kSeqOffset = (sizeof(aqe_result) + 63) / 64 * 64;  // the sequence word on its own cache line
-    // (coherent, i.e. fine-grained: the device's stores must reach host memory while the launch is still running — fetch() polls)
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (!c->scratch_pool.empty()) {  // a destroyed plan's scratch, as it is (host.hpp, PlanScratch)
+        const PlanScratch sc = c->scratch_pool.back();
+        c->scratch_pool.pop_back();
+        p->partials = sc.partials; p->counter = sc.counter; p->d_state = sc.d_state;
+        p->h_result = sc.h_result; p->d_result = sc.d_result; p->ev0 = sc.ev0; p->ev1 = sc.ev1;
+    } else {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
+        HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
+        HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
+        HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
+        // (coherent, i.e. fine-grained: the device's stores must reach host memory while the launch is still running — fetch() polls)
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
+        HIPCHK(c, hipEventCreate(&p->ev0));
+        HIPCHK(c, hipEventCreate(&p->ev1));
+    }
     std::memset(p->h_result, 0, kSeqOffset + 64);
     p->h_seq = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(p->h_result) + kSeqOffset);
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
-    HIPCHK(c, hipEventCreate(&p->ev0));
-    HIPCHK(c, hipEventCreate(&p->ev1));
     *out = p.release();
     return AQE_OK;
 }

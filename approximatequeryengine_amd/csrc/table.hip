@@ -359,6 +359,15 @@ void aqe_destroy(aqe_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_cache(c);
+    for (const PlanScratch& sc : c->scratch_pool) {
+        (void)hipFree(sc.partials);
+        (void)hipFree(sc.counter);
+        (void)hipFree(sc.d_state);
+        (void)hipHostFree(sc.h_result);
+        (void)hipEventDestroy(sc.ev0);
+        (void)hipEventDestroy(sc.ev1);
+    }
+    c->scratch_pool.clear();
     free_table(c);
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->grp_partial) (void)hipFree(c->grp_partial);
