@@ -60,6 +60,8 @@ struct PlanScratch {
     aqe_result* h_result = nullptr;
     aqe_result* d_result = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    aqe::PersistCtl* d_ctl = nullptr;  // persistent sweep: the stop word (tagged with the launch epoch: never reset)
+    void* d_rehearsal = nullptr;       // ... and where the monitor's rehearsal writes
 };
 
 struct aqe_ctx {

@@ -11,18 +11,19 @@ void destroy_plan(aqe_plan* p) {
     (void)hipDeviceSynchronize();  // fetch() may have returned before the plan's last launch had ended
     if (p->d_fams) (void)hipFree(p->d_fams);
     if (p->d_idx) (void)hipFree(p->d_idx);
-    if (p->ctx && p->partials && p->counter && p->d_state && p->h_result && p->ev0 && p->ev1 && p->ctx->scratch_pool.size() < 128) {
+    if (p->ctx && p->partials && p->counter && p->d_state && p->h_result && p->ev0 && p->ev1 && p->d_ctl && p->d_rehearsal &&
+        p->ctx->scratch_pool.size() < 128) {
         // (the device is idle — synchronised above — so the counters are back at zero and nothing is in flight)
-        p->ctx->scratch_pool.push_back(PlanScratch{p->partials, p->counter, p->d_state, p->h_result, p->d_result, p->ev0, p->ev1});
+        p->ctx->scratch_pool.push_back(PlanScratch{p->partials, p->counter, p->d_state, p->h_result, p->d_result, p->ev0, p->ev1, p->d_ctl, p->d_rehearsal});
         p->partials = nullptr; p->counter = nullptr; p->d_state = nullptr; p->h_result = nullptr; p->ev0 = p->ev1 = nullptr;
+        p->d_ctl = nullptr; p->d_rehearsal = nullptr;
     }
     if (p->partials) (void)hipFree(p->partials);
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
     for (SweepForm* f : {&p->decide, &p->totals, &p->head}) {
-        if (f->d_fams) (void)hipFree(f->d_fams);
-        if (f->d_ppart) (void)hipFree(f->d_ppart);
+        if (f->d_ppart) (void)hipFree(f->d_ppart);  // (the form's family table lives in the same block)
     }
     if (p->d_state) (void)hipFree(p->d_state);
     if (p->round_graph) (void)hipGraphExecDestroy(p->round_graph);
@@ -252,18 +253,19 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
         F.step_begin[r + 1] = F.step_begin[r] + static_cast<uint32_t>((members + 7) / 8);
     }
     F.round_mod[S] = static_cast<uint32_t>(F.round_begin[S] % V);
-    if (!F.h_fams.empty()) {
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_fams), F.h_fams.size() * sizeof(DevFamily)));
-        HIPCHK(c, hipMemcpy(F.d_fams, F.h_fams.data(), F.h_fams.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
-    }
     // the monitor reads whole windows of kDecSteps steps: keep one window of slack behind the last slot.
     // Pad slots (a round's run rounded up to 8) are never written: zero data, flag word "always published".
-    std::vector<uint64_t> init(static_cast<size_t>(kVec) * 8 * (static_cast<size_t>(F.step_begin[S]) + kDecSteps), 0);
+    // ONE allocation and ONE copy per form: [partials, initialised][family table] (allocation calls are what a plan costs).
+    const size_t ppart_words = static_cast<size_t>(kVec) * 8 * (static_cast<size_t>(F.step_begin[S]) + kDecSteps);
+    const size_t fams_words = (F.h_fams.size() * sizeof(DevFamily) + 7) / 8;
+    std::vector<uint64_t> init(ppart_words + fams_words, 0);
     for (size_t r = 0; r < S; ++r)
         for (size_t slot = 8 * static_cast<size_t>(F.step_begin[r]) + F.part_count[r]; slot < 8 * static_cast<size_t>(F.step_begin[r + 1]); ++slot)
             init[slot * kVec + 7] = kSlotAlways;
+    if (!F.h_fams.empty()) std::memcpy(init.data() + ppart_words, F.h_fams.data(), F.h_fams.size() * sizeof(DevFamily));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), init.size() * sizeof(uint64_t)));
     HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    F.d_fams = F.h_fams.empty() ? nullptr : reinterpret_cast<DevFamily*>(reinterpret_cast<uint64_t*>(F.d_ppart) + ppart_words);  // (inside d_ppart's block: never freed on its own)
     F.ok = true;
     return AQE_OK;
 }
@@ -433,7 +435,6 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                             p->head = std::move(F);
                             break;
                         }
-                        if (F.d_fams) (void)hipFree(F.d_fams);
                         if (F.d_ppart) (void)hipFree(F.d_ppart);
                         if (rc2 != AQE_OK) return rc2;
                     }
@@ -444,11 +445,6 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             int rc2 = build_sweep_form(p.get(), false, p->totals, p->grid, R);
             if (rc2 != AQE_OK) return rc2;
         }
-        if (p->decide.ok || p->totals.ok) {
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
-            HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
-            HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
-        }
     }
     constexpr size_t kSeqOffset = (sizeof(aqe_result) + 63) / 64 * 64;  // the sequence word on its own cache line
     if (!c->scratch_pool.empty()) {  // a destroyed plan's scratch, as it is (host.hpp, PlanScratch)
@@ -456,6 +452,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         c->scratch_pool.pop_back();
         p->partials = sc.partials; p->counter = sc.counter; p->d_state = sc.d_state;
         p->h_result = sc.h_result; p->d_result = sc.d_result; p->ev0 = sc.ev0; p->ev1 = sc.ev1;
+        p->d_ctl = sc.d_ctl; p->d_rehearsal = sc.d_rehearsal;
     } else {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
         HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
@@ -468,6 +465,9 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
         HIPCHK(c, hipEventCreate(&p->ev0));
         HIPCHK(c, hipEventCreate(&p->ev1));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
+        HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
+        HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
     }
     std::memset(p->h_result, 0, kSeqOffset + 64);
     p->h_seq = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(p->h_result) + kSeqOffset);

@@ -366,6 +366,8 @@ void aqe_destroy(aqe_ctx* c) {
         (void)hipHostFree(sc.h_result);
         (void)hipEventDestroy(sc.ev0);
         (void)hipEventDestroy(sc.ev1);
+        (void)hipFree(sc.d_ctl);
+        (void)hipFree(sc.d_rehearsal);
     }
     c->scratch_pool.clear();
     free_table(c);

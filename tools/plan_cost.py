@@ -13,3 +13,6 @@ t("plan create+close random 10% new seed", lambda i: eng.plan(make_query(nat.M_R
 t("reduce random 10% new seed", lambda i: eng.reduce(make_query(nat.M_RANDOM_POINTER, 10.0, seed=i)))
 t("reduce random 10% same seed", lambda i: eng.reduce(make_query(nat.M_RANDOM_POINTER, 10.0, seed=7)))
 t("reduce stride new pct", lambda i: eng.reduce(make_query(nat.M_MEMORY_STRIDE, 1.0 + i * 1e-3)))
+t("plan create+close CLT e=0.01 (new R0 each)", lambda i: eng.plan(make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.01, clt_round0=1024 + i, clt_growth=4)).close())
+t("reduce CLT new R0", lambda i: eng.reduce(make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.01, clt_round0=2048 + i, clt_growth=4)))
+t("reduce CLT e=1 new R0", lambda i: eng.reduce(make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=1.0, clt_round0=2048 + i, clt_growth=4)))
