@@ -53,6 +53,7 @@ constexpr size_t kGraphMinRounds = 4, kGraphMaxRounds = 8192;  // one-launch-per
 // alone ~100 us), so a destroyed plan hands them back to its context and the next plan takes them over as they are:
 // the arrival counters reset themselves, the first launch of a query overwrites the state, partials are written
 // before they are read, and the result block's check word carries a launch epoch that is never reused.
+constexpr size_t kPoolFams = 64;
 struct PlanScratch {
     double* partials = nullptr;
     unsigned* counter = nullptr;
@@ -62,6 +63,7 @@ struct PlanScratch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     aqe::PersistCtl* d_ctl = nullptr;  // persistent sweep: the stop word (tagged with the launch epoch: never reset)
     void* d_rehearsal = nullptr;       // ... and where the monitor's rehearsal writes
+    aqe::DevFamily* d_fams_small = nullptr;  // room for a family table of up to kPoolFams entries
 };
 
 struct aqe_ctx {
@@ -130,6 +132,7 @@ struct aqe_plan {
     aqe::HostPlan host;
     uint64_t table_epoch = 0;
     aqe::DevFamily* d_fams = nullptr;
+    aqe::DevFamily* d_fams_small = nullptr;  // the pooled table (d_fams points here when the plan's table fits)
     std::vector<aqe::DevFamily> h_fams;
     std::vector<aqe::LaunchDesc> rounds;
     aqe::LaunchDesc topup;

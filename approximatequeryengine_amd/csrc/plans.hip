@@ -9,19 +9,20 @@ namespace aqe {
 void destroy_plan(aqe_plan* p) {
     if (!p) return;
     (void)hipDeviceSynchronize();  // fetch() may have returned before the plan's last launch had ended
-    if (p->d_fams) (void)hipFree(p->d_fams);
+    if (p->d_fams && p->d_fams != p->d_fams_small) (void)hipFree(p->d_fams);
     if (p->d_idx) (void)hipFree(p->d_idx);
-    if (p->ctx && p->partials && p->counter && p->d_state && p->h_result && p->ev0 && p->ev1 && p->d_ctl && p->d_rehearsal &&
+    if (p->ctx && p->d_fams_small && p->partials && p->counter && p->d_state && p->h_result && p->ev0 && p->ev1 && p->d_ctl && p->d_rehearsal &&
         p->ctx->scratch_pool.size() < 128) {
         // (the device is idle — synchronised above — so the counters are back at zero and nothing is in flight)
-        p->ctx->scratch_pool.push_back(PlanScratch{p->partials, p->counter, p->d_state, p->h_result, p->d_result, p->ev0, p->ev1, p->d_ctl, p->d_rehearsal});
+        p->ctx->scratch_pool.push_back(PlanScratch{p->partials, p->counter, p->d_state, p->h_result, p->d_result, p->ev0, p->ev1, p->d_ctl, p->d_rehearsal, p->d_fams_small});
         p->partials = nullptr; p->counter = nullptr; p->d_state = nullptr; p->h_result = nullptr; p->ev0 = p->ev1 = nullptr;
-        p->d_ctl = nullptr; p->d_rehearsal = nullptr;
+        p->d_ctl = nullptr; p->d_rehearsal = nullptr; p->d_fams_small = nullptr;
     }
     if (p->partials) (void)hipFree(p->partials);
     if (p->counter) (void)hipFree(p->counter);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
+    if (p->d_fams_small) (void)hipFree(p->d_fams_small);
     for (SweepForm* f : {&p->decide, &p->totals, &p->head}) {
         if (f->d_ppart) (void)hipFree(f->d_ppart);  // (the form's family table lives in the same block)
     }
@@ -365,8 +366,35 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         p->topup.fam_offset = p->h_fams.size();
         for (const auto& f : p->host.topup_fams) add_family(p->h_fams, p->topup, f, out_pos, c->dense16);
     }
-    if (!p->h_fams.empty()) {
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams), p->h_fams.size() * sizeof(DevFamily)));
+    constexpr size_t kSeqOffset = (sizeof(aqe_result) + 63) / 64 * 64;  // the sequence word on its own cache line
+    if (!c->scratch_pool.empty()) {  // a destroyed plan's scratch, as it is (host.hpp, PlanScratch)
+        const PlanScratch sc = c->scratch_pool.back();
+        c->scratch_pool.pop_back();
+        p->partials = sc.partials; p->counter = sc.counter; p->d_state = sc.d_state;
+        p->h_result = sc.h_result; p->d_result = sc.d_result; p->ev0 = sc.ev0; p->ev1 = sc.ev1;
+        p->d_ctl = sc.d_ctl; p->d_rehearsal = sc.d_rehearsal; p->d_fams_small = sc.d_fams_small;
+    } else {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
+        HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
+        HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
+        HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
+        // (coherent, i.e. fine-grained: the device's stores must reach host memory while the launch is still running — fetch() polls)
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
+        HIPCHK(c, hipEventCreate(&p->ev0));
+        HIPCHK(c, hipEventCreate(&p->ev1));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
+        HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
+        HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams_small), kPoolFams * sizeof(DevFamily)));
+    }
+    std::memset(p->h_result, 0, kSeqOffset + 64);
+    p->h_seq = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(p->h_result) + kSeqOffset);
+    if (!p->h_fams.empty()) {  // (a short table goes into the pooled scratch: no allocation)
+        if (p->h_fams.size() <= kPoolFams) p->d_fams = p->d_fams_small;
+        else HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams), p->h_fams.size() * sizeof(DevFamily)));
         HIPCHK(c, hipMemcpy(p->d_fams, p->h_fams.data(), p->h_fams.size() * sizeof(DevFamily), hipMemcpyHostToDevice));
     }
     if (!p->host.random_idx.empty()) {
@@ -446,31 +474,6 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             if (rc2 != AQE_OK) return rc2;
         }
     }
-    constexpr size_t kSeqOffset = (sizeof(aqe_result) + 63) / 64 * 64;  // the sequence word on its own cache line
-    if (!c->scratch_pool.empty()) {  // a destroyed plan's scratch, as it is (host.hpp, PlanScratch)
-        const PlanScratch sc = c->scratch_pool.back();
-        c->scratch_pool.pop_back();
-        p->partials = sc.partials; p->counter = sc.counter; p->d_state = sc.d_state;
-        p->h_result = sc.h_result; p->d_result = sc.d_result; p->ev0 = sc.ev0; p->ev1 = sc.ev1;
-        p->d_ctl = sc.d_ctl; p->d_rehearsal = sc.d_rehearsal;
-    } else {
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
-        HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
-        HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
-        HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
-        // (coherent, i.e. fine-grained: the device's stores must reach host memory while the launch is still running — fetch() polls)
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped | hipHostMallocCoherent));
-        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
-        HIPCHK(c, hipEventCreate(&p->ev0));
-        HIPCHK(c, hipEventCreate(&p->ev1));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
-        HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
-        HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
-    }
-    std::memset(p->h_result, 0, kSeqOffset + 64);
-    p->h_seq = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(p->h_result) + kSeqOffset);
     *out = p.release();
     return AQE_OK;
 }

@@ -368,6 +368,7 @@ void aqe_destroy(aqe_ctx* c) {
         (void)hipEventDestroy(sc.ev1);
         (void)hipFree(sc.d_ctl);
         (void)hipFree(sc.d_rehearsal);
+        (void)hipFree(sc.d_fams_small);
     }
     c->scratch_pool.clear();
     free_table(c);
