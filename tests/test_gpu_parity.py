@@ -347,6 +347,38 @@ def test_fetch_polls_the_pinned_result_while_the_stream_is_busy(nat, engines):
         p.close()
 
 
+def test_plans_inherit_scratch_from_destroyed_plans(nat, engines):
+    """A destroyed plan hands its device scratch (partials, counters, state, pinned result block, control block) to the
+    next plan of the context as it is — whatever kind of query either was.  Plans of five kinds are created, run
+    once (fused form; the CLT ones also through the stepwise per-round API) and destroyed in rotation."""
+    import torch
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(1_000_000)
+    qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=1.0, clt_round0=512, clt_growth=2),   # stops, top-up
+          make_query(nat.M_MEMORY_STRIDE, 2.0),
+          make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.0, clt_round0=4096, clt_growth=4),  # runs to the end
+          make_query(nat.M_BLOCK, 3.0, where=(100.0, 400.0)),
+          make_query(nat.M_RANDOM_POINTER, 0.5, seed=3)]
+    want = [eng.reduce(q) for q in qs]
+    key = lambda r: (r.n, r.visited, r.converged, r.rounds, r.topup, r.topup_pending, r.device_status)
+    vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
+    for it in range(40):
+        for i, q in enumerate(qs):
+            p = eng.plan(q)
+            p.enqueue_all()
+            r = p.fetch()
+            assert key(r) == key(want[i]), (it, i)
+            assert rel(r.sum, want[i].sum) <= 1e-14 and rel(r.value, want[i].value) <= 1e-13
+            if i in (0, 2) and it % 8 == 0:  # the same plan again, round by round (world of one: no reduction in between)
+                for rnd in range(p.rounds + (1 if p.has_topup else 0)):
+                    p.enqueue_round(rnd, vec.data_ptr())
+                    p.enqueue_update(rnd, vec.data_ptr())
+                p.enqueue_finalize()
+                r = p.fetch()
+                assert key(r) == key(want[i]), ("stepwise", it, i)
+            p.close()
+
+
 def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
     """Where the reference divides by zero (DB.cpp:927, 985, 993) the C ABI returns AQE_ERR_INVALID."""
     from approximatequeryengine_amd.engine import make_query
