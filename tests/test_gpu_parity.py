@@ -379,6 +379,67 @@ def test_plans_inherit_scratch_from_destroyed_plans(nat, engines):
             p.close()
 
 
+def test_randomised_sampler_parameters_against_the_oracle(nat, oracle):
+    """Seeded sweep over table sizes and sampler parameters nobody picked by hand: for every case the HIP reduce
+    equals the oracle's moments over the oracle's index list (with and without WHERE), and the HIP gather returns
+    exactly those rows."""
+    from approximatequeryengine_amd.engine import Engine
+    import os
+    rng = np.random.default_rng(int(os.environ.get("AQE_FUZZ_SEED", "20251004")))  # (the environment widens the sweep for a one-off hunt)
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]
+    cases = 0
+    for _ in range(int(os.environ.get("AQE_FUZZ_TABLES", "14"))):
+        n = int(pick(1, 2, 63, 64, 65, 999, 1000, 1001, 4097, 12_345, 99_999, 250_001, int(rng.integers(2000, 400_000))))
+        rows = oracle.synth(n, seed=int(rng.integers(1, 1000)))
+        eng = Engine(0)
+        try:
+            eng.stage_records(rows, keep_aos=True)
+            for _ in range(12):
+                pct = float(pick(0.01, 0.37, 1.0, 3.3, 10.0, 25.0, 50.0, 99.0, 100.0, round(float(rng.uniform(0.05, 60.0)), 3)))
+                m = pick("memory_stride_sample", "optimized_address_arithmetic_sample", "block_sample", "page_sample", "parallel_block_sample",
+                         "optimized_clt_sample", "fast_pointer_sample", "slow_pointer_sample", "dual_pointer_sample", "parallel_pointer_sample",
+                         "random_pointer_sample", "clt_validated_dual_pointer_sample")
+                args = {"memory_stride_sample": [int(pick(0, 32, 64, 96, 320, 3200, 32 * int(rng.integers(1, 500))))],
+                        "optimized_address_arithmetic_sample": [],
+                        "block_sample": [int(pick(1, 7, 100, 1000, 4096, int(rng.integers(1, 6000))))],
+                        "page_sample": [int(pick(32, 512, 4096, 8192, 32 * int(rng.integers(1, 400))))],
+                        "parallel_block_sample": [int(pick(10, 1000, int(rng.integers(1, 3000)))), int(rng.integers(1, 9))],
+                        "optimized_clt_sample": [0.95, 20, int(rng.integers(1, 9))],
+                        "fast_pointer_sample": [int(rng.integers(1, 8))],
+                        "slow_pointer_sample": [], "dual_pointer_sample": [],
+                        "parallel_pointer_sample": [int(rng.integers(1, 9))],
+                        "random_pointer_sample": [int(rng.integers(0, 2**31 - 1))],
+                        "clt_validated_dual_pointer_sample": [float(pick(0.9, 0.95, 0.99)), int(pick(4, 10, 25)), int(pick(1, 2, 4, 6)), float(pick(0.0, 0.5, 2.0, 5.0))]}[m]
+                if m == "clt_validated_dual_pointer_sample" and n > 60_000:
+                    continue  # (the reference's cadence: tens of thousands of rounds on a big table; covered by CLT_CASES)
+                if m == "random_pointer_sample":
+                    pct = min(pct, 10.0)
+                call = {"method": m, "pct": pct, "args": args}
+                try:
+                    idx = oracle_indices(oracle, rows, call)
+                except AssertionError:
+                    continue  # parameters the reference itself rejects (e.g. a CLT target below one row per pointer)
+                if idx is None:
+                    continue
+                q = _query_for(nat, call)
+                try:
+                    _check_against_oracle(nat, oracle, eng, rows, q, idx)
+                except nat.AqeError as e:
+                    assert e.status == nat.ERR_INVALID and len(idx) == 0, (n, call, str(e))
+                    continue
+                if m != "clt_validated_dual_pointer_sample":  # (the CLT sampler has no WHERE form in the reference)
+                    lo = float(rng.uniform(1.0, 600.0))
+                    q.has_where, q.where_min, q.where_max = 1, lo, lo + float(rng.uniform(0.0, 500.0))
+                    _check_against_oracle(nat, oracle, eng, rows, q, idx, where=(q.where_min, q.where_max))
+                    q.has_where = 0
+                got = eng.gather(q)
+                assert np.array_equal(np.sort(got["id"] - 1), np.sort(np.asarray(idx, dtype=np.int64))), (n, call)
+                cases += 1
+        finally:
+            eng.close()
+    assert cases >= 100
+
+
 def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
     """Where the reference divides by zero (DB.cpp:927, 985, 993) the C ABI returns AQE_ERR_INVALID."""
     from approximatequeryengine_amd.engine import make_query
