@@ -440,6 +440,55 @@ def test_randomised_sampler_parameters_against_the_oracle(nat, oracle):
     assert cases >= 100
 
 
+def test_randomised_clt_schedules_against_the_oracle(nat, oracle):
+    """Seeded sweep over CLT queries nobody picked by hand — table size, distribution (uniform, skewed, constant head),
+    sample percent, pointers, error bound, round schedule — in whatever form the library picks (full launch, head form
+    with or without the top-up slot, continuation after a failed prediction, launch by launch, graph): decisions,
+    counts and sums equal the oracle's round-synchronous restatement of DB.cpp:885-1043."""
+    import os
+    from approximatequeryengine_amd.engine import Engine, make_query
+    rng = np.random.default_rng(int(os.environ.get("AQE_FUZZ_SEED", "7")))
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]
+    cases = 0
+    for _ in range(int(os.environ.get("AQE_FUZZ_TABLES", "8"))):
+        n = int(pick(5_000, 20_000, 100_003, 400_000, 1_000_000, int(rng.integers(3_000, 700_000))))
+        rows = oracle.synth(n, seed=int(rng.integers(1, 1000)))
+        kind = pick("uniform", "skewed", "flat_head")
+        if kind == "skewed":
+            rows["amount"] = np.exp(rng.normal(3.0, 1.2, n))
+        elif kind == "flat_head":
+            # (noise, not a pattern: a periodic head lets a strided pointer draw one single value, and with zero variance
+            # "error <= 0" hangs on the last bit of the reference's two-pass mean)
+            rows["amount"][: min(n, 4096)] = 500.0 + 1e-3 * rng.random(min(n, 4096))
+        eng = Engine(0)
+        try:
+            eng.stage_records(rows, keep_aos=False)
+            for _ in range(6):
+                pct = float(pick(5.0, 10.0, 20.0, 33.0, 50.0))
+                conf = float(pick(0.9, 0.95, 0.99))
+                ci = int(pick(4, 10, 20))
+                T = int(pick(1, 2, 3, 4, 5, 6, 8, 16))
+                e = float(pick(0.0, 0.05, 0.3, 1.0, 2.0, 5.0, 20.0))
+                R0 = int(pick(16, 64, 256, 1024, 4096, int(rng.integers(8, 5000))))
+                g = int(pick(2, 3, 4))
+                rc, want, _ = oracle.clt_run(rows, pct, conf, ci, T, e, R0=R0, growth=g)
+                q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=conf, check_interval=ci, num_threads=T,
+                               max_error_percent=e, clt_round0=R0, clt_growth=g)
+                if rc != 0:  # parameters the reference divides by zero on
+                    with pytest.raises(nat.AqeError):
+                        eng.reduce(q)
+                    continue
+                for rep in range(2):  # (the second execution may take another form: a failed prediction switches the plan)
+                    r = eng.reduce(q)
+                    assert (r.converged, r.rounds, r.topup, r.n, r.visited, r.topup_pending) == \
+                        (want.converged, want.rounds, want.topup, want.final.n, want.final.n, 0), (n, kind, pct, conf, ci, T, e, R0, g, rep)
+                    assert rel(r.sum, want.final.sum) <= SUM_TOL and rel(r.m2, want.final.m2) <= 1e-9
+                cases += 1
+        finally:
+            eng.close()
+    assert cases >= 30
+
+
 def test_clt_invalid_parameters_are_errors_not_crashes(nat, engines):
     """Where the reference divides by zero (DB.cpp:927, 985, 993) the C ABI returns AQE_ERR_INVALID."""
     from approximatequeryengine_amd.engine import make_query
