@@ -1003,6 +1003,41 @@ def test_group_by_with_per_group_interval(nat, oracle, table):
                 assert sum(r.visited for r in got) == len(idx)
 
 
+def test_group_by_key_ranges_nobody_picked_by_hand(nat, oracle):
+    """GROUP BY over key columns of 1 ... 1024 distinct values, offset and negative minima, sparse keys — the register
+    bins (<= 8 keys), the LDS bins, and their borders — with several samplers and WHERE, against the oracle's grouping."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    rng = np.random.default_rng(99)
+    n = 200_003
+    rows = oracle.synth(n, seed=5)
+    for nb, kmin, sparse in ((1, 0, False), (2, -1, False), (3, 7, False), (5, -2, False), (7, 100, False), (8, 0, False), (9, 0, False),
+                             (17, -8, False), (64, 1000, False), (1000, -500, False), (1024, 0, False), (40, 3, True)):
+        keys = kmin + rng.integers(0, nb, n)
+        if sparse:
+            keys = kmin + (rng.integers(0, 4, n) * 13)  # four keys spread over a span of 40
+        rows["region"] = keys.astype(np.int32)
+        rows["product_id"] = (kmin + (np.arange(n) * 7) % nb).astype(np.int32)
+        with Engine(0) as eng:
+            eng.stage_records(rows, keep_aos=True)
+            for q, idx, where in (
+                (make_query(nat.M_EXACT, 100.0), np.arange(n, dtype=np.uint64), None),
+                (make_query(nat.M_BLOCK, 7.0, block_size=333, where=(200.0, 900.0)), oracle.idx_block(n, 7.0, 333), (200.0, 900.0)),
+                (make_query(nat.M_MEMORY_STRIDE, 3.0), oracle.idx_memory_stride(n, 3.0), None),
+            ):
+                for column in (nat.GROUP_REGION, nat.GROUP_PRODUCT):
+                    got = eng.reduce_grouped(q, column, max_groups=1024)
+                    want = {k: (c, s_, q_) for k, c, s_, q_ in oracle.group(rows, column, idx=idx, where=where, cap=4096)}
+                    vis = dict((k, c) for k, c, *_ in oracle.group(rows, column, idx=idx, cap=4096))
+                    assert [r.key for r in got] == sorted(vis), (nb, kmin, column)
+                    for r in got:
+                        c, s_, q_ = want.get(r.key, (0, 0.0, 0.0))
+                        assert (r.n, r.visited) == (c, vis[r.key]), (nb, kmin, column, r.key)
+                        # (sums are kept shifted by c ~ 500 and S, Q rebuilt from them: exact to rounding of n c and n c^2,
+                        # which for a group of one small amount is coarser than rounding of S and Q themselves)
+                        assert abs(r.sum - s_) <= SUM_TOL * max(abs(s_), 1e3 * max(c, 1)) and abs(r.sumsq - q_) <= SUM_TOL * max(abs(q_), 1e6 * max(c, 1))
+                    assert sum(r.visited for r in got) == len(idx)
+
+
 def test_group_by_over_virtual_shards(nat, oracle, table):
     """The multi-GPU form of GROUP BY on G shards of one GPU: agree the key range, bin per shard, add the bins
     (stand-in for the all-reduce), finish — identical to the single-shard answer for G in {1, 2, 3, 8}."""
