@@ -389,7 +389,7 @@ def test_randomised_sampler_parameters_against_the_oracle(nat, oracle):
     pick = lambda *xs: xs[int(rng.integers(len(xs)))]
     cases = 0
     for _ in range(int(os.environ.get("AQE_FUZZ_TABLES", "14"))):
-        n = int(pick(1, 2, 63, 64, 65, 999, 1000, 1001, 4097, 12_345, 99_999, 250_001, int(rng.integers(2000, 400_000))))
+        n = int(pick(1, 2, 63, 64, 65, 999, 1000, 1001, 4097, 12_345, 99_999, 250_001, int(rng.integers(2000, int(os.environ.get("AQE_FUZZ_MAXN", "400000"))))))
         rows = oracle.synth(n, seed=int(rng.integers(1, 1000)))
         eng = Engine(0)
         try:
