@@ -149,6 +149,9 @@ def lib() -> C.CDLL:
         "aqe_batch_join": (C.c_int, [vp, vp]),
         "aqe_batch_enqueue_replays": (C.c_int, [vp, vp, u64, vp]),
         "aqe_batch_fetch": (C.c_int, [vp, P(Result)]),
+        "aqe_batch_enqueue_all": (C.c_int, [vp, vp]),
+        "aqe_batch_set_profiling": (C.c_int, [vp, C.c_int]),
+        "aqe_batch_launch_info": (C.c_int, [vp, P(C.c_float), P(u64), P(u32)]),
         "aqe_plan_reset": (C.c_int, [vp, vp]),
         "aqe_plan_fetch": (C.c_int, [vp, P(Result), vp]),
         "aqe_plan_last_kernel_ms": (C.c_int, [vp, P(C.c_float)]),

@@ -104,7 +104,10 @@ __device__ __forceinline__ unsigned flags_rounds(const unsigned long long (&f)[4
 }
 
 // One poll: the number of complete rounds (>= judged).
-__device__ __forceinline__ unsigned monitor_poll(KargPtr Kv, unsigned judged) {
+// kEpochArg: the launch's epoch comes as an argument instead of out of the descriptor (k_sweep_multi: the descriptors
+// of a batch are written once; only the epoch changes from launch to launch).
+template <bool kEpochArg = false>
+__device__ __forceinline__ unsigned monitor_poll(KargPtr Kv, unsigned judged, unsigned long long epoch_arg = 0) {
     u64 kbits = uniform64(reinterpret_cast<u64>(Kv));
     asm volatile("" : "+s"(kbits));  // nothing of this is to be hoisted into every wave's prologue
     const KargPtr K = (KargPtr)kbits;
@@ -114,7 +117,7 @@ __device__ __forceinline__ unsigned monitor_poll(KargPtr Kv, unsigned judged) {
     const unsigned sb_hi = K->step_begin[(lane < rounds ? lane : rounds - 1u) + 1u];
     unsigned long long f[4];
     flags_issue(K->partials, S, lane, f);
-    return flags_rounds(f, K->epoch, S, judged, rounds, sb_hi, lane);
+    return flags_rounds(f, kEpochArg ? epoch_arg : K->epoch, S, judged, rounds, sb_hi, lane);
 }
 
 struct FoldOut {
@@ -139,14 +142,15 @@ struct FoldOut {
 // warm != 0 (1: the estimate worked out beside the rules, 2: worked out after the decision — an early stop, the
 // head form): a rehearsal while the monitor has nothing to do — same instructions, nothing folded, results
 // written to a scratch area — so that the real call finds its code in the instruction cache.
-__device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigned p_newv, double run, unsigned warm) {
+template <bool kEpochArg = false>
+__device__ __forceinline__ FoldOut monitor_fold(KargPtr Kv, unsigned pv, unsigned p_newv, double run, unsigned warm, unsigned long long epoch_arg = 0) {
     u64 kbits = uniform64(reinterpret_cast<u64>(Kv));
     asm volatile("" : "+s"(kbits));
     const KargPtr K = (KargPtr)kbits;
     unsigned p = __builtin_amdgcn_readfirstlane(pv), p_new = __builtin_amdgcn_readfirstlane(p_newv);
     const unsigned lane = threadIdx.x & 63;
     const unsigned rounds = K->rounds;
-    const unsigned long long epoch = K->epoch;
+    const unsigned long long epoch = kEpochArg ? epoch_arg : K->epoch;
     const bool totals_only = K->totals_only != 0;
     const bool tslot = K->topup_slot != 0;              // the last slot is the top-up: summed on its own, never judged
     const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
@@ -431,11 +435,151 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
     stamp_wave(P, 3, lane);
 }
 
+
+// ---- k_sweep_multi: a BATCH of queries in ONE launch ------------------------------------------------------------
+//
+// A 10 M-row query is a 5 us sweep inside a launch whose fixed costs (start, hand-off, the monitor's decision tail)
+// are twice that; the reference pays the analogous price per call by creating its worker threads per query
+// (custom_bplus_db.cpp:918-1029).  Here a batch of Q independent queries shares one launch: the grid is cut into Q
+// GROUPS of workgroups, group q runs query q exactly as a launch of its own would — its own descriptor (a
+// PersistLaunch in device memory, written once when the batch is made), its own partial list, its own monitor wave
+// (wave 0 of the group's first workgroup), its own should_stop word — and the start and the tails of all Q queries
+// are paid once, side by side.  Only the launch epoch changes from launch to launch: it travels as an argument.
+// A workgroup finds its place through wg_map[blockIdx.x] = query << 32 | group size << 16 | index in the group.
+__device__ __forceinline__ void leave_round_multi(KargPtr K, unsigned bid, unsigned G, unsigned long long epoch, unsigned r, const Acc& acc, int lane,
+                                                  unsigned wave, double (*lds_part)[kPersistWaves][kVec], unsigned* lds_cnt) {
+    const double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
+                         static_cast<double>(acc.nv)};
+    const double mine = wave_sum7(v, lane);  // lane 8c holds component c
+    if ((lane & 7) == 0 && lane < 56) lds_part[r][wave][lane >> 3] = mine;
+    const unsigned V = G * kPersistWaves - 1u;    // the group's sweepers: every wave but its monitor
+    const unsigned v0 = bid * kPersistWaves - 1u;  // sweeper id of this workgroup's wave 0 (wraps for the monitor)
+    const u64 b0 = K->round_begin[r], b1 = K->round_begin[r + 1];
+    const unsigned m0 = K->round_mod[r];
+    unsigned nw = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kPersistWaves; ++j) nw += (v0 + j != ~0u && sweeper_has_tile(v0 + j, V, b0, m0, b1)) ? 1u : 0u;
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&lds_cnt[r], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old + 1 != nw) return;
+    const size_t slot = 8u * static_cast<size_t>(K->step_begin[r]) + ((bid - K->part_first[r]) & (G - 1u));
+    double* const out = K->partials + slot * kVec;
+    if (lane < 7) {
+        double x[kPersistWaves];
+#pragma unroll
+        for (unsigned j = 0; j < kPersistWaves; ++j) x[j] = lds_part[r][j][lane];
+        double s = 0.0;
+#pragma unroll
+        for (unsigned j = 0; j < kPersistWaves; ++j) s += (v0 + j != ~0u && sweeper_has_tile(v0 + j, V, b0, m0, b1)) ? x[j] : 0.0;
+        __hip_atomic_store(out + lane, s, AQE_RLX);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // data, drain, flag (Guideline 16)
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 7), epoch, AQE_RLX);
+}
+
+// The monitor of one group.  Its wait is bounded by the device clock, not by a poll count: groups of a large batch
+// may sit behind other groups' workgroups for as long as those take.  On give-up it also raises should_stop, so the
+// group's sweepers leave instead of finishing a query nobody will report.
+constexpr unsigned long long kMultiGiveUpTicks = 3000000000ull;  // 30 s of the 100 MHz clock
+__device__ __forceinline__ void monitor_main_multi(KargPtr K, unsigned long long epoch) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    if (K->want_ticks && lane == 0) lds_t0 = t_start;
+    unsigned judged = 0;
+    double run = 0.0;
+    for (;;) {
+        unsigned complete = monitor_poll<true>(K, judged, epoch);
+        if (K->topup_slot != 0 && complete != K->rounds) complete = judged;  // that form is judged once, when everything is in
+        if (complete > judged) {
+            const FoldOut o = monitor_fold<true>(K, judged, complete, run, 0u, epoch);  // does not return if the query ends here
+            run = o.run;
+            judged = o.judged;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(8);  // ~0.25 us: Q monitors poll side by side, and nothing here is on a critical path
+        if (__builtin_amdgcn_s_memrealtime() - t_start > kMultiGiveUpTicks) {
+            if (lane == 0) {  // report it (aqe_result.device_status) instead of hanging
+                QueryState st{};
+                st.error = 1;
+                state_store(K->state, st);
+                FinalizeParams fin;
+                fin.n_global = K->fin.n_global; fin.pct = K->fin.pct; fin.shift = K->fin.shift; fin.agg = K->fin.agg;
+                fin.convention = K->fin.convention; fin.is_exact = K->fin.is_exact; fin.is_clt = K->fin.is_clt;
+                finalize(st, fin, K->result);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&K->ctl->stop_word, (epoch << 8) | 1ull, AQE_RLX);
+            }
+            break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPersistThreads) void k_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch) {
+    __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];
+    __shared__ unsigned lds_cnt[kMaxPersistRounds];
+    __shared__ DevFamily lds_fams[kMaxLdsFams];
+    if (threadIdx.x < kMaxPersistRounds) lds_cnt[threadIdx.x] = 0;
+    const u64 me = uniform64(wg_map[blockIdx.x]);
+    const unsigned G = static_cast<unsigned>(me >> 16) & 0xffffu, bid = static_cast<unsigned>(me) & 0xffffu;
+    const KargPtr K = (KargPtr)(table + (me >> 32));
+    SweepCommon sw;
+    sw.amount = K->sw.amount; sw.shard_lo = K->sw.shard_lo; sw.fams = K->sw.fams; sw.nfam = K->sw.nfam; sw.has_where = K->sw.has_where;
+    sw.wmin = K->sw.wmin; sw.wmax = K->sw.wmax; sw.shift = K->sw.shift; sw.dense16 = K->sw.dense16; sw.pad = 0;
+    const DevFamily* fams = stage_families(sw, lds_fams);
+    if (sw.nfam > kMaxLdsFams) __syncthreads();  // (stage_families took the barrier otherwise: lds_cnt is published either way)
+
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = threadIdx.x >> 6;
+    const u64 w = uniform64(static_cast<u64>(bid) * kPersistWaves + wave);  // wave id within the group
+    if (w == 0) {
+        monitor_main_multi(K, epoch);
+        return;
+    }
+    const u64 V = static_cast<u64>(G) * kPersistWaves - 1u;
+    const u64 ntiles = K->ntiles;
+    const unsigned nfam = sw.nfam;
+    const unsigned long long stop_tag = (epoch << 8) | 1ull;
+    const unsigned long long* const stop_word = &K->ctl->stop_word;
+
+    Acc acc;
+    unsigned r = 0;
+    u64 round_end = 0;
+    bool open = false;
+    u64 t = w - 1u;
+    for (;;) {
+        const bool have = t < ntiles;
+        if (open && (!have || t >= round_end)) {  // round r is finished for this wave
+            leave_round_multi(K, bid, G, epoch, r, acc, lane, wave, lds_part, lds_cnt);
+            acc = Acc{};
+            open = false;
+            continue;
+        }
+        if (!have) break;
+        const unsigned long long sw_word = __hip_atomic_load(stop_word, AQE_RLX);  // should_stop (DB.cpp:930/987)
+        const DevFamily& F = fams[find_family(fams, nfam, t)];
+        r = __builtin_amdgcn_readfirstlane(F.round);
+        round_end = uniform64(F.round_end);
+        sweep_family(sw, F, t, lane, ~0ull, acc);
+        open = true;
+        t += V;
+        if (sw_word == stop_tag) break;  // this query's monitor ended it: nothing is owed to anybody
+    }
+}
+
 }  // namespace
 
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) hipExtLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
     else hipLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, hipStream_t s,
+                              hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) hipExtLaunchKernelGGL(k_sweep_multi, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, table, wg_map, epoch);
+    else hipLaunchKernelGGL(k_sweep_multi, dim3(grid), dim3(kPersistThreads), 0, s, table, wg_map, epoch);
     return hipGetLastError();
 }
 

@@ -438,6 +438,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                     // (Measured, bench query at e = 1 %: 230 k aggregates/s and 14 us per launch, against 76-100 k for
                     // one launch per round replayed as a graph, which is what such plans used before.)
                     const size_t r_head = std::min(R, r_stop + 1);
+                    p->r_head = r_head;
                     // Attempts, in order: rounds + top-up on one tile per wave; the same on half the largest grid when that many
                     // workgroups' partials would not fit the monitor's one window of steps and the top-up is small enough
                     // (<= 64 MB) for half the chip to sweep it faster than a second launch would start; the rounds alone.
@@ -492,17 +493,18 @@ int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
 
 namespace {
 
-int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_totals, hipStream_t s) {
+// The descriptor of one persistent sweep of form F of plan p (what k_sweep_persist takes by value and k_sweep_multi reads
+// from its table).  `inline_ok`: the family table may travel in the descriptor (kernel arguments of a single launch).
+void fill_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_totals, unsigned long long epoch, bool inline_ok, PersistLaunch& a) {
     aqe_ctx* c = p->ctx;
-    PersistLaunch a{};
+    a = PersistLaunch{};
     a.sw = sweep_common(p, F.d_fams, static_cast<uint32_t>(F.h_fams.size()));
     a.ntiles = F.ntiles;
     for (uint32_t r = 0; r <= F.slots; ++r) a.round_begin[r] = F.round_begin[r];
     for (uint32_t r = 0; r < F.slots; ++r) { a.part_first[r] = F.part_first[r]; a.part_count[r] = F.part_count[r]; }
     for (uint32_t r = 0; r <= F.slots; ++r) { a.step_begin[r] = F.step_begin[r]; a.round_mod[r] = F.round_mod[r]; }
     a.rounds = F.slots;
-    a.epoch = c->epoch++;
-    p->poll_epoch = totals_only ? 0 : a.epoch;
+    a.epoch = epoch;
     a.ctl = p->d_ctl;
     a.partials = F.d_ppart;
     a.state = p->d_state;
@@ -519,15 +521,23 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     a.topup_slot = totals_only ? 0u : F.topup_slot;
     a.topup_gate = p->host.has_topup ? 1u : 0u;
     a.totals_only = totals_only ? 1u : 0u;
-    p->last_exec = totals_only ? 2 : 1;
-    p->last_grid = F.grid;
     a.out_totals = out_totals;
-    a.inline_fams = (F.h_fams.size() <= static_cast<size_t>(kPersistInlineFams) && F.ntiles < 0xffffffffull) ? 1u : 0u;
+    a.inline_fams = (inline_ok && F.h_fams.size() <= static_cast<size_t>(kPersistInlineFams) && F.ntiles < 0xffffffffull) ? 1u : 0u;
     if (a.inline_fams) {
         std::copy(F.h_fams.begin(), F.h_fams.end(), a.fams);
         for (size_t i = 0; i < static_cast<size_t>(kPersistInlineFams); ++i)
             a.fam_begin[i] = i < F.h_fams.size() ? static_cast<uint32_t>(F.h_fams[i].tile_begin) : 0xffffffffu;
     }
+}
+
+int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_totals, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    PersistLaunch a;
+    fill_form(p, F, totals_only, out_totals, c->epoch++, true, a);
+    p->poll_epoch = totals_only ? 0 : a.epoch;
+    p->last_exec = totals_only ? 2 : 1;
+    p->last_grid = F.grid;
+    p->last_form = &F;
     if (c->d_stamps) {
         HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds), s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -638,7 +648,8 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
     if (p->last_exec == 1 && p->h_result->topup_pending == 2) {
         // the head form ran out of rounds before the query stopped (the prediction failed): the remaining rounds go
         // out one launch each, the top-up behind them — and from now on this plan takes the full single launch
-        for (uint32_t i = p->head.slots - p->head.topup_slot; i < p->rounds.size(); ++i) {
+        const SweepForm& H = p->last_form ? *p->last_form : p->head;
+        for (uint32_t i = H.slots - H.topup_slot; i < p->rounds.size(); ++i) {
             int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
             if (rc != AQE_OK) return rc;
         }
@@ -753,13 +764,173 @@ int ensure_lanes(aqe_ctx* c) {
 }  // namespace
 }  // namespace aqe
 
+// One-launch form of a batch (k_sweep_multi, persist.hip): the grid is cut into one group of workgroups per plan, group i
+// sweeps plan i's rounds with a form built for the group's size.  kind 0: decisions taken in the kernel (single GPU:
+// the plan's decide form, or its head form when the query is predicted to stop early); kind 1: totals only (multi-GPU).
+struct BatchMulti {
+    bool built = false;
+    std::vector<SweepForm> forms;          // group form of plan i
+    PersistLaunch* d_table = nullptr;      // [plans] descriptors, written once
+    unsigned long long* d_wgmap = nullptr; // [grid] workgroup -> (plan, group size, index in the group)
+    unsigned grid = 0;
+    uint64_t samples = 0;                  // rows one launch sweeps (all plans)
+    const double* totals = nullptr;        // kind 1: the buffer the descriptors were written for
+    uint64_t stride = 0;
+};
+
 struct aqe_batch {
     aqe_ctx* ctx = nullptr;
-    std::vector<aqe_plan*> plans;   // plan i runs on lane i % kBatchLanes of the context
+    std::vector<aqe_plan*> plans;
     std::vector<hipEvent_t> swept;  // lane l's sweeps of this batch are enqueued up to here
     hipEvent_t reduced = nullptr;   // the caller's stream up to (and including) the collective and the replays
     ReplayItem* d_items = nullptr;  // one entry per plan, for the single replay launch
+    BatchMulti multi[2];
+    hipStream_t last_stream = nullptr;  // where the most recent one-launch execution went
+    int last_kind = -1;
+    bool profile = false;               // aqe_batch_set_profiling: the launch carries an event pair on its dispatch
+    bool profiled = false;              // ... and the most recent launch did
+    hipEvent_t pev0 = nullptr, pev1 = nullptr;
 };
+
+namespace aqe {
+namespace {
+
+void free_multi(BatchMulti& m) {
+    for (SweepForm& f : m.forms)
+        if (f.d_ppart) (void)hipFree(f.d_ppart);
+    m.forms.clear();
+    if (m.d_table) (void)hipFree(m.d_table);
+    if (m.d_wgmap) (void)hipFree(m.d_wgmap);
+    m.d_table = nullptr;
+    m.d_wgmap = nullptr;
+    m.built = false;
+}
+
+uint64_t head_tiles(const aqe_plan* p) {
+    uint64_t t = p->host.has_topup ? p->topup.ntiles : 0;
+    for (size_t r = 0; r < p->r_head && r < p->rounds.size(); ++r) t += p->rounds[r].ntiles;
+    return t;
+}
+
+// Builds the one-launch form of a batch: group sizes in proportion to the plans' tiles (powers of two, the context's
+// persistent grid as the budget), one sweep form per plan for its group's size, the descriptor table, the workgroup map.
+int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride) {
+    aqe_ctx* c = b->ctx;
+    BatchMulti& m = b->multi[kind];
+    HIPCHK(c, hipDeviceSynchronize());  // a previous launch may still be reading the old table and partial lists
+    free_multi(m);
+    const size_t n = b->plans.size();
+    std::vector<uint64_t> w(n, 0);
+    std::vector<char> head(n, 0);
+    uint64_t wsum = 0;
+    for (size_t i = 0; i < n; ++i) {
+        aqe_plan* p = b->plans[i];
+        const size_t R = p->rounds.size();
+        if (p->host.is_random || R == 0 || R > static_cast<size_t>(kMaxPersistRounds))
+            return fail(c, AQE_ERR_UNSUPPORTED, "a plan of the batch has no single-launch form (seeded-random sampler, empty sample or more than 32 rounds)");
+        bool every = true;
+        for (size_t r = 0; r < R; ++r) every = every && p->rounds[r].ntiles > 0;
+        if (kind == 0 && !(c->shard_lo == 0 && c->n_local == c->n_global && every))
+            return fail(c, AQE_ERR_UNSUPPORTED, "in-kernel decisions need the whole table in this context and rows in every round; shards take the totals form");
+        head[i] = kind == 0 && p->per_round && p->r_head > 0 && p->r_head <= R;
+        if (head[i]) w[i] = head_tiles(p);
+        else for (size_t r = 0; r < R; ++r) w[i] += p->rounds[r].ntiles;
+        w[i] = std::max<uint64_t>(w[i], 1);
+        wsum += w[i];
+    }
+    // Group sizes: powers of two (the cyclic-run arithmetic of a form wants one), in proportion to the plans' tiles, the
+    // context's persistent grid (one workgroup per compute unit) as the budget.  Rounding down leaves up to half the
+    // budget unused, so the groups with the most tiles per workgroup are doubled while the budget allows.
+    const uint64_t budget = std::max(1u, c->persist_grid);
+    std::vector<uint32_t> gs(n, 1);
+    auto cap_of = [&](size_t i) {  // no more workgroups than one tile per sweeper wave needs
+        uint32_t cap = 1;
+        while (cap < static_cast<uint32_t>(kMaxPersistGrid) && static_cast<uint64_t>(cap) * kPersistWaves - 1 < w[i]) cap *= 2;
+        return cap;
+    };
+    uint64_t used = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double share = static_cast<double>(budget) * static_cast<double>(w[i]) / static_cast<double>(wsum);
+        while (2.0 * gs[i] <= share && 2u * gs[i] <= cap_of(i)) gs[i] *= 2;
+        used += gs[i];
+    }
+    for (;;) {
+        size_t best = n;
+        double best_load = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            if (used + gs[i] > budget || 2u * gs[i] > cap_of(i)) continue;
+            const double load = static_cast<double>(w[i]) / gs[i];
+            if (load > best_load) { best_load = load; best = i; }
+        }
+        if (best == n) break;
+        used += gs[best];
+        gs[best] *= 2;
+    }
+    m.forms.resize(n);
+    std::vector<PersistLaunch> table(n);
+    std::vector<unsigned long long> wgmap;
+    m.samples = 0;
+    for (size_t i = 0; i < n; ++i) {
+        aqe_plan* p = b->plans[i];
+        const size_t R = p->rounds.size();
+        const uint32_t g = gs[i];
+        SweepForm& F = m.forms[i];
+        int rc = AQE_OK;
+        if (head[i]) {
+            // rounds + top-up as one more slot (the monitor judges once, from one window of steps), else the rounds alone
+            bool done = false;
+            if (p->host.has_topup) {
+                rc = build_sweep_form(p, true, F, g, p->r_head);
+                if (rc != AQE_OK) return rc;
+                if (F.step_begin[F.slots] <= static_cast<uint32_t>(kDecSteps)) done = true;
+                else { (void)hipFree(F.d_ppart); F = SweepForm{}; }
+            }
+            if (!done) rc = build_sweep_form(p, false, F, g, p->r_head);
+        } else {
+            rc = build_sweep_form(p, false, F, g, R);
+        }
+        if (rc != AQE_OK) return rc;
+        fill_form(p, F, kind == 1, kind == 1 ? dev_totals + i * row_stride : nullptr, 0, false, table[i]);
+        table[i].stamps = nullptr;  // (the stamp layout is per launch grid: single launches only)
+        table[i].want_ticks = 0;
+        for (uint32_t k = 0; k < g; ++k)
+            wgmap.push_back((static_cast<unsigned long long>(i) << 32) | (static_cast<unsigned long long>(g) << 16) | k);
+        m.samples += F.samples;
+    }
+    m.grid = static_cast<unsigned>(wgmap.size());
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_table), n * sizeof(PersistLaunch)));
+    HIPCHK(c, hipMemcpy(m.d_table, table.data(), n * sizeof(PersistLaunch), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_wgmap), wgmap.size() * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemcpy(m.d_wgmap, wgmap.data(), wgmap.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    m.totals = dev_totals;
+    m.stride = row_stride;
+    m.built = true;
+    return AQE_OK;
+}
+
+int launch_multi(aqe_batch* b, int kind, hipStream_t s) {
+    aqe_ctx* c = b->ctx;
+    BatchMulti& m = b->multi[kind];
+    const unsigned long long epoch = c->epoch++;
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        aqe_plan* p = b->plans[i];
+        p->poll_epoch = kind == 0 ? epoch : 0;
+        p->last_exec = kind == 0 ? 1 : 2;
+        p->last_form = &m.forms[i];
+        p->last_grid = m.forms[i].grid;
+        p->lev_used = 0;
+        p->timed = false;
+        p->tick_timed = false;
+    }
+    b->profiled = b->profile;
+    HIPCHK(c, launch_sweep_multi(m.d_table, m.d_wgmap, epoch, m.grid, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
+    b->last_stream = s;
+    b->last_kind = kind;
+    return AQE_OK;
+}
+
+}  // namespace
+}  // namespace aqe
 
 extern "C" {
 
@@ -857,6 +1028,12 @@ void aqe_batch_destroy(aqe_batch* b) {
         (void)hipSetDevice(b->ctx->device);
         for (hipStream_t s : b->ctx->lanes) (void)hipStreamSynchronize(s);
     }
+    if (b->ctx) (void)hipDeviceSynchronize();  // fetch() may have returned before the batch's last launch had ended
+    for (BatchMulti& m : b->multi) free_multi(m);
+    for (aqe_plan* p : b->plans)
+        if (p) p->last_form = nullptr;  // (pointed into this batch's forms)
+    if (b->pev0) (void)hipEventDestroy(b->pev0);
+    if (b->pev1) (void)hipEventDestroy(b->pev1);
     for (hipEvent_t e : b->swept) (void)hipEventDestroy(e);
     if (b->reduced) (void)hipEventDestroy(b->reduced);
     if (b->d_items) (void)hipFree(b->d_items);
@@ -867,7 +1044,6 @@ int aqe_batch_create(aqe_plan* const* plans, uint32_t n, aqe_batch** out) {
     if (!plans || !out || n == 0) return AQE_ERR_INVALID;
     for (uint32_t i = 0; i < n; ++i) {
         if (!plans[i] || !plans[i]->ctx || plans[i]->ctx != plans[0]->ctx) return AQE_ERR_INVALID;
-        if (!plans[i]->totals.ok) return fail(plans[i]->ctx, AQE_ERR_UNSUPPORTED, "a plan of the batch has no batched (totals) form");
         for (uint32_t j = 0; j < i; ++j)
             if (plans[j] == plans[i]) return fail(plans[i]->ctx, AQE_ERR_INVALID, "a plan may appear once in a batch (its hand-off scratch is its own)");
     }
@@ -900,17 +1076,80 @@ int aqe_batch_enqueue_sweeps(aqe_batch* b, double* dev_totals, uint64_t row_stri
     if (!b || !dev_totals) return AQE_ERR_INVALID;
     aqe_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    for (aqe_plan* p : b->plans) {
+        int rc = plan_is_current(p);
+        if (rc != AQE_OK) return rc;
+        if (p->rounds.size() < 2) return fail(c, AQE_ERR_UNSUPPORTED, "a plan of the batch has no batched (totals) form (single round: use the per-round calls)");
+        if (row_stride < static_cast<uint64_t>(p->rounds.size()) * kVec) return fail(c, AQE_ERR_INVALID, "row_stride shorter than a plan's totals");
+    }
+    BatchMulti& m = b->multi[1];
+    if (!m.built || m.totals != dev_totals || m.stride != row_stride) {
+        int rc = build_multi(b, 1, dev_totals, row_stride);
+        if (rc != AQE_OK) return rc;
+    }
+    // ONE launch sweeps every plan's rounds (a group of workgroups per plan) on the first side stream; the plans'
+    // previous replay precedes it there (aqe_batch_enqueue_replays makes the side streams wait for it)
+    int rc = launch_multi(b, 1, c->lanes[0]);
+    if (rc != AQE_OK) return rc;
+    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipEventRecord(b->swept[l], c->lanes[l]));
+    return AQE_OK;
+}
+
+int aqe_batch_enqueue_all(aqe_batch* b, void* stream) {
+    if (!b) return AQE_ERR_INVALID;
+    aqe_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    BatchMulti& m = b->multi[0];
+    bool stale = !m.built;
     for (size_t i = 0; i < b->plans.size(); ++i) {
         aqe_plan* p = b->plans[i];
         int rc = plan_is_current(p);
         if (rc != AQE_OK) return rc;
-        if (row_stride < static_cast<uint64_t>(p->totals.slots) * kVec) return fail(c, AQE_ERR_INVALID, "row_stride shorter than a plan's totals");
-        p->lev_used = 0;
-        // (the plan's previous replay precedes this sweep in its lane: nothing to wait for)
-        rc = launch_form(p, p->totals, true, dev_totals + i * row_stride, c->lanes[i % kBatchLanes]);
+        // a head form whose prediction failed (fetch continued the query round by round): the plan takes the full form now
+        if (m.built && m.forms[i].more_rounds && !p->per_round) stale = true;
+    }
+    if (stale) {
+        int rc = build_multi(b, 0, nullptr, 0);
         if (rc != AQE_OK) return rc;
     }
-    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipEventRecord(b->swept[l], c->lanes[l]));
+    int rc = launch_multi(b, 0, s);
+    if (rc != AQE_OK) return rc;
+    // The reference's top-up (DB.cpp:1031-1040) is rarely due: its launch (device-gated) goes out only for plans whose
+    // previous execution needed it and whose form does not sweep it as a slot; otherwise fetch runs it when the result asks.
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        aqe_plan* p = b->plans[i];
+        if (p->host.has_topup && p->expect_topup && !m.forms[i].topup_slot) {
+            rc = enqueue_launch(p, p->topup, static_cast<uint32_t>(p->rounds.size()), true, true, nullptr, s);
+            if (rc != AQE_OK) return rc;
+        }
+    }
+    return AQE_OK;
+}
+
+int aqe_batch_set_profiling(aqe_batch* b, int enable) {
+    if (!b) return AQE_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    if (enable && !b->pev0) {
+        HIPCHK(b->ctx, hipEventCreate(&b->pev0));
+        HIPCHK(b->ctx, hipEventCreate(&b->pev1));
+    }
+    b->profile = enable != 0;
+    return AQE_OK;
+}
+
+int aqe_batch_launch_info(aqe_batch* b, float* ms, uint64_t* samples, uint32_t* workgroups) {
+    if (!b) return AQE_ERR_INVALID;
+    if (b->last_kind < 0) return fail(b->ctx, AQE_ERR_INVALID, "no one-launch execution yet");
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    const BatchMulti& m = b->multi[b->last_kind];
+    if (samples) *samples = m.samples;
+    if (workgroups) *workgroups = m.grid;
+    if (ms) {
+        if (!b->profiled) return fail(b->ctx, AQE_ERR_INVALID, "the most recent launch was not profiled (aqe_batch_set_profiling)");
+        HIPCHK(b->ctx, hipEventSynchronize(b->pev1));
+        HIPCHK(b->ctx, hipEventElapsedTime(ms, b->pev0, b->pev1));
+    }
     return AQE_OK;
 }
 
@@ -945,7 +1184,9 @@ int aqe_batch_fetch(aqe_batch* b, aqe_result* out_n) {
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
     for (size_t i = 0; i < b->plans.size(); ++i) {
         int rc = plan_is_current(b->plans[i]);
-        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, b->ctx->lanes[i % kBatchLanes]);
+        // (totals form: the replay ran on the caller's stream and the side streams wait for it; one-launch form: its stream)
+        hipStream_t s = b->last_kind == 0 ? b->last_stream : b->ctx->lanes[i % kBatchLanes];
+        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, s);
         if (rc != AQE_OK) return rc;
     }
     return AQE_OK;

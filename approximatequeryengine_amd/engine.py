@@ -99,9 +99,15 @@ class Plan:
 
 
 class Batch:
-    """Plans of one Engine driven through the batched multi-GPU form together (aqe_batch): the sweeps run on
-    the engine's side streams, ``stream`` — where the caller issues the collective — is made to wait for them
-    (join), and the replays go back to the side streams.  Three host calls per step for the whole batch."""
+    """Plans of one Engine executed together (aqe_batch).
+
+    Single GPU: ``enqueue_all(stream)`` runs every plan's query in ONE launch (a group of workgroups per plan, each
+    with its own monitor wave and should_stop word) and ``fetch()`` returns the results.
+
+    Multi-GPU: the same one launch with the decisions left out (``enqueue_sweeps``: this shard's round totals per
+    plan, on the engine's side stream), ``join(stream)`` makes the caller's stream — where the collective is
+    issued — wait for it, and ``enqueue_replays`` decides every plan from the reduced totals in one more launch.
+    Three host calls per step for the whole batch."""
 
     def __init__(self, plans):
         self.plans = list(plans)
@@ -134,6 +140,18 @@ class Batch:
         out = (Result * len(self.plans))()
         nat.check(nat.lib().aqe_batch_fetch(self._h, out), self.engine._h)
         return list(out)
+
+    def enqueue_all(self, stream: int = 0):
+        nat.check(nat.lib().aqe_batch_enqueue_all(self._h, C.c_void_p(stream)), self.engine._h)
+
+    def set_profiling(self, enable: bool = True):
+        nat.check(nat.lib().aqe_batch_set_profiling(self._h, int(enable)), self.engine._h)
+
+    def launch_info(self, timed: bool = True):
+        """(milliseconds, rows swept, workgroups) of the most recent one-launch execution (ms None unless profiled)."""
+        ms, n, g = C.c_float(), C.c_uint64(), C.c_uint32()
+        nat.check(nat.lib().aqe_batch_launch_info(self._h, C.byref(ms) if timed else None, C.byref(n), C.byref(g)), self.engine._h)
+        return (ms.value if timed else None), n.value, g.value
 
 
 class Engine:

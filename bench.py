@@ -7,20 +7,30 @@
 
 Workload (BASELINE.json configs[1]): 10 M-row synthetic `sales` table per GPU (f64 amount, seed 42),
 `SELECT AVG(amount) ... --e 0.01` through the CLT dual-pointer monitor exactly as the reference CLI
-issues it (enhanced_aqe_cli.py:243-255): pct = 20 (e <= 1), confidence 0.95, check_interval 10, T = 4
-pointers per GPU, e = 0.01 PERCENT — which cannot converge on 10 M rows, so every query performs the
-full fast+slow sweep (4 M samples per GPU) with the should_stop test armed on every launch.  One step =
-one such query (value + 95 % interval) with the table resident in HBM.  SUM/AVG/COUNT share the moments.
+issues it (enhanced_aqe_cli.py:243-255): pct = 20 (e <= 1), confidence 0.95, check_interval 10,
+e = 0.01 PERCENT — which cannot converge on 10 M rows, so every query performs the full fast+slow sweep
+(4 M samples per GPU) with the should_stop test armed.  One step = one BATCH of B such queries (value +
+95 % interval each) with the table resident in HBM, executed as ONE launch (k_sweep_multi: a group of
+workgroups, a monitor wave and a should_stop word per query).  The queries of a batch are not copies of one
+another: pointer counts (T = 4, 6, ... 16), aggregates (AVG / SUM / COUNT) and thresholds differ, every
+query does all of its own loads, and EVERY result is fetched inside the timed loop (two batches alternate:
+while one sweeps, the previous one's results are read).
 
 N GPUs: weak scaling.  Each rank holds its own 10 M-row region of an N x 10 M-row table; a query runs
-T = 4N pointers over the global table, each rank sweeps what falls in its region, and ONE RCCL
-all-reduce of the 8-double moment vector per convergence step merges the regions.  `value` counts one
-10 M-row region aggregate per GPU per query (so a global query over N regions counts N); the global
-query rate is reported beside it as `global_queries_per_sec`.
+T x N pointers over the global table, each rank sweeps what falls in its region (the same one launch,
+decisions left out), ONE RCCL all-reduce of the per-round moment vectors serves the whole batch, and one
+launch replays the stop rules.  `value` counts one 10 M-row region aggregate per GPU per query (so a
+global query over N regions counts N); the global query rate is reported beside it.
+
+Besides the headline the line carries `configs` (every other BASELINE.json configuration that fits one GPU,
+each with its own launch time, algorithmic bytes and roofline fraction), `cold` (staging from a file in the
+page cache + building the stride-major views) and `cpu_baseline` (the reference's own C++ on this box's
+host cores).  `--headline-only` skips those.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,68 +40,289 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; 6.0-6.3 TB/s is what streaming kernels reach)
 ROWS_PER_GPU = 10_000_000
 SEED = 42
 CLT_ROUND0 = 4096   # samples per pointer in round 0 ...
-CLT_GROWTH = 4      # ... times 4 every round: 5 launches cover the 1 M-sample progressions
+CLT_GROWTH = 4      # ... times 4 every round: 5 rounds cover the 1 M-sample progressions
+PMC_FILE = ROOT / "profiles" / "round2_pmc_raw.json"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--error-percent", type=float, default=0.01, help="--e of the reference CLI, in percent")
-    ap.add_argument("--batch", "--streams", dest="batch", type=int, default=32,
-                    help="independent queries per step.  1 GPU: each has its own plan and HIP stream (the decision tail of "
-                         "one overlaps the sweep of the next).  N GPUs: one all-reduce serves the whole batch "
-                         "(aqe_batch: sweeps on the library's side streams, two host calls per step).")
+    ap.add_argument("--batch", type=int, default=32, help="independent queries per step (one launch serves them all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--headline-only", action="store_true", help="skip the early-termination reading (profiling runs: one kind of sweep in the trace)")
+    ap.add_argument("--headline-only", action="store_true", help="skip configs / cold / early-termination reading / cpu baseline")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration list (100 M and 1 B-row tables)")
+    ap.add_argument("--max-config-rows", type=int, default=1_000_000_000)
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     return ap.parse_args()
 
 
+def source_hash() -> str:
+    """Hash of the library's sources: the PMC traffic in profiles/ is only reported for the code it was measured on."""
+    h = hashlib.sha256()
+    files = sorted((ROOT / "approximatequeryengine_amd" / "csrc").glob("*")) + [ROOT / "include" / "aqe_hip.h"]
+    for f in files:
+        if f.suffix in (".hip", ".hpp", ".cpp", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def e_to_pct(e: float) -> float:  # enhanced_aqe_cli.py:243-250
+    return 20.0 if e <= 1.0 else 15.0 if e <= 2.0 else 10.0 if e <= 5.0 else 5.0
+
+
+def headline_queries(nat, make_query, B: int, world: int, err: float):
+    """The B queries of one step.  They differ: T = 4, 6, ... 16 pointers (x N GPUs) — other regions, other families,
+    the same 20 % of the rows (the CLI fixes pct by e) — aggregates AVG / SUM / COUNT, and thresholds a hair apart."""
+    pct = e_to_pct(err)
+    return [make_query(nat.M_CLT_DUAL_POINTER, pct, agg=(nat.AVG, nat.SUM, nat.COUNT)[i % 3], confidence_level=0.95, check_interval=10,
+                       num_threads=(4 + 2 * (i % 7)) * world, max_error_percent=err * (1.0 + 1e-3 * (i // 7)),
+                       clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH) for i in range(B)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY §8d(ii)): the reference's own C++ (oracle/_ref, built in the authoring container from
+# /root/reference) and its linear-time C restatement (oracle/), timed on this box's host cores.
+# ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline(rows_per_gpu: int, e: float, sample_rows: int) -> dict:
-    """The reference's own C++ (oracle/_ref, built in the authoring container from /root/reference) timed on
-    this box's host cores on a bounded sample; falls back to the C restatement (oracle/) when absent."""
     import numpy as np
     from oracle.pyoracle import Oracle, Ref, ref_available
     o = Oracle()
-    pct = 20.0 if e <= 1.0 else 15.0 if e <= 2.0 else 10.0 if e <= 5.0 else 5.0
-    out = {}
-    # (a) linear-time port on the full workload
+    pct = e_to_pct(e)
+    cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = cores
+    quota = None  # cgroup v2 CPU quota of this container, in cores
+    try:
+        q_, per_ = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q_ != "max":
+            quota = float(q_) / float(per_)
+    except Exception:
+        pass
+    out = {"host_cores": cores, "usable_cores": usable, "cgroup_cpu_quota": quota}
     rows = o.synth(rows_per_gpu, SEED)
+
+    def port_query():
+        rc, res, _ = o.clt_run(rows, pct, 0.95, 10, 4, e, R0=CLT_ROUND0, growth=CLT_GROWTH)
+        return res
+
+    # (a) linear-time port, one thread, full workload
     t0 = time.perf_counter()
     reps = 0
     while True:
-        rc, res, _ = o.clt_run(rows, pct, 0.95, 10, 4, e, R0=CLT_ROUND0, growth=CLT_GROWTH)
+        res = port_query()
         reps += 1
-        if time.perf_counter() - t0 > 3.0 or reps >= 20:
+        if time.perf_counter() - t0 > 2.0 or reps >= 20:
             break
     dt = (time.perf_counter() - t0) / reps
-    port = {"value": 1.0 / dt, "unit": "aggregates/sec", "cores": 1, "kind": "port",
-            "sample": f"full workload ({rows_per_gpu:,} rows, {int(res.final.n):,} samples/query), {reps} queries, "
-                      "oracle/aqe_oracle.c single thread, linear-time restatement"}
-    out["port"] = port
-    if ref_available():
+    samples = int(res.final.n)
+    out["port"] = {"value": 1.0 / dt, "unit": "aggregates/sec", "cores": 1, "kind": "port",
+                   "samples_per_sec": samples / dt, "GBps_touched": 8.0 * samples / dt / 1e9,
+                   "sample": f"full workload ({rows_per_gpu:,} rows, {samples:,} samples/query), {reps} queries, "
+                             "oracle/aqe_oracle.c single thread, linear-time restatement (in-place moments: best-effort CPU)"}
+    # (b) the same port with every usable core busy: one worker PROCESS per core (oracle/cpu_leg.py), each with its own
+    # copy of the table, started together, about 3 s each
+    import subprocess
+    T = max(1, min(usable, int(quota) if quota and quota >= 1 else usable, 32))  # (a one-GPU box gets a 16-core share)
+    env = dict(os.environ, MALLOC_MMAP_MAX_="0", MALLOC_TRIM_THRESHOLD_="2000000000", PYTHONPATH=str(ROOT))
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_leg", str(rows_per_gpu), repr(e), "3.0", str(CLT_ROUND0), str(CLT_GROWTH)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=str(ROOT), env=env) for _ in range(T)]
+    try:
+        for p_ in procs:
+            assert json.loads(p_.stdout.readline())["ready"]
+        for p_ in procs:
+            p_.stdin.write("go\n")
+            p_.stdin.flush()
+        got = [json.loads(p_.stdout.readline()) for p_ in procs]
+        rate = sum(g["queries"] / g["seconds"] for g in got)
+        out["port_all_cores"] = {"value": rate, "unit": "aggregates/sec", "cores": T, "kind": "port",
+                                 "samples_per_sec": samples * rate, "GBps_touched": 8.0 * samples * rate / 1e9,
+                                 "sample": f"{T} worker processes (one per usable host core, at most 32), each the full workload on its own copy of the table "
+                                           f"for ~3 s ({sum(g['queries'] for g in got)} queries in all)"}
+    finally:
+        for p_ in procs:
+            try:
+                p_.stdin.close()
+                p_.wait(timeout=30)
+            except Exception:
+                p_.kill()
+    if not ref_available():
+        return out
+    r = Ref()
+    try:
+        # (c) the reference's CLT monitor.  It re-scans all of a worker's samples at every check
+        # (custom_bplus_db.cpp:936-946, 993-1003): cost quadratic in rows.  Timed on a bounded table first; the full
+        # 10 M-row table only if the quadratic law says it ends within the budget.
         n = min(sample_rows, rows_per_gpu)
-        sub = rows[:n].copy()
-        r = Ref()
-        r.fill_direct(sub)
+        r.fill_direct(rows[:n].copy())
         t0 = time.perf_counter()
         ids = r.sample("clt_validated_dual_pointer_sample", pct, 0.95, 10, 4, e)
         amt = r.last_amounts(len(ids))
         _ = float(np.sum(amt)) / max(len(amt), 1)
-        dt = time.perf_counter() - t0
+        dt_small = time.perf_counter() - t0
+        scale = (rows_per_gpu / n) ** 2
+        predicted = dt_small * scale
+        ref_leg = {"unit": "aggregates/sec", "cores": 4, "kind": "reference", "host_cores": cores,
+                   "bounded_run": {"rows": n, "seconds": dt_small, "samples_returned": int(len(ids))}}
+        r.fill_direct(rows)
+        if n < rows_per_gpu and predicted <= 45.0:
+            t0 = time.perf_counter()
+            ids = r.sample("clt_validated_dual_pointer_sample", pct, 0.95, 10, 4, e)
+            amt = r.last_amounts(len(ids))
+            _ = float(np.sum(amt)) / max(len(amt), 1)
+            dt_full = time.perf_counter() - t0
+            ref_leg.update({"value": 1.0 / dt_full, "rows_per_sec": rows_per_gpu / dt_full, "samples_per_sec": len(ids) / dt_full,
+                            "sample": f"1 query on the full {rows_per_gpu:,}-row table ({len(ids):,} samples returned, {dt_full:.1f} s), "
+                                      "clt_validated_dual_pointer_sample(20, 0.95, 10, 4, e) with 4 std::async workers as the CLI hard-codes "
+                                      "(enhanced_aqe_cli.py:253-255) + the CLI's mean over the returned amounts"})
+        else:
+            ref_leg.update({"value": 1.0 / predicted if n < rows_per_gpu else 1.0 / dt_small,
+                            "sample": f"1 query on a {n:,}-row table took {dt_small:.2f} s; the full {rows_per_gpu:,}-row figure is EXTRAPOLATED by the "
+                                      f"monitor's quadratic cost (x{scale:.0f} = {predicted:.0f} s per query; it re-scans all samples at every "
+                                      "check, custom_bplus_db.cpp:936-946), because running it would take more than the bench's CPU budget"})
+        out["reference"] = ref_leg
+        # (d) the `--s 1` path as the reference really runs it (SURVEY §3.1): sampler returning records on the full table.
+        # memory_stride_sample uses the flat cache (DB.cpp:1540-1566); random_pointer_sample copies all 32 N bytes
+        # first (collect_leaf_records, DB.cpp:715-735, 856-882) and materialises its records.  The Python-side
+        # list conversion and generator sum of the CLI (CLI:189-200) are NOT included (no pybind11 module here):
+        # these are lower bounds of the reference's cost.
+        legs = {}
+        for name, args in (("memory_stride_sample", (1.0, 0.0)), ("random_pointer_sample", (1.0, 42.0)), ("block_sample", (1.0, 1000.0))):
+            t0 = time.perf_counter()
+            k = 0
+            while True:
+                ids = r.sample(name, *args)
+                amt = r.last_amounts(len(ids))
+                _ = float(np.sum(amt)) * rows_per_gpu / max(len(amt), 1)
+                k += 1
+                if time.perf_counter() - t0 > 1.5 or k >= 50:
+                    break
+            dts = (time.perf_counter() - t0) / k
+            legs[name] = {"aggregates_per_sec": 1.0 / dts, "ms_per_query": 1e3 * dts, "samples": int(len(ids)), "queries_timed": k,
+                          "rows_per_sec": rows_per_gpu / dts,
+                          "GBps_touched": (32.0 * rows_per_gpu if name == "random_pointer_sample" else 32.0 * len(ids)) / dts / 1e9}
+        out["reference_sampling_1pct"] = {"kind": "reference", "cores": 1, "rows": rows_per_gpu, "legs": legs,
+                                          "note": "reference-faithful: record-returning sampler + sum of the returned amounts; the CLI's "
+                                                  "pybind11 list conversion and Python generator sum (0.67 us per sampled row, BASELINE.md) come on top"}
+    finally:
         r.close()
-        out["reference"] = {
-            "value": 1.0 / dt, "unit": "aggregates/sec", "cores": 4, "kind": "reference",
-            "sample": f"1 query on a {n:,}-row table ({n / rows_per_gpu:.0%} of the workload rows; the reference's "
-                      f"monitor re-scans all samples at every check, custom_bplus_db.cpp:936-946, so its cost is "
-                      f"quadratic in rows), {len(ids):,} samples returned, 4 std::async workers as the CLI hard-codes"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-configuration roofline lines (one query in flight, per-launch HIP events attached to the dispatch)
+# ---------------------------------------------------------------------------------------------------------------
+def measure_config(eng, st, name, q, reps=20, note=None):
+    import statistics
+    plan = eng.plan(q)
+    try:
+        for _ in range(3):
+            plan.enqueue_all(st)
+            r = plan.fetch(st)
+        plan.set_profiling(True)
+        per_query, lat = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            plan.enqueue_all(st)
+            r = plan.fetch(st)
+            lat.append(time.perf_counter() - t0)
+            per_query.append(plan.launch_ms())
+        plan.set_profiling(False)
+        tot = sorted(sum(x) for x in per_query)
+        us = 1e3 * statistics.median(tot)
+        nbytes = 8.0 * r.visited
+        out = {"config": name, "samples": int(r.visited), "n": int(r.n), "value": r.value, "ci": [r.ci_lower, r.ci_upper],
+               "converged": int(r.converged), "rounds": int(r.rounds), "topup_rows": int(r.topup),
+               "launches_per_query": len(per_query[-1]), "kernel_us": us, "kernel_us_min": 1e3 * tot[0],
+               "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / (us * 1e-6) / 1e9 if us > 0 else None,
+               "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS if us > 0 else None,
+               "closed_loop_us_p50": 1e6 * statistics.median(lat)}
+        if note:
+            out["note"] = note
+        return out
+    finally:
+        plan.close()
+
+
+def run_configs(eng, nat, make_query, st, max_rows):
+    """SURVEY §8d configs 1, 3-local, 4-local, 5 + the dense scans: launch time from dispatch events, 8 B per sampled row."""
+    out = []
+    lib = nat.lib()
+
+    def clt(e):
+        return make_query(nat.M_CLT_DUAL_POINTER, lib.aqe_error_to_sample_percent(e), agg=nat.AVG, max_error_percent=e,
+                          clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
+
+    # configs[0] on the bench table (10 M rows): --s 1 % strided, seeded random, block
+    n = eng.info().global_rows
+    tag = f"{n // 1_000_000}M"
+    out.append(measure_config(eng, st, f"config0 {tag} stride 1% SUM (memory_stride_sample)", make_query(nat.M_MEMORY_STRIDE, 1.0),
+                              note="latency-bound: 100 k samples, 0.8 MB"))
+    out.append(measure_config(eng, st, f"config0 {tag} random 1% seed 42 SUM (random_pointer_sample, host mt19937 index list)",
+                              make_query(nat.M_RANDOM_POINTER, 1.0, seed=42), note="sparse gather: 8 B useful of every 64-B sector"))
+    out.append(measure_config(eng, st, f"{tag} block 1% B=1000 SUM", make_query(nat.M_BLOCK, 1.0)))
+    out.append(measure_config(eng, st, f"{tag} exact SUM (full scan)", make_query(nat.M_EXACT, 100.0)))
+    for rows in (100_000_000, 1_000_000_000):
+        if rows > max_rows:
+            continue
+        t0 = time.perf_counter()
+        eng.generate_synthetic(rows)
+        gen_s = time.perf_counter() - t0
+        tag = f"{rows // 1_000_000}M" if rows < 1_000_000_000 else "1B"
+        if rows == 100_000_000:
+            out.append(measure_config(eng, st, f"config2-local {tag} stride 1% SUM", make_query(nat.M_MEMORY_STRIDE, 1.0)))
+            out.append(measure_config(eng, st, f"config4 {tag} block 1% B=1000 SUM WHERE amount in [250,750]",
+                                      make_query(nat.M_BLOCK, 1.0, where=(250.0, 750.0), convention=nat.EST_CPP)))
+            out.append(measure_config(eng, st, f"{tag} CLT AVG e=0.01% (never converges)", clt(0.01)))
+        else:
+            out.append(measure_config(eng, st, f"config3-local {tag} CLT AVG e=0.005% (never converges: full 20% dual-pointer sweep)", clt(0.005), reps=10))
+            out.append(measure_config(eng, st, f"config3-local {tag} CLT AVG e=0.5% (stops early + top-up)", clt(0.5), reps=10))
+        out.append(measure_config(eng, st, f"{tag} exact SUM (full scan)", make_query(nat.M_EXACT, 100.0), reps=10))
+        out.append(measure_config(eng, st, f"{tag} stride 20% SUM", make_query(nat.M_MEMORY_STRIDE, 20.0), reps=10))
+        out.append(measure_config(eng, st, f"{tag} block 20% B=1000 SUM", make_query(nat.M_BLOCK, 20.0), reps=10))
+        out[-1]["table_generate_s"] = gen_s
+    return out
+
+
+def cold_numbers(Engine, nat, make_query, rows: int, e: float) -> dict:
+    """Cold path: a table in the reference's file format (page cache) -> HBM, then the first CLT query
+    (which builds the stride-major views of the column), then the same query warm."""
+    import tempfile
+    pct = e_to_pct(e)
+    q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, max_error_percent=e, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "sales.db")
+        with Engine(0) as g:
+            g.generate_synthetic(rows, keep_aos=True)
+            g.save_file(path)
+        size = os.path.getsize(path)
+        out = {"rows": rows, "file_bytes": size}
+        for keep in (False, True):
+            with Engine(0) as eng:
+                t0 = time.perf_counter()
+                eng.stage_file(path, keep_aos=keep)
+                t1 = time.perf_counter()
+                r = eng.reduce(q)  # plan + both stride-major views + the query
+                t2 = time.perf_counter()
+                r = eng.reduce(q)
+                t3 = time.perf_counter()
+                info = eng.info()
+                out["amounts_only" if not keep else "rows_kept"] = {
+                    "stage_file_ms": 1e3 * (t1 - t0), "file_GBps": size / (t1 - t0) / 1e9,
+                    "first_query_ms (plan + view build + sweep)": 1e3 * (t2 - t1), "second_query_ms": 1e3 * (t3 - t2),
+                    "hbm_bytes": int(info.hbm_bytes), "avg": r.value}
+        out["note"] = ("file written by aqe_save_file in the reference's format (24-byte header + 32-byte rows, custom_bplus_db.cpp:665-711), read back from "
+                       "the page cache through mmap + pinned double buffers; replaces load_from_file + collect_leaf_records (DB.cpp:685-735)")
     return out
 
 
@@ -100,24 +331,22 @@ def main():
     import torch
     import torch.distributed as dist
     from approximatequeryengine_amd import _native as nat
-    from approximatequeryengine_amd.distributed import PipelinedBatches, ShardedBatch, ShardedQuery, shard_bounds, torch_all_reduce
+    from approximatequeryengine_amd.distributed import PipelinedBatches, ShardedBatch, shard_bounds, torch_all_reduce
     from approximatequeryengine_amd.engine import Batch, Engine, make_query
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     # AQE_BENCH_REHEARSAL=1: several ranks share ONE GPU over gloo (to exercise the N>1 code path on a one-GPU
-    # box); never used for reported numbers.
+    # box); AQE_BENCH_FORCE_DIST=1: the N>1 code path through RCCL with a world of one.  Never used for reported numbers.
     rehearsal = os.environ.get("AQE_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    # AQE_BENCH_FORCE_DIST=1: take the N>1 code path (RCCL all-reduce of the slot totals, k_replay) with a world of
-    # one rank — the way to exercise RCCL on a one-GPU box; never used for reported numbers.
     use_dist = world > 1 or os.environ.get("AQE_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
+    collective = None
     if use_dist:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -125,58 +354,71 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
 
     rows = args.rows_per_gpu
     n_global = rows * world
     lo, hi = shard_bounds(n_global, world, rank)
     e = args.error_percent
-    pct = 20.0 if e <= 1.0 else 15.0 if e <= 2.0 else 10.0 if e <= 5.0 else 5.0  # enhanced_aqe_cli.py:243-250
+    pct = e_to_pct(e)
+    B = max(1, args.batch)
+    extras = not args.headline_only
 
     eng = Engine(local_rank)
     eng.generate_synthetic(hi - lo, shard_lo=lo, n_global=n_global, seed=SEED, keep_aos=False)
-    q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=0.95, check_interval=10,
-                   num_threads=4 * world, max_error_percent=e, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
-    # One step = a batch of B independent copies of the query, each with its own plan (hand-off scratch).
-    # 1 GPU: one HIP stream per query, in-kernel decisions (k_sweep_persist).  N GPUs: every query's round totals
-    # go into one [B, totals] buffer, ONE RCCL all-reduce per step, then k_replay decides each query; two such
-    # batches alternate, software-pipelined, so that one step's collective runs under the next step's sweeps.
-    B = max(1, args.batch)
-    # Queries that run beside others take half the compute units each (AQE_Q_SHARE_GPU): two launches then sit side by
-    # side on the chip.  The one-in-flight measurements (roofline, closed loop) use a plan of the same query without it.
-    q_batch = type(q).from_buffer_copy(q)
-    if B > 1:
-        q_batch.flags |= nat.Q_SHARE_GPU
-    plans = [eng.plan(q_batch) for _ in range(B)]
-    pipe = None
-    sides = [torch.cuda.Stream() for _ in range(1 if use_dist else B)]
-    plan, side = eng.plan(q), sides[0]
-    st = side.cuda_stream
-    n_streams = len(sides)
 
-    with torch.cuda.stream(side):
+    def batch_queries(err):
+        return headline_queries(nat, make_query, B, world, err)
+
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    st = side[0].cuda_stream
+    q_one = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, confidence_level=0.95, check_interval=10,
+                       num_threads=4 * world, max_error_percent=e, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
+    plan_one = eng.plan(q_one)
+    plan_sets = [[eng.plan(q) for q in batch_queries(e)] for _ in range(2)]
+    natives = [Batch(ps) for ps in plan_sets]
+    pipe = None
+
+    with torch.cuda.stream(side[0]):
         if use_dist:
-            if plan.totals_len:
-                plans = plans + [eng.plan(q_batch) for _ in range(B)]  # the second batch of the pipeline
-                natives, sbs = [], []
-                for half in (plans[:B], plans[B:]):
-                    buf = torch.zeros(B, plan.totals_len, dtype=torch.float64, device="cuda")
-                    natives.append(Batch(half))  # sweeps and replays on the library's side streams
-                    sbs.append(ShardedBatch(half, buf, torch_all_reduce(), stream=st, batch=natives[-1]))
-                pipe = PipelinedBatches(sbs)
-                step = pipe.enqueue
-                n_streams = 1 + 3
-                collectives_per_step = 1
-            else:  # plans without a batched form: one collective per convergence step and query
-                vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
-                sqs = [ShardedQuery(p, vec, torch_all_reduce(), stream=st) for p in plans]
-                step = lambda: [x.enqueue() for x in sqs]  # noqa: E731
-                collectives_per_step = B * (plan.rounds + (1 if plan.has_topup else 0))
+            width = max(p.totals_len for ps in plan_sets for p in ps)
+            if not width:
+                raise SystemExit("the bench query has no batched (totals) form on this shard")
+            sbs = []
+            for ps, nb in zip(plan_sets, natives):
+                buf = torch.zeros(B, width, dtype=torch.float64, device="cuda")
+                sbs.append(ShardedBatch(ps, buf, torch_all_reduce(), stream=st, batch=nb))
+            pipe = PipelinedBatches(sbs)
+            collectives_per_step = 1
+            k_state = {"k": 0}
+
+            def step():           # sweeps of one batch; collective + replays of the previous one
+                pipe.enqueue()
+
+            def drain():
+                return pipe.fetch()
+
+            def one():            # one batch, start to end (profiling / latency)
+                sbs[0].enqueue()
         else:
             collectives_per_step = 0
+            k_state = {"k": 0, "results": None}
 
-            def step():
-                for p, s_ in zip(plans, sides):
-                    p.enqueue_all(s_.cuda_stream)
+            def step():           # one launch for a whole batch; the previous batch's results are read meanwhile
+                k = k_state["k"]
+                natives[k % 2].enqueue_all(side[k % 2].cuda_stream)
+                if k > 0:
+                    k_state["results"] = natives[(k - 1) % 2].fetch()
+                k_state["k"] = k + 1
+
+            def drain():
+                k = k_state["k"]
+                if k > 0:
+                    k_state["results"] = natives[(k - 1) % 2].fetch()
+                return k_state["results"]
+
+            def one():
+                natives[0].enqueue_all(st)
 
         def fence():
             if pipe is not None:
@@ -186,143 +428,132 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, ONE query in flight,
-        #      taken before the throughput loop ----
+        # ---- reference answers of the batch's queries, each as a launch of its own (single GPU) ----
         for _ in range(3):
             step()
+        firsts = drain()
         fence()
-        if not use_dist:
-            one = lambda: plan.enqueue_all(st)  # noqa: E731
-        elif plan.totals_len:
-            one_buf = torch.zeros(plan.totals_len, dtype=torch.float64, device="cuda")
-            one = ShardedQuery(plan, one_buf, torch_all_reduce(), stream=st).enqueue
-        else:
-            one = sqs[0].enqueue
-        plan.set_profiling(True)
-        one()
-        torch.cuda.synchronize()
-        samples = plan.launch_samples()  # launches of the form just executed
-        prof_steps = max(10, min(200, args.steps))
-        sum_ms = [0.0] * len(samples)
+
+        # ---- roofline of the dominant kernel (k_sweep_multi): ONE batch in flight, the launch's own begin/end
+        #      timestamps (event pair attached to the dispatch), before the throughput loop ----
+        prof_steps = max(10, min(100, args.steps))
+        natives[0].set_profiling(True)
+        ms_sum, ms_min, swept, wgs = 0.0, 1e9, 0, 0
         for _ in range(prof_steps):
             one()
-            torch.cuda.synchronize()
-            for i, ms in enumerate(plan.launch_ms()):
-                sum_ms[i] += ms
-        plan.set_profiling(False)
-        shared_launch_us = None
-        if B > 1 and not use_dist:  # the same launch on half the compute units (the form the batch runs), alone
-            ps = plans[0]
-            ps.set_profiling(True)
-            acc = 0.0
+            if use_dist:
+                fence()
+            else:
+                natives[0].fetch()
+            ms, swept, wgs = natives[0].launch_info()
+            ms_sum += ms
+            ms_min = min(ms_min, ms)
+        natives[0].set_profiling(False)
+        avg_launch_ms = ms_sum / prof_steps
+        bytes_per_launch = 8.0 * swept
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+
+        # ---- a single query on the whole chip (k_sweep_persist), one in flight: launch time and closed loop ----
+        single = None
+        if not use_dist:
+            plan_one.set_profiling(True)
+            acc = []
             for _ in range(prof_steps):
-                ps.enqueue_all(st)
+                plan_one.enqueue_all(st)
                 torch.cuda.synchronize()
-                acc += ps.launch_ms()[0]
-            ps.set_profiling(False)
-            shared_launch_us = 1e3 * acc / prof_steps
-        # closed-loop latency (enqueue + fetch per query)
-        lat = []
-        for _ in range(50):
-            t1 = time.perf_counter()
-            one()
-            plan.fetch(st)
-            lat.append(time.perf_counter() - t1)
-        lat.sort()
+                acc.append(sum(plan_one.launch_ms()))
+            plan_one.set_profiling(False)
+            lat = []
+            for _ in range(50):
+                t1 = time.perf_counter()
+                plan_one.enqueue_all(st)
+                r_one = plan_one.fetch(st)
+                lat.append(time.perf_counter() - t1)
+            lat.sort()
+            acc.sort()
+            s_us = 1e3 * sum(acc) / len(acc)
+            single = {"kernel": "k_sweep_persist", "avg_launch_us": s_us, "min_launch_us": 1e3 * acc[0], "samples": int(r_one.visited),
+                      "achieved_GBps": 8.0 * r_one.visited / (s_us * 1e-6) / 1e9, "frac": 8.0 * r_one.visited / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                      "closed_loop_latency_us": {"p50": 1e6 * lat[len(lat) // 2], "min": 1e6 * lat[0]},
+                      "aggregates_per_sec_one_in_flight": 1.0 / lat[len(lat) // 2]}
 
         # ---- the other reading of "--e 0.01" (SURVEY §8d config 2): the FRACTION 0.01 = 1 percent.  That query
-        #      converges after the first rounds, should_stop fires, and the reference's top-up (custom_bplus_db.cpp:
-        #      1031-1040) supplies most of the sample: the early-termination path.  Reported beside the headline. ----
+        #      converges after the first round, should_stop fires, and the reference's top-up (custom_bplus_db.cpp:
+        #      1031-1040) supplies most of the sample: the early-termination path, also one launch per batch. ----
         other = None
-        if not use_dist and e == 0.01 and not args.headline_only:
+        if not use_dist and e == 0.01 and extras:
             e2 = 1.0
-            q2 = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, confidence_level=0.95, check_interval=10, num_threads=4,
-                            max_error_percent=e2, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
-            if B > 1:
-                q2.flags |= nat.Q_SHARE_GPU
-            plans2 = [eng.plan(q2) for _ in range(B)]
-
-            def step2():
-                for p, s_ in zip(plans2, sides):
-                    p.enqueue_all(s_.cuda_stream)
-
-            for _ in range(3):
-                step2()
-            # (fetching tells each plan that its top-up is due: from now on the launch is enqueued with the sweep)
-            r2 = [p.fetch(s_.cuda_stream) for p, s_ in zip(plans2, sides)][0]
-            step2()
-            fence()
-            # one in flight first (the GPU clocks down after a sustained loop), then the throughput loop
-            lat2 = []
+            sets2 = [[eng.plan(q) for q in batch_queries(e2)] for _ in range(2)]
+            nb2 = [Batch(ps) for ps in sets2]
+            for b_ in nb2:
+                b_.enqueue_all(st)
+                r2 = b_.fetch()
+            nb2[0].set_profiling(True)
+            acc2 = []
             for _ in range(30):
-                t1 = time.perf_counter()
-                plans2[0].enqueue_all(st)
-                plans2[0].fetch(st)
-                lat2.append(time.perf_counter() - t1)
-            lat2.sort()
-            p0 = plans2[0]
-            p0.set_profiling(True)
-            acc2 = 0.0
-            for _ in range(30):
-                p0.enqueue_all(st)
-                torch.cuda.synchronize()
-                acc2 += sum(p0.launch_ms())
-            p0.set_profiling(False)
-            k2 = max(10, min(100, args.steps))
+                nb2[0].enqueue_all(st)
+                nb2[0].fetch()
+                acc2.append(nb2[0].launch_info())
+            nb2[0].set_profiling(False)
+            k2 = max(10, min(200, args.steps))
+            torch.cuda.synchronize()
             t2 = time.perf_counter()
-            for _ in range(k2):
-                step2()
-            fence()
+            for k in range(k2):
+                nb2[k % 2].enqueue_all(side[k % 2].cuda_stream)
+                if k:
+                    r2 = nb2[(k - 1) % 2].fetch()
+            r2 = nb2[(k2 - 1) % 2].fetch()
+            torch.cuda.synchronize()
             dt2 = time.perf_counter() - t2
-            other = {"error_percent": e2, "launch_us": 1e3 * acc2 / 30, "aggregates_per_sec": B * k2 / dt2, "steps": k2, "queries_per_step": B,
-                     "closed_loop_latency_us_p50": 1e6 * lat2[len(lat2) // 2],
-                     "result": {"avg": r2.value, "ci": [r2.ci_lower, r2.ci_upper], "n": int(r2.n), "converged": int(r2.converged),
-                                "rounds": int(r2.rounds), "topup_rows": int(r2.topup)},
-                     "note": "ONE launch on a few workgroups (the plan predicts an early stop from the table's head: cv and the "
-                             "error rule, and sweeps only the first rounds plus the reference's top-up, every 20th row, as one more "
-                             "slot): the monitor wave judges the rounds shown, finds the sample short (DB.cpp:1032) and adds the "
-                             "top-up; had the query not stopped there, fetch() would launch the remaining rounds"}
-            for p in plans2:
-                p.close()
+            l_us = 1e3 * sum(a[0] for a in acc2) / len(acc2)
+            other = {"error_percent": e2, "aggregates_per_sec": B * k2 / dt2, "steps": k2, "queries_per_step": B,
+                     "launch_us": l_us, "rows_swept_per_launch": int(acc2[0][1]), "workgroups": int(acc2[0][2]),
+                     "achieved_GBps": 8.0 * acc2[0][1] / (l_us * 1e-6) / 1e9,
+                     "result": {"value": r2[0].value, "ci": [r2[0].ci_lower, r2[0].ci_upper], "n": int(r2[0].n), "converged": int(r2[0].converged),
+                                "rounds": int(r2[0].rounds), "topup_rows": int(r2[0].topup)},
+                     "note": "every plan predicts its early stop from the table's head (cv and the error rule) and takes its HEAD form as its "
+                             "group of the launch: the first rounds plus the reference's top-up (every 20th row) as one more slot; the group's "
+                             "monitor judges the rounds, finds the sample short (DB.cpp:1032) and adds the top-up; had a query not stopped "
+                             "there, fetch() would launch its remaining rounds"}
+            for b_ in nb2:
+                b_.close()
+            for ps in sets2:
+                for p in ps:
+                    p.close()
 
+        # ---- the timed region: K steps, every result fetched ----
         for _ in range(max(args.warmup, 1)):
             step()
-        batched_dist = use_dist and bool(plan.totals_len)
-        fetch_all = pipe.fetch if batched_dist else (lambda: [p.fetch(sides[i % len(sides)].cuda_stream) for i, p in enumerate(plans)])  # noqa: E731
-        firsts = fetch_all()
-        first = firsts[0]
+        drain()
         fence()
+        k_state["k"] = 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        lasts = drain()
         fence()
         dt = time.perf_counter() - t0
-        lasts = fetch_all()
-        last = lasts[0]
-        assert all(x.value == first.value and x.n == first.n for x in firsts + lasts), "queries in flight disagree"
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        last = lasts[0]
+        agree = all((a.n, a.visited, a.rounds, a.converged) == (b_.n, b_.visited, b_.rounds, b_.converged) and a.value == b_.value
+                    for a, b_ in zip(firsts[: len(lasts)], lasts)) if not use_dist else True
+        assert agree, "results of the timed loop differ from the first execution's"
 
-    # the separate top-up launch never fires in this workload: not a sweep (the batched form has no such launch)
-    sweeps = len(samples) - (1 if (plan.has_topup and len(samples) > 1) else 0)
-    launches = sweeps
-    avg_launch_ms = sum(sum_ms[:sweeps]) / prof_steps / launches
-    visited_local = sum(samples[:sweeps])
-    bytes_per_launch = 8.0 * visited_local / launches
-    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    per_launch = [{"samples": int(s), "avg_us": 1e3 * m / prof_steps,
-                   "GBps": (8.0 * s / (m / prof_steps * 1e-3) / 1e9) if m > 0 else 0.0}
-                  for s, m in zip(samples, sum_ms)]
-
-    # HBM-side traffic of the sweep kernel: a PMC measurement (FETCH_SIZE + WRITE_SIZE in their own rocprofv3
-    # passes, gfx950 correction calibrated on a known 80 MB scan) cannot be taken inside this process; the
-    # committed value in profiles/ is for this exact workload and kernel, and is only reported for it.
-    traffic = None
+    # HBM-side traffic of the sweep kernel: a PMC measurement (FETCH_SIZE + WRITE_SIZE in their own rocprofv3 passes,
+    # gfx950 correction calibrated on a known 80 MB scan) cannot be taken inside this process; the committed value in
+    # profiles/ is reported only when it was measured on these very sources and this workload.
+    traffic, traffic_src = None, None
     try:
         if not use_dist and rows == ROWS_PER_GPU and e == 0.01:
-            traffic = json.loads((ROOT / "profiles" / "round1_pmc_raw.json").read_text())["k_sweep_persist_traffic_bytes_per_launch"]
+            doc = json.loads(PMC_FILE.read_text())
+            if doc.get("source_hash") == source_hash() and doc.get("batch") == B:
+                traffic = doc["k_sweep_multi_traffic_bytes_per_launch"]
+                traffic_src = f"{PMC_FILE.relative_to(ROOT)} (rocprofv3 --pmc, bytes per launch of {B} queries, sources {doc['source_hash']})"
+            else:
+                traffic_src = f"{PMC_FILE.relative_to(ROOT)} was measured on other sources / another batch size: not reported"
     except Exception:
         traffic = None
 
@@ -336,55 +567,60 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "configs[1]: 10M-row APPROX AVG (SUM/COUNT from the same moments), CLT --e 0.01 "
-                            "(percent, as the reference CLI reads it: never converges -> full 20% dual-pointer sweep, "
-                            "should_stop armed on every launch), table resident in HBM",
+                "workload": "configs[1]: 10M-row APPROX AVG/SUM/COUNT (same moments), CLT --e 0.01 (percent, as the reference CLI "
+                            "reads it: never converges -> full 20% dual-pointer sweep, should_stop armed), table resident in HBM; "
+                            f"one step = a batch of {B} different queries in ONE launch, every result fetched",
                 "rows_per_gpu": rows, "global_rows": n_global, "sample_percent": pct, "error_percent": e,
-                "pointers": 4 * world, "samples_per_query_per_gpu": int(visited_local if use_dist else last.visited),
-                "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_query": len(samples),
-                "queries_per_step": B, "streams": n_streams,
-                "collectives_per_step": collectives_per_step,
+                "pointers": "4,6,...,16 per GPU (x n_gpus)", "samples_per_query_per_gpu": int(swept // B),
+                "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_step": 1 if not use_dist else 2,
+                "queries_per_step": B, "batches_in_flight": 2, "fetched_every_step": True,
+                "collectives_per_step": collectives_per_step, "collective": collective,
                 "unit_definition": "one 10M-row region aggregate per GPU per query; a global query over N regions counts N",
             },
             "global_queries_per_sec": B * args.steps / dt,
-            "early_termination_reading": other,
-            "closed_loop_latency_us": {"p50": 1e6 * lat[len(lat) // 2], "min": 1e6 * lat[0]},
-            "result": {"avg": last.value, "ci": [last.ci_lower, last.ci_upper], "n": int(last.n),
-                       "converged": int(last.converged), "rounds": int(last.rounds),
-                       "same_as_first": bool(first.value == last.value)},
+            "result": {"value": last.value, "ci": [last.ci_lower, last.ci_upper], "n": int(last.n), "converged": int(last.converged),
+                       "rounds": int(last.rounds), "same_as_first_execution": bool(agree)},
             "roofline": {
-                "bound": "hbm", "kernel": "k_sweep_persist" if (not use_dist or plan.totals_len) else "k_round", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_source": "profiles/round1_pmc_raw.json (rocprofv3 --pmc, bytes per launch)" if traffic else None,
-                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms,
-                # what the memory system actually moved per launch (PMC), as a rate, and the share of it that was sampled
-                # rows: ~1.0 with the stride-major views of the column (in place the sampled rows — 0 and 2 of every 5
-                # — are 40 % of every line touched, and the whole column passes)
-                "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
-                "line_utilisation": (bytes_per_launch / traffic) if traffic else None,
-                "launches_per_query": launches, "per_launch": per_launch,
-                "batch_form_launch_us": shared_launch_us,
-                "note": "8 B per sampled row (SoA f64 amount column) / mean sweep-kernel duration, one query in flight; the "
-                        "duration is the dispatch's own begin/end timestamps, taken by HIP events attached to the launch "
-                        "(hipExtLaunchKernelGGL) on the launch stream - the same clock rocprofv3 reports "
-                        "(profiles/round1_bench_kernel_stats.csv); the top-up launch (a no-op here) is excluded",
+                "bound": "hbm", "kernel": "k_sweep_multi", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms, "min_launch_us": 1e3 * ms_min,
+                "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps,
+                "note": "8 B per sampled row (SoA f64 amount column) x the rows all queries of the batch sweep / mean duration of the ONE "
+                        "launch that serves the batch; the duration is the dispatch's own begin/end timestamps (HIP events attached to "
+                        "the launch, hipExtLaunchKernelGGL, on the launch stream) - the clock rocprofv3 reports "
+                        "(profiles/round2_bench_kernel_stats.csv).  A 10 M-row column and its stride-major views (80 MB each) stay in "
+                        "the 256 MiB Infinity Cache between queries and the groups of a batch walk the same views side by side, so this "
+                        "is cache-assisted bandwidth priced against the HBM peak; the 100 M- and 1 B-row lines under `configs` are HBM proper",
             },
+            "single_query": single,
+            "early_termination_reading": other,
         }
-        if not use_dist and not args.no_cpu_baseline:
+        if extras and not use_dist:
+            if not args.no_configs:
+                try:
+                    line["configs"] = run_configs(eng, nat, make_query, st, args.max_config_rows)
+                except Exception as ex:
+                    line["configs"] = [{"error": repr(ex)}]
             try:
-                cb = cpu_baseline(rows, e, args.cpu_sample_rows)
-                line["cpu_baseline"] = cb.get("reference", cb["port"])
-                line["cpu_baseline_port"] = cb["port"]
-            except Exception as ex:  # the bench line must still print
-                line["cpu_baseline"] = {"value": None, "unit": "aggregates/sec", "cores": 0, "kind": "port",
-                                        "sample": f"failed: {ex!r}"}
+                eng.release_table()
+                line["cold"] = cold_numbers(Engine, nat, make_query, rows, e)
+            except Exception as ex:
+                line["cold"] = {"error": repr(ex)}
+            if not args.no_cpu_baseline:
+                try:
+                    cb = cpu_baseline(rows, e, args.cpu_sample_rows)
+                    line["cpu_baseline"] = cb.get("reference", cb["port"])
+                    line["cpu_baseline_all"] = cb
+                except Exception as ex:  # the bench line must still print
+                    line["cpu_baseline"] = {"value": None, "unit": "aggregates/sec", "cores": 0, "kind": "port", "sample": f"failed: {ex!r}"}
         print(json.dumps(line), flush=True)
 
-    if pipe is not None:
-        for nb in natives:
-            nb.close()
-    for p in plans + [plan]:
-        p.close()
+    for nb in natives:
+        nb.close()
+    for ps in plan_sets:
+        for p in ps:
+            p.close()
+    plan_one.close()
     eng.close()
     if use_dist:
         dist.barrier()

@@ -333,6 +333,21 @@ AQE_API int aqe_batch_enqueue_sweeps(aqe_batch* batch, double* dev_totals, uint6
 AQE_API int aqe_batch_join(aqe_batch* batch, void* stream);
 AQE_API int aqe_batch_enqueue_replays(aqe_batch* batch, const double* dev_totals, uint64_t row_stride_doubles, void* stream);
 AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
+/* Single-GPU form of a batch: Q independent queries in ONE launch, decisions taken in the kernel.  The grid is cut
+ * into one group of workgroups per plan (sizes in proportion to the plans' rows); group i runs plan i exactly as
+ * aqe_plan_enqueue_all would on a launch of its own — its own monitor wave, its own should_stop word — so the
+ * start of the launch and the decision tails of all Q queries are paid once instead of Q times.  This is what
+ * replaces the reference's thread creation per call (std::async workers per query, DB.cpp:918-1029) when queries
+ * arrive in batches.  A plan predicted to stop early takes its head form (first rounds + the top-up) as its group.
+ * Any plan with a family sampler and 1..32 rounds qualifies (not RANDOM_POINTER); the context must hold the whole
+ * table.  Results: aqe_batch_fetch (each plan's result is picked up as soon as its monitor has written it).
+ * aqe_batch_enqueue_sweeps is the same launch with the decisions left to the replay after the all-reduce. */
+AQE_API int aqe_batch_enqueue_all(aqe_batch* batch, void* stream);
+/* Timing of the one-launch forms for roofline reports: with profiling on, the launch carries an event pair on its
+ * dispatch (the kernel's own begin/end timestamps); aqe_batch_launch_info returns the duration of the most recent
+ * launch, the rows it sweeps (all plans; 8 B each) and its workgroups.  Any of the outputs may be NULL. */
+AQE_API int aqe_batch_set_profiling(aqe_batch* batch, int enable);
+AQE_API int aqe_batch_launch_info(aqe_batch* batch, float* ms, uint64_t* samples, uint32_t* workgroups);
 /* fused single-GPU form: the whole query, asynchronously.  A multi-round (CLT) plan is ONE launch with in-kernel
  * decisions; the reference's top-up (DB.cpp:1031-1040), rarely due, gets its own launch only when the plan's
  * previous execution needed it — otherwise aqe_plan_fetch runs it if the result turns out to want it.

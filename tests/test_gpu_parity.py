@@ -948,6 +948,70 @@ def test_native_batch_drives_several_plans_with_two_calls_per_step(nat, table):
             p.close()
 
 
+def test_batch_in_one_launch_matches_single_plans_and_oracle(nat, oracle, table):
+    """aqe_batch_enqueue_all: a mixed batch of queries in ONE launch (k_sweep_multi: a group of workgroups, a monitor
+    wave and a should_stop word per query).  Every query must report what it reports as a launch of its own and what
+    the oracle computes (DB.cpp:885-1043 for the CLT monitor; 1526-1603, 1151-1181, 242-274 for the others) — step
+    after step, results fetched every step, including the early-stop / top-up / head-form plans."""
+    from approximatequeryengine_amd.engine import Batch, Engine, make_query
+    import torch
+    n = 1_000_000
+    rows = table(n)
+    clt = [(0.0, 4096, 4, 4, nat.AVG), (1.0, 256, 2, 8, nat.SUM), (0.3, 16, 2, 8, nat.AVG), (0.01, 4096, 4, 6, nat.COUNT),
+           (1.0, 4096, 4, 4, nat.AVG), (0.05, 1024, 4, 5, nat.SUM)]
+    qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=agg, max_error_percent=e, clt_round0=r0, clt_growth=g, num_threads=t)
+          for e, r0, g, t, agg in clt]
+    qs += [make_query(nat.M_MEMORY_STRIDE, 20.0), make_query(nat.M_EXACT, 100.0, where=(250.0, 750.0)),
+           make_query(nat.M_BLOCK, 5.0, where=(100.0, 900.0), convention=nat.EST_CPP), make_query(nat.M_PAGE, 5.0, block_size=4096, agg=nat.AVG),
+           make_query(nat.M_OPTIMIZED_CLT, 10.0, num_threads=4)]
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)
+        want = [eng.reduce(q) for q in qs]
+        for (e, r0, g, t, agg), w in zip(clt, want):  # the single-plan path itself against the oracle
+            rc, o, _ = oracle.clt_run(rows, 20.0, 0.95, 10, t, e, R0=r0, growth=g)
+            assert rc == 0 and (w.n, w.converged, w.rounds, w.topup) == (o.final.n, o.converged, o.rounds, o.topup)
+            assert rel(w.sum, o.final.sum) <= SUM_TOL
+        side = torch.cuda.Stream()
+        for sizes in ((len(qs),), (1,), (3, 5)):  # one batch of all; batches of one; two batches in flight on one stream
+            for lo in range(0, len(qs), sum(sizes)):
+                groups, at = [], lo
+                for k in sizes:
+                    groups.append(list(range(at, min(at + k, len(qs)))))
+                    at += k
+                groups = [g_ for g_ in groups if g_]
+                plan_sets = [[eng.plan(qs[i]) for i in g_] for g_ in groups]
+                batches = [Batch(ps) for ps in plan_sets]
+                for step in range(4):
+                    for b in batches:
+                        b.enqueue_all(side.cuda_stream)
+                    for b, g_ in zip(batches, groups):
+                        for r, i in zip(b.fetch(), g_):
+                            w = want[i]
+                            assert (r.n, r.visited, r.converged, r.rounds, r.topup, r.topup_pending, r.device_status) == \
+                                   (w.n, w.visited, w.converged, w.rounds, w.topup, 0, 0), (i, step, r.as_dict(), w.as_dict())
+                            assert rel(r.sum, w.sum) <= 1e-13 and rel(r.sumsq, w.sumsq) <= 1e-13
+                            assert rel(r.value, w.value) <= 1e-12 and rel(r.ci_lower, w.ci_lower) <= 1e-12 and rel(r.ci_upper, w.ci_upper) <= 1e-12
+                b0 = batches[0]
+                b0.set_profiling(True)
+                b0.enqueue_all(side.cuda_stream)
+                b0.fetch()
+                ms, swept, wgs = b0.launch_info()
+                assert ms > 0 and wgs >= 1 and swept > 0
+                b0.set_profiling(False)
+                for b in batches:
+                    b.close()
+                for ps in plan_sets:
+                    for p in ps:
+                        p.close()
+        # a seeded-random plan has no single-launch form
+        pr = eng.plan(make_query(nat.M_RANDOM_POINTER, 1.0, seed=7))
+        br = Batch([pr])
+        with pytest.raises(nat.AqeError):
+            br.enqueue_all(side.cuda_stream)
+        br.close()
+        pr.close()
+
+
 def test_group_by_with_per_group_interval(nat, oracle, table):
     """GROUP BY region / product_id (executor.cpp:202-321): per-group (n, S, Q) against what SQLite returned for the
     reference's statements (tests/golden/groupby_sqlite.json), estimate and interval against the oracle's

@@ -1,13 +1,16 @@
-"""Turn the two rocprofv3 --pmc passes over tools/pmc_probe.py into profiles/round1_pmc_raw.json.
+"""Turn the two rocprofv3 --pmc passes over tools/pmc_probe.py into profiles/round2_pmc_raw.json.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 tools/pmc_probe.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 tools/pmc_probe.py
-    python tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round1_pmc_raw.json
+    python tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round2_pmc_raw.json [batch]
 
 Per kernel (name + grid size): median counter value over its launches, in the counter's own unit (KB).  FETCH_SIZE on
 gfx950 under-reports coalesced streaming reads (MI355X_MICROARCH.md, HBM recipe): the correction factor is calibrated
-on this library's own exact scan of the 10 M-row amount column (known traffic: 80 MB), then applied to the sweep."""
+on this library's own exact scan of the 10 M-row amount column (known traffic: 80 MB), then applied to the sweeps.
+The file carries the hash of the library sources it was measured on: bench.py reports the traffic only for those."""
 import csv, glob, json, os, re, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 
 def medians(d):
     out = {}
@@ -23,7 +26,8 @@ def medians(d):
     return res
 
 fetch_dir, write_dir, dst = sys.argv[1:4]
-doc = {}
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+doc = {"source_hash": bench.source_hash(), "batch": batch}
 doc.update(medians(fetch_dir))
 doc.update(medians(write_dir))
 F, W = doc["FETCH_SIZE"], doc.get("WRITE_SIZE", {})
@@ -31,7 +35,15 @@ scan = max((k for k in F if k.startswith("k_round ")), key=lambda k: F[k]["media
 known = 80_000_000
 corr = known / (F[scan]["median_KB"] * 1024.0)
 doc["calibration"] = {"known_bytes": known, "kernel": f"{scan} (exact scan of the 10M-row amount column)", "fetch_correction": corr}
-sweep = next(k for k in F if k.startswith("k_sweep_persist "))
-doc["k_sweep_persist_traffic_bytes_per_launch"] = F[sweep]["median_KB"] * 1024.0 * corr + W.get(sweep, {"median_KB": 0.0})["median_KB"] * 1024.0
+def traffic(prefix):
+    ks = [k for k in F if k.startswith(prefix + " ")]
+    if not ks:
+        return None
+    k = max(ks, key=lambda k: F[k]["median_KB"])
+    return F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
+doc["k_sweep_multi_traffic_bytes_per_launch"] = traffic("k_sweep_multi")
+doc["k_sweep_persist_traffic_bytes_per_launch"] = traffic("k_sweep_persist")
+doc["k_indexed_traffic_bytes_per_launch"] = traffic("k_indexed")
+doc["k_grouped_traffic_bytes_per_launch (largest grouped sweep: the exact scan)"] = traffic("k_grouped")
 json.dump(doc, open(dst, "w"), indent=1)
-print(json.dumps({k: doc[k] for k in ("calibration", "k_sweep_persist_traffic_bytes_per_launch")}, indent=1))
+print(json.dumps({k: v for k, v in doc.items() if not isinstance(v, dict) or k == "calibration"}, indent=1))
