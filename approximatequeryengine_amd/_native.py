@@ -29,6 +29,7 @@ F_TOPUP = 1
 F_PAIR = 2
 STAGE_KEEP_AOS = 1
 MOMENT_VEC = 8
+COMM_ID_BYTES = 128
 
 
 class Query(C.Structure):
@@ -152,6 +153,17 @@ def lib() -> C.CDLL:
         "aqe_batch_enqueue_all": (C.c_int, [vp, vp]),
         "aqe_batch_set_profiling": (C.c_int, [vp, C.c_int]),
         "aqe_batch_launch_info": (C.c_int, [vp, P(C.c_float), P(u64), P(u32)]),
+        "aqe_comm_unique_id": (C.c_int, [vp]),
+        "aqe_comm_create": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
+        "aqe_comm_create_all": (C.c_int, [P(vp), C.c_int, P(vp)]),
+        "aqe_comm_destroy": (None, [vp]),
+        "aqe_comm_info": (C.c_int, [vp, P(C.c_int), P(C.c_int)]),
+        "aqe_comm_all_reduce_sum": (C.c_int, [vp, vp, u64, vp]),
+        "aqe_comm_all_reduce_max": (C.c_int, [vp, vp, u64, vp]),
+        "aqe_comm_group_start": (C.c_int, []),
+        "aqe_comm_group_end": (C.c_int, []),
+        "aqe_plan_run_sharded": (C.c_int, [vp, vp, vp, vp, P(Result)]),
+        "aqe_batch_run_sharded": (C.c_int, [vp, vp, vp, u64, u32, vp]),
         "aqe_plan_reset": (C.c_int, [vp, vp]),
         "aqe_plan_fetch": (C.c_int, [vp, P(Result), vp]),
         "aqe_plan_last_kernel_ms": (C.c_int, [vp, P(C.c_float)]),

@@ -16,7 +16,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libaqe_hip.so"
-SOURCES = [CSRC / "capi.hip", CSRC / "table.hip", CSRC / "plans.hip", CSRC / "kernels.hip", CSRC / "persist.hip", CSRC / "grouped.hip", CSRC / "sort.hip", CSRC / "planner.cpp"]
+SOURCES = [CSRC / "capi.hip", CSRC / "table.hip", CSRC / "plans.hip", CSRC / "kernels.hip", CSRC / "persist.hip", CSRC / "grouped.hip", CSRC / "sort.hip", CSRC / "comm.hip", CSRC / "planner.cpp"]
 HEADERS = [CSRC / "host.hpp", CSRC / "kernels.hpp", CSRC / "device_common.hpp", CSRC / "planner.hpp", ROOT / "include" / "aqe_hip.h"]
 ARCH = "gfx950"
 
@@ -42,7 +42,7 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     LIB.parent.mkdir(parents=True, exist_ok=True)
     tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
     cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-function", "-fno-fast-math", "-ffp-contract=off", "-pthread",
+           "-Wall", "-Wno-unused-function", "-fno-fast-math", "-ffp-contract=off", "-pthread", "-ldl",
            "-I", str(ROOT / "include"), "-o", str(tmp)] + [str(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

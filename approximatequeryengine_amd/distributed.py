@@ -19,6 +19,20 @@ from typing import Callable, Optional, Tuple
 MOMENT_VEC = 8
 
 
+def _stream_for(stream: int, tensor) -> int:
+    """The stream a sharded object enqueues on.  A null handle means "the engine's own stream" to the C ABI, which is
+    NOT ordered against the stream the framework's collective runs on: for device tensors 0 is therefore resolved to
+    torch's current stream, and refused when that is the legacy default stream (whose handle is also 0)."""
+    if stream or not getattr(tensor, "is_cuda", False):
+        return stream
+    import torch
+    s = torch.cuda.current_stream(tensor.device).cuda_stream
+    if not s:
+        raise ValueError("run under `with torch.cuda.stream(side):` or pass stream=side.cuda_stream: the legacy default "
+                         "stream cannot be handed to the library, and its own stream is not ordered against the collective")
+    return s
+
+
 def shard_bounds(n_global: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Proper prefix partition of the flat row array: rank g owns [⌊g·N/G⌋, ⌊(g+1)·N/G⌋).
     (The reference's own region split, custom_bplus_db.cpp:1903-1921, overlaps by a row and can drop
@@ -32,7 +46,8 @@ class ShardedQuery:
     plan        an object with the ``engine.Plan`` interface, planned over THIS rank's shard
     vec         a float64 tensor on the plan's device, at least max(MOMENT_VEC, plan.totals_len) long
     all_reduce  callable(tensor) -> None performing an in-place SUM over the group
-    stream      raw stream handle passed through to the plan (0 = the plan's own stream)
+    stream      raw stream handle passed through to the plan; 0 = torch's current stream for a device buffer (the
+                legacy default stream is refused: run under ``with torch.cuda.stream(side)``)
     batched     True: ONE collective per query — every round is swept speculatively in one launch, the
                 per-round totals are all-reduced once, and the stop rules are replayed on the reduced totals
                 (identical answer; the rounds after the stop are swept for nothing, which on a 10 M-row shard
@@ -46,7 +61,7 @@ class ShardedQuery:
         self.plan = plan
         self.vec = vec
         self.all_reduce = all_reduce
-        self.stream = stream
+        self.stream = _stream_for(stream, vec)
         can = getattr(plan, "totals_len", 0) > 0
         self.batched = can if batched is None else (batched and can)
         need = plan.totals_len if self.batched else MOMENT_VEC
@@ -107,7 +122,7 @@ class ShardedBatch:
     def __init__(self, plans, buf, all_reduce: Callable, stream: int = 0, batch=None):
         if any(getattr(p, "totals_len", 0) == 0 for p in plans):
             raise ValueError("every plan of a ShardedBatch needs a batched (totals) form")
-        self.plans, self.buf, self.all_reduce, self.stream, self.batch = list(plans), buf, all_reduce, stream, batch
+        self.plans, self.buf, self.all_reduce, self.stream, self.batch = list(plans), buf, all_reduce, _stream_for(stream, buf), batch
         self.width = max(p.totals_len for p in plans)
         if buf.dim() != 2 or buf.shape[0] < len(self.plans) or buf.shape[1] < self.width or not buf.is_contiguous():
             raise ValueError("buffer must be a contiguous [len(plans), >= totals_len] float64 tensor")
@@ -193,10 +208,10 @@ def sharded_group_by(engine, query, group_column: int, bins, all_reduce_sum: Cal
 
     bins            float64 tensor on the engine's device with room for 4 * (number of distinct keys) doubles
     all_reduce_max  callable(tensor) -> None, in-place MAX over the group (``torch_all_reduce(op="max")``)
-    stream          raw handle of the stream the collectives are issued on.  NOT 0: a null handle means "the
-                    engine's own stream" to the C ABI, which is not ordered against torch's default stream — run
-                    under ``with torch.cuda.stream(side)`` and pass ``side.cuda_stream``.
+    stream          raw handle of the stream the collectives are issued on; 0 = torch's current stream (run under
+                    ``with torch.cuda.stream(side)``: the legacy default stream is refused, see ``_stream_for``).
     """
+    stream = _stream_for(stream, bins)
     lo, hi = engine.group_key_range(group_column)
     rng = bins.new_tensor([-float(lo), float(hi)])
     all_reduce_max(rng)
@@ -222,3 +237,25 @@ def torch_all_reduce(group=None, op: str = "sum") -> Callable:
         dist.all_reduce(t, op=red, group=group)
 
     return _ar
+
+
+def native_all_reduce(comm, stream: int, op: str = "sum") -> Callable:
+    """In-place all-reduce through the library's own RCCL communicator (engine.Comm, aqe_comm_*): what a C++ host of
+    the C ABI uses; no torch.distributed involved in the data path."""
+    fn = comm.all_reduce_sum if op == "sum" else comm.all_reduce_max
+
+    def _ar(t):
+        fn(t.data_ptr(), t.numel(), stream)
+
+    return _ar
+
+
+def comm_from_torch_group(engine, group=None):
+    """An engine.Comm over the ranks of a torch.distributed group: rank 0 draws the RCCL unique id, the group
+    broadcasts its 128 bytes (any backend — this is the out-of-band exchange), every rank joins."""
+    import torch.distributed as dist
+    from .engine import Comm
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ident = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return Comm(engine, ident[0], world, rank)

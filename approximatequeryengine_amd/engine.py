@@ -154,6 +154,68 @@ class Batch:
         return (ms.value if timed else None), n.value, g.value
 
 
+class Comm:
+    """RCCL communicator behind the C ABI (aqe_comm): in-place f64 all-reduce on the engine's GPU.
+
+    One process per GPU: rank 0 calls ``Comm.unique_id()``, hands the 128 bytes to every rank out of band, and every
+    rank constructs ``Comm(engine, id, nranks, rank)``.  One process, several GPUs: ``Comm.create_all(engines)``."""
+
+    def __init__(self, engine: "Engine", unique_id: bytes, nranks: int, rank: int, _handle=None):
+        self.engine = engine
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            if len(unique_id) != nat.COMM_ID_BYTES:
+                raise ValueError("unique_id must be 128 bytes (Comm.unique_id())")
+            buf = C.create_string_buffer(bytes(unique_id), nat.COMM_ID_BYTES)
+            nat.check(nat.lib().aqe_comm_create(engine._h, buf, nranks, rank, C.byref(self._h)), engine._h)
+        n, r = C.c_int(), C.c_int()
+        nat.check(nat.lib().aqe_comm_info(self._h, C.byref(n), C.byref(r)), engine._h)
+        self.nranks, self.rank = n.value, r.value
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+        nat.check(nat.lib().aqe_comm_unique_id(buf), None)
+        return buf.raw
+
+    @classmethod
+    def create_all(cls, engines):
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        out = (C.c_void_p * len(engines))()
+        nat.check(nat.lib().aqe_comm_create_all(arr, len(engines), out), engines[0]._h)
+        return [cls(e, b"", 0, 0, _handle=C.c_void_p(h)) for e, h in zip(engines, out)]
+
+    def close(self):
+        if self._h:
+            nat.lib().aqe_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_reduce_sum(self, dev_ptr: int, count: int, stream: int = 0):
+        nat.check(nat.lib().aqe_comm_all_reduce_sum(self._h, C.c_void_p(dev_ptr), count, C.c_void_p(stream)), self.engine._h)
+
+    def all_reduce_max(self, dev_ptr: int, count: int, stream: int = 0):
+        nat.check(nat.lib().aqe_comm_all_reduce_max(self._h, C.c_void_p(dev_ptr), count, C.c_void_p(stream)), self.engine._h)
+
+    def run_plan(self, plan: "Plan", dev_vec_ptr: int, stream: int = 0) -> Result:
+        """aqe_plan_run_sharded: the whole query over the ranks, host side in C."""
+        res = Result()
+        nat.check(nat.lib().aqe_plan_run_sharded(plan._h, self._h, C.c_void_p(dev_vec_ptr), C.c_void_p(stream), C.byref(res)), self.engine._h)
+        return res
+
+    def run_batch(self, batch: "Batch", dev_totals_ptr: int, row_stride: int, stream: int = 0):
+        """aqe_batch_run_sharded: sweeps, join, ONE all-reduce, replays — one host call per step (asynchronous)."""
+        nat.check(nat.lib().aqe_batch_run_sharded(batch._h, self._h, C.c_void_p(dev_totals_ptr), row_stride, len(batch.plans),
+                                                  C.c_void_p(stream)), self.engine._h)
+
+
 class Engine:
     """One GPU context holding one shard [shard_lo, shard_lo+local_rows) of a table of global_rows rows."""
 

@@ -348,6 +348,34 @@ AQE_API int aqe_batch_enqueue_all(aqe_batch* batch, void* stream);
  * launch, the rows it sweeps (all plans; 8 B each) and its workgroups.  Any of the outputs may be NULL. */
 AQE_API int aqe_batch_set_profiling(aqe_batch* batch, int enable);
 AQE_API int aqe_batch_launch_info(aqe_batch* batch, float* ms, uint64_t* samples, uint32_t* workgroups);
+/* ---- the collective behind the C ABI: RCCL over xGMI ---------------------------------------------
+ * One all-reduce SUM of the moment vectors replaces the reference's in-process merges (mutex-guarded vector, CAS on
+ * atomic<double>, DB.cpp:948-951, 966-967, 2031-2036).  librccl is opened on first use (no link-time dependency; a
+ * copy already loaded into the process — PyTorch's — is taken when there is one; AQE_RCCL_LIB overrides).
+ *   one process per GPU:   rank 0 calls aqe_comm_unique_id and hands the 128 bytes to every rank out of band (file,
+ *                          socket, MPI, a torch store); every rank calls aqe_comm_create(ctx, id, nranks, rank).
+ *   one process, n GPUs:   aqe_comm_create_all(ctxs, n, comms) — one context per GPU (ncclCommInitAll); collective
+ *                          calls of one step are then bracketed by aqe_comm_group_start / aqe_comm_group_end.
+ * Collectives are in place on f64 device memory and are enqueued on `stream` (NULL = the context's own stream). */
+#define AQE_COMM_ID_BYTES 128
+typedef struct aqe_comm aqe_comm;
+AQE_API int aqe_comm_unique_id(void* id128);
+AQE_API int aqe_comm_create(aqe_ctx* ctx, const void* id128, int nranks, int rank, aqe_comm** out);
+AQE_API int aqe_comm_create_all(aqe_ctx* const* ctxs, int n, aqe_comm** out_n);
+AQE_API void aqe_comm_destroy(aqe_comm* comm);
+AQE_API int aqe_comm_info(const aqe_comm* comm, int* nranks, int* rank);
+AQE_API int aqe_comm_all_reduce_sum(aqe_comm* comm, double* dev_buf, uint64_t count, void* stream);
+AQE_API int aqe_comm_all_reduce_max(aqe_comm* comm, double* dev_buf, uint64_t count, void* stream);
+AQE_API int aqe_comm_group_start(void);
+AQE_API int aqe_comm_group_end(void);
+/* A whole query over the ranks of a communicator (what distributed.ShardedQuery.run does from Python): the batched
+ * form when the plan has one (ONE collective), else one collective per convergence step; a due top-up is finished
+ * with the stepwise step.  dev_vec: max(AQE_MOMENT_VEC, totals_len) doubles of device memory.  Synchronous. */
+AQE_API int aqe_plan_run_sharded(aqe_plan* plan, aqe_comm* comm, double* dev_vec, void* stream, aqe_result* out);
+/* One step of a batch over the ranks of a communicator, asynchronously: sweeps (ONE launch), join, ONE all-reduce SUM
+ * of dev_totals[n_plans][row_stride], replays (ONE launch).  Results: aqe_batch_fetch. */
+AQE_API int aqe_batch_run_sharded(aqe_batch* batch, aqe_comm* comm, double* dev_totals, uint64_t row_stride_doubles, uint32_t n_plans, void* stream);
+
 /* fused single-GPU form: the whole query, asynchronously.  A multi-round (CLT) plan is ONE launch with in-kernel
  * decisions; the reference's top-up (DB.cpp:1031-1040), rarely due, gets its own launch only when the plan's
  * previous execution needed it — otherwise aqe_plan_fetch runs it if the result turns out to want it.

@@ -1012,6 +1012,75 @@ def test_batch_in_one_launch_matches_single_plans_and_oracle(nat, oracle, table)
         pr.close()
 
 
+def test_rccl_communicator_behind_the_c_abi(nat, oracle, table):
+    """aqe_comm_*: the library's own RCCL communicator (a world of one rank here — the collective really runs through
+    librccl), the whole-query and whole-batch host paths in C (aqe_plan_run_sharded, aqe_batch_run_sharded), and the
+    Python orchestration driven with its DEFAULT stream argument.  Answers: the single-GPU path's, and the oracle's."""
+    from approximatequeryengine_amd.distributed import ShardedBatch, ShardedQuery, native_all_reduce
+    from approximatequeryengine_amd.engine import Batch, Comm, Engine, make_query
+    import torch
+    n = 1_000_000
+    rows = table(n)
+    qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=r0, clt_growth=g, num_threads=t)
+          for e, r0, g, t in ((0.0, 4096, 4, 4), (1.0, 256, 2, 8), (0.3, 16, 2, 8))]
+    qs += [make_query(nat.M_MEMORY_STRIDE, 1.0), make_query(nat.M_BLOCK, 1.0, where=(250.0, 750.0), convention=nat.EST_CPP),
+           make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=2.0)]  # the last: 5000 rounds, no batched form
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)
+        want = [eng.reduce(q) for q in qs]
+        side = torch.cuda.Stream()
+        comm = Comm(eng, Comm.unique_id(), 1, 0)
+        assert (comm.nranks, comm.rank) == (1, 0)
+        with torch.cuda.stream(side):
+            t = torch.arange(64, dtype=torch.float64, device="cuda")
+            comm.all_reduce_sum(t.data_ptr(), t.numel(), side.cuda_stream)
+            comm.all_reduce_max(t.data_ptr(), t.numel(), side.cuda_stream)
+            side.synchronize()
+            assert torch.equal(t.cpu(), torch.arange(64, dtype=torch.float64))
+            vec = torch.zeros(512, dtype=torch.float64, device="cuda")
+            for q, w in zip(qs, want):
+                p = eng.plan(q)
+                r = comm.run_plan(p, vec.data_ptr(), side.cuda_stream)
+                assert (r.n, r.visited, r.converged, r.rounds, r.topup, r.topup_pending) == (w.n, w.visited, w.converged, w.rounds, w.topup, 0), q.method
+                assert rel(r.sum, w.sum) <= 1e-13 and rel(r.value, w.value) <= 1e-12 and rel(r.ci_lower, w.ci_lower) <= 1e-12
+                # the Python orchestration with its defaults (stream=0 -> torch's current stream) and the native collective
+                sq = ShardedQuery(p, vec, native_all_reduce(comm, side.cuda_stream))
+                assert sq.stream == side.cuda_stream
+                r = sq.run()
+                assert (r.n, r.converged, r.rounds, r.topup) == (w.n, w.converged, w.rounds, w.topup) and rel(r.sum, w.sum) <= 1e-13
+                p.close()
+            plans = [eng.plan(q) for q in qs[:3]]
+            nb = Batch(plans)
+            buf = torch.zeros(len(plans), max(p.totals_len for p in plans), dtype=torch.float64, device="cuda")
+            for _ in range(3):
+                comm.run_batch(nb, buf.data_ptr(), buf.shape[1], side.cuda_stream)
+            for r, w in zip(nb.fetch(), want):
+                assert (r.converged, r.rounds, r.topup_pending) == (w.converged, w.rounds, 1 if w.topup else 0)
+                if not w.topup:
+                    assert (r.n, r.visited) == (w.n, w.visited) and rel(r.sum, w.sum) <= 1e-13
+            sb = ShardedBatch(plans, buf, native_all_reduce(comm, side.cuda_stream), batch=nb)  # default stream argument
+            assert sb.stream == side.cuda_stream
+            for r, w in zip(sb.run(), want):
+                assert (r.n, r.converged, r.rounds, r.topup, r.topup_pending) == (w.n, w.converged, w.rounds, w.topup, 0) and rel(r.sum, w.sum) <= 1e-13
+            nb.close()
+            for p in plans:
+                p.close()
+        # on the legacy default stream the default argument is refused instead of racing with the collective
+        p = eng.plan(qs[0])
+        with pytest.raises(ValueError):
+            ShardedQuery(p, torch.zeros(512, dtype=torch.float64, device="cuda"), lambda t_: None)
+        p.close()
+        comm.close()
+        (c2,) = Comm.create_all([eng])  # the single-process form (ncclCommInitAll)
+        assert (c2.nranks, c2.rank) == (1, 0)
+        with torch.cuda.stream(side):
+            t = torch.ones(8, dtype=torch.float64, device="cuda")
+            c2.all_reduce_sum(t.data_ptr(), 8, side.cuda_stream)
+            side.synchronize()
+            assert float(t.sum()) == 8.0
+        c2.close()
+
+
 def test_group_by_with_per_group_interval(nat, oracle, table):
     """GROUP BY region / product_id (executor.cpp:202-321): per-group (n, S, Q) against what SQLite returned for the
     reference's statements (tests/golden/groupby_sqlite.json), estimate and interval against the oracle's
