@@ -426,6 +426,12 @@ class CustomBPlusDB:
             if rows[1] <= rows[0]:
                 raise RuntimeError("No samples collected")
         if method == "clt":
+            # the CLT monitor returns the reference's own estimate (CLI:262-291) over the whole table: it has no WHERE
+            # form (planner.cpp), no alternative convention and no seed — asking for one is an error, not a no-op
+            if where is not None:
+                raise ValueError("method='clt' has no WHERE form (clt_validated_dual_pointer_sample samples the whole table, DB.cpp:885-1043)")
+            if convention != "cli":
+                raise ValueError("method='clt' reports the CLI estimate (enhanced_aqe_cli.py:262-291): convention must be 'cli'")
             e = 2.0 if error_percent is None else float(error_percent)
             pct = nat.lib().aqe_error_to_sample_percent(e)
             q = self._clt_query(pct, confidence_level, check_interval, num_threads, e, round0, growth, a)

@@ -132,15 +132,21 @@ def run(args, out=sys.stdout) -> int:
         e, s = 2.0, 10.0
     else:
         e, s = args.e if args.e is not None else 5.0, args.s if args.s is not None else 10.0
+    # `WHERE amount BETWEEN a AND b` / `>= a AND <= b` / `> a` (the façade's extraction, custom_scheduler.cpp:277-294) is
+    # honoured by every sampler that has a WHERE form; the reference CLI ignores it for scalar queries altogether
+    where = aqe_backend.parse_where(clean)
     if qtype == QUERY_RANDOM:
         m = {"block": "block", "parallel": "region", "random": "random"}.get(args.method or "", "stride")
-        res = db.approx(agg, method=m, sample_percent=s, seed=args.seed, num_threads=args.threads)
+        res = db.approx(agg, method=m, sample_percent=s, seed=args.seed, num_threads=args.threads, where=where)
         name = f"{m} sampling ({s}%)"
     elif qtype == QUERY_CLT:
+        if where is not None:
+            print("note: the CLT sampler has no WHERE form (clt_validated_dual_pointer_sample samples the whole table): the WHERE clause is ignored, as in the reference CLI", file=out)
+            where = None
         res = db.approx(agg, method="clt", error_percent=e, num_threads=args.threads, confidence_level=args.confidence)
         name = f"CLT (±{e}%)"
     else:
-        res = db.approx(agg, method="exact")
+        res = db.approx(agg, method="exact", where=where)
         name = "exact"
     ms = (time.perf_counter() - t0) * 1e3
     print(f"\n{name} result:\n   value: {res.value:,.4f}", file=out)
@@ -149,7 +155,7 @@ def run(args, out=sys.stdout) -> int:
     print(f"   samples used: {res.n:,}   rounds: {res.rounds}   converged: {bool(res.converged)}", file=out)
     print(f"   execution time: {ms:.2f} ms (kernels {res.kernel_ms * 1e3:.1f} us, {res.achieved_GBps:.0f} GB/s algorithmic)", file=out)
     if args.compare and qtype != QUERY_EXACT:
-        exact = db.approx(agg, method="exact")
+        exact = db.approx(agg, method="exact", where=where)
         print(f"\ncomparison:\n   approximate: {res.value:,.4f}\n   exact:       {exact.value:,.4f}", file=out)
         if exact.value != 0:
             print(f"   actual error: {abs(res.value - exact.value) / abs(exact.value) * 100:.4f}%", file=out)

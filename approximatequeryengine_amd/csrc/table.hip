@@ -319,7 +319,8 @@ int open_db_file(aqe_ctx* c, const char* path, MappedFile& mf, uint64_t& count) 
     uint64_t hdr[3];  // size_t total | size_t height | size_t count, DB.cpp:669-676
     std::memcpy(hdr, mf.base, sizeof hdr);
     count = hdr[2];
-    if (24 + count * sizeof(aqe_record) > mf.bytes) return fail(c, AQE_ERR_IO, std::string("truncated database file: ") + path);
+    // (the count is untrusted: compared without multiplying, a header of 2^59 rows must not wrap past the check)
+    if (count > (mf.bytes - 24) / sizeof(aqe_record)) return fail(c, AQE_ERR_IO, std::string("truncated database file: ") + path);
     return AQE_OK;
 }
 

@@ -90,7 +90,7 @@ def _check_against_oracle(nat, o, eng, rows, q, idx, where=None):
     return res
 
 
-@pytest.mark.parametrize("n", [10_000, 100_000, 100_007, 1_000_000])
+@pytest.mark.parametrize("n", [10_000, 100_000, 100_007, 1_000_000, 10_000_000])
 def test_golden_calls_reduce_and_gather(nat, oracle, golden, table, engines, n):
     """Every deterministic reference call in the golden file: the HIP reduce reproduces the sums the
     reference's samples give, and the HIP gather returns exactly the reference's rows."""
@@ -98,7 +98,7 @@ def test_golden_calls_reduce_and_gather(nat, oracle, golden, table, engines, n):
     rows, eng = table(n), engines(n)
     for call in T["calls"]:
         q = _query_for(nat, call)
-        if call["method"] in ("memory_stride_sample", "optimized_address_arithmetic_sample"):
+        if call["method"] in ("memory_stride_sample", "optimized_address_arithmetic_sample") and "cache_rows" in T:
             q.visible_rows = T["cache_rows"]  # the reference's stale-cache length (DB.cpp:188-191)
         res = eng.reduce(q)
         g = call["idx"]
@@ -178,6 +178,8 @@ CLT_CASES = [
     (100_007, 20.0, 0.95, 10, 64, 1.0, 8, 2),      # 64 pointers
     (1_000_000, 20.0, 0.95, 10, 4, 2.0, 10, 1),    # the reference's cadence and defaults: 5000 rounds planned, stops early
     (200_000, 20.0, 0.95, 10, 4, 0.0, 10, 1),      # ... and never converging: 1000 rounds, launched chunk by chunk
+    (10_000_000, 20.0, 0.95, 10, 4, 0.01, 4096, 4),  # the bench query at its own size: 4 M samples, never converges
+    (10_000_000, 20.0, 0.95, 10, 4, 1.0, 4096, 4),   # ... and its other reading: stops after round 0, 500 000-row top-up
 ]
 
 
@@ -219,6 +221,22 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     assert rel(res.ci_lower, lo) <= EST_TOL and rel(res.ci_upper, hi) <= EST_TOL
     got = eng.gather(q)
     assert np.array_equal(np.sort(got["id"] - 1), np.sort(idx.astype(np.int64)))
+
+
+def test_clt_collected_rows_lie_within_the_reference_runs(nat, golden, engines):
+    """The converging regime of the reference is a race; what can be pinned is the range its 30 recorded
+    runs show.  Rows collected before the stop (returned - base/4 top-up, DB.cpp:1032-1040): reference 395 ... 49 885;
+    the pooled, round-synchronous monitor on the device must land inside (it stops when the POOL satisfies the rule
+    one fast thread satisfies alone in the reference — fewer rows than the reference's typical run)."""
+    from approximatequeryengine_amd.engine import make_query
+    runs = golden["tables"]["1000000"]["distributions"]["clt_e1_pct20_T4"]
+    eng = engines(1_000_000)
+    r = eng.reduce(make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, confidence_level=0.95, check_interval=10, num_threads=4, max_error_percent=1.0))
+    ref_collected = [x["n"] - 50_000 for x in runs]
+    assert r.converged == 1 and r.topup == 50_000
+    assert min(ref_collected) <= r.n - r.topup <= max(ref_collected)
+    avgs = np.array([x["avg"] for x in runs])
+    assert abs(r.value - avgs.mean()) <= 3 * max(avgs.std(), 0.5)
 
 
 def test_clt_head_form_misprediction_is_continued(nat, oracle, table):
@@ -698,6 +716,19 @@ def test_file_staging_round_trip(nat, oracle, golden, table, tmp_path):
         t = eng.info()
         assert (t.global_rows, t.shard_lo, t.local_rows, t.has_aos) == (n, 10_000, 20_000, 0)
         assert t.shift == float(np.sum(rows["amount"][:1024], dtype=np.float64) / 1024) or abs(t.shift - rows["amount"][:1024].mean()) < 1e-9
+        # hostile / truncated headers are I/O errors, not reads past the mapping: a row count that wraps 24 + 32 * count
+        # around 2^64 (2^59 + 1 rows in a 56-byte file), a count one row beyond the file, a file shorter than its header
+        import struct
+        for name, blob in (("wrap.db", struct.pack("<QQQ", 1, 1, (1 << 59) + 1) + b"\0" * 32),
+                           ("short.db", p.read_bytes()[: 24 + 32 * 100 - 1]),
+                           ("tiny.db", b"\0" * 23)):
+            bad = tmp_path / name
+            bad.write_bytes(blob if name != "short.db" else struct.pack("<QQQ", 100, 1, 100) + blob[24:])
+            with pytest.raises(nat.AqeError) as ei:
+                eng.stage_file(bad, keep_aos=False)
+            assert ei.value.status == nat.ERR_IO
+            with pytest.raises(nat.AqeError):
+                eng.stage_file(bad, shard_lo=0, n_local=1, keep_aos=True)
 
 
 def test_synthetic_generator_matches_oracle(nat, oracle):
@@ -1185,8 +1216,9 @@ def test_group_by_over_virtual_shards(nat, oracle, table):
         whole.stage_records(rows, keep_aos=True)
         refs = {(i, col): whole.reduce_grouped(q, col) for i, q in enumerate(queries) for col in (nat.GROUP_REGION, nat.GROUP_PRODUCT)}
         # a world of one through the helper: identity collectives
-        bins = torch.zeros(4 * 1024, dtype=torch.float64, device="cuda")
-        got = sharded_group_by(whole, queries[0], nat.GROUP_PRODUCT, bins, lambda t: None, lambda t: None, torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.stream(torch.cuda.Stream()):  # the helper's default stream argument = torch's current stream
+            bins = torch.zeros(4 * 1024, dtype=torch.float64, device="cuda")
+            got = sharded_group_by(whole, queries[0], nat.GROUP_PRODUCT, bins, lambda t: None, lambda t: None)
         # (counts exact; a group's floating-point sum depends on the order lanes reach the LDS bin: equal to rounding)
         assert [(g_.key, g_.n) for g_ in got] == [(w.key, w.n) for w in refs[(0, nat.GROUP_PRODUCT)]]
         assert all(rel(g_.sum, w.sum) <= 1e-13 for g_, w in zip(got, refs[(0, nat.GROUP_PRODUCT)]))

@@ -158,6 +158,18 @@ def test_clt_distribution_of_reference_runs(oracle, golden, table):
     assert abs(avg - ref_avgs.mean()) <= 3 * max(ref_avgs.std(), 0.5)
     # sample counts: reference returns collected + base/4 top-up (DB.cpp:1032-1040) => >= base/4
     assert min(r["n"] for r in runs) >= 50_000 and res.final.n >= 50_000
+    # Rows COLLECTED before the stop (pre-top-up).  The reference stops when ONE fast thread's own statistics satisfy
+    # the rule (n_fast ~ 12.4 k at e = 1 %, golden clt_fast_stop) while the other threads have collected whatever the
+    # race let them: 395 ... 49 885 rows over its 30 runs (about T x 12.4 k when all four run at full speed).  The
+    # round-synchronous restatement judges the POOLED triple — the "(n, S, Q) all-reduce per convergence step" of the
+    # north star — so it stops once the pool holds ~12.7 k rows: fewer rows than the reference's typical run, inside
+    # the range its runs actually show.  (Either way the returned sample is dominated by the base/4 top-up.)
+    base4 = 200_000 // 4
+    ref_collected = [r["n"] - base4 for r in runs]
+    ours = res.final.n - res.topup
+    assert res.topup == base4 and min(ref_collected) <= ours <= max(ref_collected), (ours, min(ref_collected), max(ref_collected))
+    fast_alone = next(g_["n_fast_at_stop"] for g_ in golden["tables"]["1000000"]["clt_fast_stop"] if g_["e"] == 1.0 and g_["pct"] == 20.0)
+    assert 0.8 * fast_alone <= ours <= 1.25 * fast_alone  # the pool needs what one fast worker needs: the rule is the same test
 
 
 def test_random_device_reducers_are_statistically_consistent(oracle, golden, table):
