@@ -60,7 +60,7 @@ SPECS = [
 ]
 
 
-@pytest.mark.parametrize("world,batched", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,batched", [(2, False), (3, False), (2, True), (4, False), (4, True)])
 def test_sharded_query_over_gloo_matches_single_process_oracle(oracle, table, tmp_path, world, batched):
     n = 200_003
     port = _free_port()
@@ -87,6 +87,80 @@ def test_sharded_query_over_gloo_matches_single_process_oracle(oracle, table, tm
                 assert g["collectives"] == 1 + (1 if want.topup else 0) and g["topup_pending"] == 0
             assert abs(g["sum"] - want.final.sum) <= 1e-12 * abs(want.final.sum)
             assert abs(g["m2"] - want.final.m2) <= 1e-9 * abs(want.final.m2)
+
+
+def _batch_worker(rank, world, port, n, specs, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_engine import OracleShardPlan
+    from approximatequeryengine_amd.distributed import PipelinedBatches, ShardedBatch, shard_bounds
+    from oracle.pyoracle import Oracle
+    o = Oracle()
+    lo, hi = shard_bounds(n, world, rank)
+    rows = o.synth(hi - lo, 42, first=lo)
+    shift = float(o.synth(min(n, 1024), 42)["amount"].mean())
+    calls = [0]
+
+    def all_reduce(t):
+        calls[0] += 1
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def make():
+        plans = [OracleShardPlan(o, rows, lo, n, shift, spec) for spec in specs]
+        buf = torch.zeros(len(plans), max(p.totals_len for p in plans) + 8, dtype=torch.float64)
+        return ShardedBatch(plans, buf, all_reduce)
+
+    # (a) one batch, one collective for all of its queries; run() finishes the due top-ups with ONE more collective
+    sb = make()
+    sb.enqueue()
+    marks = [r["topup_pending"] for r in sb.fetch()]
+    c_step = calls[0]
+    out = sb.run()
+    c_run = calls[0] - c_step
+    # (b) two batches software-pipelined over several steps: a step's collective is issued after the NEXT step's sweeps
+    pipe = PipelinedBatches([make(), make()])
+    before = calls[0]
+    for _ in range(5):
+        pipe.enqueue()
+    piped = pipe.fetch()
+    torch.save({"marks": marks, "c_step": c_step, "c_run": c_run, "out": out, "piped": piped, "c_pipe": calls[0] - before},
+               os.path.join(out_dir, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_batch_and_pipeline_over_gloo(oracle, table, tmp_path, world):
+    """ShardedBatch (one all-reduce per batch of queries) and PipelinedBatches over gloo: every rank gets the
+    single-process oracle's answer for every query; a due top-up (DB.cpp:1031-1040) shows as the same mark on every
+    rank and is finished by run() with one more collective for the whole batch."""
+    n = 200_003
+    specs = [s_ for s_ in SPECS if s_[0] == "clt"]
+    port = _free_port()
+    mp.spawn(_batch_worker, args=(world, port, n, specs, str(tmp_path)), nprocs=world, join=True)
+    per_rank = [torch.load(tmp_path / f"b{r}.pt", weights_only=False) for r in range(world)]
+    rows = table(n)
+    wants = []
+    for _, pct, conf, ci, T, e, R0, growth in specs:
+        rc, want, _ = oracle.clt_run(rows, pct, conf, ci, T, e, R0=R0, growth=growth)
+        assert rc == 0
+        wants.append(want)
+    for pr in per_rank:
+        assert pr == per_rank[0]  # every rank folds the same reduced buffer
+    g = per_rank[0]
+    assert g["marks"] == [1 if w.topup else 0 for w in wants] and any(g["marks"]) and not all(g["marks"])
+    assert g["c_step"] == 1                      # ONE collective for the whole batch
+    assert g["c_run"] == 2                       # run(): the batch's collective + one more for all due top-ups
+    assert g["c_pipe"] == 5 and len(g["piped"]) == 2 * len(specs)
+    for got, w in zip(g["out"], wants):
+        assert (got["n"], got["converged"], got["rounds"], got["topup"], got["topup_pending"]) == (w.final.n, w.converged, w.rounds, w.topup, 0)
+        assert abs(got["sum"] - w.final.sum) <= 1e-12 * abs(w.final.sum)
+    for got, w in zip(g["piped"], wants + wants):
+        assert (got["converged"], got["rounds"], got["topup_pending"]) == (w.converged, w.rounds, 1 if w.topup else 0)
+        if not w.topup:
+            assert got["n"] == w.final.n and abs(got["sum"] - w.final.sum) <= 1e-12 * abs(w.final.sum)
 
 
 def test_shard_bounds_are_a_proper_partition():
