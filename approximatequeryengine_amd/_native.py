@@ -15,6 +15,7 @@ M_EXACT, M_MEMORY_STRIDE, M_ADDRESS_ARITHMETIC, M_RANDOM_POINTER, M_BLOCK, M_PAG
 M_OPTIMIZED_CLT, M_CLT_DUAL_POINTER, M_FAST_POINTER, M_SLOW_POINTER, M_DUAL_POINTER = 7, 8, 9, 10, 11
 M_PARALLEL_POINTER, M_REGION_STRIDE, M_RANDOM_START_STRIDE, M_ADAPTIVE_BLOCK, M_STRATIFIED_BLOCK = 12, 13, 14, 15, 16
 M_ROWID_MOD = 17
+M_RANDOM_DEVICE = 18
 GROUP_REGION, GROUP_PRODUCT = 1, 2
 
 SUM, AVG, COUNT = 0, 1, 2
@@ -73,7 +74,9 @@ class GroupResult(C.Structure):
 
 class TableInfo(C.Structure):
     _fields_ = [("global_rows", C.c_uint64), ("shard_lo", C.c_uint64), ("local_rows", C.c_uint64),
-                ("shift", C.c_double), ("has_aos", C.c_int32), ("device_id", C.c_int32), ("hbm_bytes", C.c_uint64)]
+                ("shift", C.c_double), ("has_aos", C.c_int32), ("device_id", C.c_int32), ("hbm_bytes", C.c_uint64),
+                ("view_bytes", C.c_uint64), ("n_views", C.c_uint32), ("view_evictions", C.c_uint32), ("view_fallbacks", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class AqeError(RuntimeError):
@@ -175,7 +178,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.aqe_abi_version() != 1:
+    if L.aqe_abi_version() != 2:
         raise ImportError("libaqe_hip.so ABI version mismatch")
     _lib = L
     return L

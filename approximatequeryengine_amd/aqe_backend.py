@@ -379,8 +379,10 @@ class CustomBPlusDB:
                                        num_threads=int(num_threads), seed=int(seed))).value
 
     def _random_cpp(self, agg, sample_percent, seed, where=None) -> nat.Result:
-        seed = int.from_bytes(os.urandom(4), "little") if seed is None else int(seed) & 0xFFFFFFFF
-        return self._reduce(make_query(nat.M_RANDOM_POINTER, sample_percent, agg=agg, convention=nat.EST_CPP, seed=seed,
+        # sample_records (DB.cpp:345-363) shuffles with std::random_device: there is nothing to match bit for bit, so
+        # the sample is drawn ON THE DEVICE (AQE_M_RANDOM_DEVICE: a keyed bijection of the rows, no host index list)
+        seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        return self._reduce(make_query(nat.M_RANDOM_DEVICE, sample_percent, agg=agg, convention=nat.EST_CPP, seed=seed,
                                        where=where))
 
     def parallel_sum_sample(self, sample_percent, num_threads=4, *, seed=None) -> float:
@@ -412,8 +414,9 @@ class CustomBPlusDB:
                where: Optional[Tuple[float, float]] = None, seed: int = 42, num_threads: int = 4, block_size: int = 1000,
                confidence_level: float = 0.95, check_interval: int = 10, round0: int = 4096, growth: int = 4,
                convention: str = "cli", id_between: Optional[Tuple[int, int]] = None) -> ApproxResult:
-        """APPROX <agg>(amount): method in {"stride","random","block","page","parallel_block","region","clt","exact",
-        "adaptive_block","stratified_block"}.
+        """APPROX <agg>(amount): method in {"stride","random","random_device","block","page","parallel_block","region","clt",
+        "exact","adaptive_block","stratified_block"}.  "random" is random_pointer_sample(seed) bit for bit (host mt19937 +
+        Lemire index list, DB.cpp:856-882); "random_device" draws a simple random sample on the device (no index list).
         ``error_percent`` (CLT) is in percent, as the reference CLI's --e (enhanced_aqe_cli.py:414-415); the
         sample percentage then follows enhanced_aqe_cli.py:243-250."""
         a = _AGG[agg.upper()]
@@ -438,7 +441,7 @@ class CustomBPlusDB:
             if rows:
                 q.row_lo, q.row_hi = rows
         else:
-            m = {"stride": nat.M_MEMORY_STRIDE, "random": nat.M_RANDOM_POINTER, "block": nat.M_BLOCK, "page": nat.M_PAGE,
+            m = {"stride": nat.M_MEMORY_STRIDE, "random": nat.M_RANDOM_POINTER, "random_device": nat.M_RANDOM_DEVICE, "block": nat.M_BLOCK, "page": nat.M_PAGE,
                  "parallel_block": nat.M_PARALLEL_BLOCK, "region": nat.M_REGION_STRIDE, "exact": nat.M_EXACT,
                  "adaptive_block": nat.M_ADAPTIVE_BLOCK, "stratified_block": nat.M_STRATIFIED_BLOCK}[method]
             if method == "adaptive_block" and block_size == 1000:

@@ -55,7 +55,7 @@ int aqe_plan_families(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, 
     if (samples_out) *samples_out = P.global_samples;
     const std::vector<aqe_family>* src = nullptr;
     static const std::vector<aqe_family> none;
-    if (P.is_random) src = &none;
+    if (P.is_random || P.is_perm) src = &none;
     else if (round < P.round_fams.size()) src = &P.round_fams[round];
     else if (round == P.rounds && P.has_topup) src = &P.topup_fams;
     else src = &none;
@@ -142,11 +142,9 @@ namespace {
 int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, hipStream_t s, unsigned* grid_out) {
     *grid_out = 0;
     aqe_plan* p = nullptr;
-    aqe_query in_place = *q;
-    in_place.flags |= AQE_Q_NO_LAYOUT;  // the key column is read beside the amounts: the families must address rows
-    int rc = cached_plan(c, &in_place, &p);
+    int rc = cached_plan(c, q, &p);
     if (rc != AQE_OK) return rc;
-    if (p->host.is_random || p->host.is_clt || p->host.on_sorted || p->rounds.size() > 1)
+    if (p->host.is_random || p->host.is_perm || p->host.is_clt || p->host.on_sorted || p->rounds.size() > 1)
         return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction takes a single-round family sampler (exact, stride, rowid-mod, block, page, pointer, region ...)");
     for (const DevFamily& f : p->h_fams)
         if (f.flags & AQE_F_PAIR) return fail(c, AQE_ERR_UNSUPPORTED, "grouped reduction does not take pair families");
@@ -156,6 +154,13 @@ int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_
     const int k = group_column - 1;
     if (c->key_min[k] < key_min || static_cast<int64_t>(c->key_max[k]) - key_min >= static_cast<int64_t>(nbins))
         return fail(c, AQE_ERR_INVALID, "this shard has keys outside [key_min, key_min + nbins)");
+    // A strided sample is laid out over the stride-major view of the column (plans.hip): the keys are then read from the
+    // key column's view in the same slot order — 12 bytes per sampled row instead of a whole line of each column.
+    const int32_t* keys = c->keycol[k];
+    if (p->view_rounds) {
+        rc = ensure_key_view(c, group_column, p->view_step_rounds, &keys);
+        if (rc != AQE_OK) return rc;
+    }
     const LaunchDesc& L = p->rounds[0];
     const unsigned grid = grouped_grid(L.ntiles);
     const size_t need = static_cast<size_t>(grid) * nbins * 4 * sizeof(double);
@@ -166,7 +171,7 @@ int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_partial), need));
         c->grp_partial_bytes = need;
     }
-    HIPCHK(c, launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, c->keycol[k], key_min, nbins, c->grp_partial, grid, s));
+    HIPCHK(c, launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, keys, key_min, nbins, c->grp_partial, grid, s));
     *grid_out = grid;
     return AQE_OK;
 }
@@ -287,8 +292,8 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
         rounds_used = static_cast<uint32_t>(r.rounds);
         topup_rows = r.topup;
     }
-    uint64_t total = p->host.is_random ? p->host.random_idx.size() : 0;
-    if (!p->host.is_random)
+    uint64_t total = p->host.is_random ? p->host.random_idx.size() : p->host.is_perm ? p->host.perm_target : 0;
+    if (!p->host.is_random && !p->host.is_perm)
         for (uint32_t r = 0; r < rounds_used; ++r) total += p->rounds[r].samples;
     total += topup_rows;
     *n_out = total;
@@ -299,6 +304,8 @@ int aqe_gather(aqe_ctx* c, const aqe_query* q, void* out_aos32, uint64_t cap, ui
     hipError_t e = hipSuccess;
     if (p->host.is_random) {
         e = launch_gather_indexed(c->aos, c->shard_lo, p->d_idx, p->host.random_idx.size(), d_out, c->stream);
+    } else if (p->host.is_perm) {  // rows come back in draw order (k = 0, 1, ...): a sample, not a sorted set
+        e = launch_gather_permuted(c->aos, perm_spec(p->host.perm_n, p->host.perm_lo, p->host.perm_target, p->host.perm_seed), d_out, c->stream);
     } else {
         for (uint32_t r = 0; r < rounds_used && e == hipSuccess; ++r) {
             const LaunchDesc& L = p->rounds[r];

@@ -21,7 +21,47 @@
 namespace aqe {
 namespace {
 
-constexpr unsigned kRegBins = 8;
+// Binning.  The bins of a workgroup live in LDS; how depends on the number of keys:
+//   * up to kPrivBins keys (region: 4): LANE-PRIVATE bins, [component][bin][thread].  Few keys mean every lane of a
+//     wave instruction hits one of a handful of addresses — shared bins serialise (64 lanes on 4 addresses), and
+//     per-lane register bins need a masked add per bin and element (what this kernel did before: 73 us for the exact
+//     scan of 10 M rows, bound by those adds).  With a word of its own per lane and bin, an LDS add never conflicts,
+//     costs the same for every key, and the workgroup's totals are summed afterwards in thread order: bit-reproducible.
+//   * more keys (product_id: 100): bins shared by the workgroup, component-major, lanes add with ds_add_f64; the lanes
+//     of a wave instruction mostly hold different keys, so collisions are rare.
+constexpr unsigned kPrivBins = 8;
+
+template <bool kPrivate>
+struct Binner {
+    double* s;      // sum of (x - c)
+    double* q;      // sum of (x - c)^2
+    unsigned* n;    // rows that pass WHERE            (private mode: u32 counters; shared mode: f64, see below)
+    unsigned* v;    // rows sampled
+    double* nd;     // shared mode: counts as f64 (one LDS atomic type)
+    double* vd;
+    unsigned nb, tid;
+    __device__ __forceinline__ void add(unsigned b, bool ok, bool pass, double d) const {
+        if (kPrivate) {
+            const unsigned i = b * kBlockThreads + tid;
+            if (ok) {
+                __hip_atomic_fetch_add(v + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pass) {
+                    __hip_atomic_fetch_add(n + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(s + i, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(q + i, d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        } else if (ok && b < nb) {
+            __hip_atomic_fetch_add(vd + b, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pass) {
+                __hip_atomic_fetch_add(nd + b, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s + b, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(q + b, d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+};
+
 
 __global__ __launch_bounds__(kBlockThreads) void k_extract_key(const aqe_record* __restrict__ aos, int32_t* __restrict__ out, u64 n,
                                                                int column) {
@@ -70,101 +110,137 @@ struct GroupLaunch {
 };
 
 // One wave folds one tile of the family table (the decomposition add_family made: kDenseTileOrdinals for dense
-// families, kTileOrdinals otherwise; PAIR families do not occur in single-round samplers).
+// families — two rows per lane per load: 16 bytes of amounts, 8 bytes of keys — kTileOrdinals otherwise; PAIR families
+// do not occur in single-round samplers).
+template <bool kPrivate>
 __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
-    // [4][nbins], component-major: the lanes of a wave mostly hold consecutive keys (product_id = row % 100), and
-    // consecutive f64 words spread over all LDS banks — [nbins][4] put them 32 bytes apart, on a quarter of the banks
-    extern __shared__ double bins[];
+    extern __shared__ double lds[];
     __shared__ DevFamily lds_fams[kMaxLdsFams];
-    for (unsigned i = threadIdx.x; i < a.nbins * 4; i += kBlockThreads) bins[i] = 0.0;
+    const unsigned nb = a.nbins;
+    const unsigned words = kPrivate ? nb * kBlockThreads * 3 : nb * 4;  // in doubles (private: s, q, and n + v as 2 x u32)
+    for (unsigned i = threadIdx.x; i < words; i += kBlockThreads) lds[i] = 0.0;
+    Binner<kPrivate> B;
+    B.nb = nb;
+    B.tid = threadIdx.x;
+    if (kPrivate) {
+        B.s = lds;
+        B.q = lds + nb * kBlockThreads;
+        B.n = reinterpret_cast<unsigned*>(lds + 2 * nb * kBlockThreads);
+        B.v = B.n + nb * kBlockThreads;
+        B.nd = B.vd = nullptr;
+    } else {
+        B.nd = lds; B.s = lds + nb; B.q = lds + 2 * nb; B.vd = lds + 3 * nb;
+        B.n = B.v = nullptr;
+    }
     const DevFamily* fams = stage_families(a.sw, lds_fams);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
     const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
-    const bool in_regs = a.nbins <= kRegBins;
-    const unsigned nb = a.nbins;  // uniform: bins past it cost nothing
-    double rs[kRegBins], rq[kRegBins];
-    unsigned cn[kRegBins], cv[kRegBins];
-#pragma unroll
-    for (unsigned b = 0; b < kRegBins; ++b) { rs[b] = rq[b] = 0.0; cn[b] = cv[b] = 0u; }
+    const double c = a.sw.shift, wmin = a.sw.wmin, wmax = a.sw.wmax;
+    const bool has_where = a.sw.has_where != 0;
+    const int kmin = a.key_min;
 
     for (u64 t = wave_id; t < a.ntiles; t += wave_stride) {
-        unsigned lo = 0, hi = a.sw.nfam;
-        while (hi - lo > 1) {
-            unsigned mid = (lo + hi) >> 1;
-            if (fams[mid].tile_begin <= t) lo = mid; else hi = mid;
-        }
-        const DevFamily& F = fams[lo];
+        const DevFamily& F = fams[find_family(fams, a.sw.nfam, t)];
         const u64 lt = t - F.tile_begin;
         u64 seg, j;
         if (F.tiles_per_seg == 0) { seg = F.seg_lo; j = F.j_lo + lt; }
         else { seg = F.seg_lo + lt / F.tiles_per_seg; j = lt % F.tiles_per_seg; }
         const u64 seg_len = F.seg_len, step = F.step, seg_ord0 = seg * seg_len;
-        const u64 tile = (a.sw.dense16 && is_dense16(step, F.flags, seg_len)) ? kDenseTileOrdinals : kTileOrdinals;
+        const u64 ord_lo = F.ord_lo, ord_hi = F.ord_hi;
         const u64 row_base = F.row0 + seg * F.pitch - a.sw.shard_lo;
-        for (u64 k0 = 0; k0 < tile; k0 += static_cast<u64>(64) * kTileUnroll) {
-            double x[kTileUnroll];
-            int key[kTileUnroll];
-            bool ok[kTileUnroll];
+        const double* const base = a.sw.amount + row_base;
+        const int32_t* const kbase = a.keys + row_base;
+        if (a.sw.dense16 && is_dense16(step, F.flags, seg_len)) {
+            struct __attribute__((packed, aligned(8))) Row2 { double x, y; };
+            struct __attribute__((packed, aligned(4))) Key2 { int x, y; };
+            const u64 oi0 = j * kDenseTileOrdinals + 2 * static_cast<u64>(lane);
+            Row2 x2[kTileUnroll];
+            Key2 k2[kTileUnroll];
+            bool ok0[kTileUnroll], ok1[kTileUnroll];
 #pragma unroll
-            for (int k = 0; k < kTileUnroll; ++k) {  // every load of the batch is issued before the first use
-                const u64 oi = j * tile + k0 + static_cast<u64>(k) * 64 + lane;
+            for (int k = 0; k < kTileUnroll; ++k) {  // every load of the tile is issued before the first use
+                const u64 oi = oi0 + static_cast<u64>(k) * 128;
                 const u64 o = seg_ord0 + oi;
-                ok[k] = oi < seg_len && o >= F.ord_lo && o < F.ord_hi;
-                const u64 row = ok[k] ? row_base + oi * step : 0;
-                x[k] = a.sw.amount[row];
-                key[k] = a.keys[row];
+                ok0[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
+                ok1[k] = oi + 1 < seg_len && o + 1 >= ord_lo && o + 1 < ord_hi;
+                const bool both = ok0[k] && ok1[k];
+                x2[k] = *reinterpret_cast<const Row2*>(both ? base + oi : a.sw.amount);
+                k2[k] = *reinterpret_cast<const Key2*>(both ? kbase + oi : a.keys);
+                if (!both) {  // window edge: single reads
+                    x2[k].x = ok0[k] ? base[oi] : 0.0;
+                    x2[k].y = ok1[k] ? base[oi + 1] : 0.0;
+                    k2[k].x = ok0[k] ? kbase[oi] : kmin;
+                    k2[k].y = ok1[k] ? kbase[oi + 1] : kmin;
+                }
             }
 #pragma unroll
             for (int k = 0; k < kTileUnroll; ++k) {
-                const bool pass = ok[k] && (!a.sw.has_where || (x[k] >= a.sw.wmin && x[k] <= a.sw.wmax));  // DB.cpp:329
-                const double d = x[k] - a.sw.shift;
-                const unsigned b = static_cast<unsigned>(key[k] - a.key_min);
-                if (in_regs) {
+                const bool p0 = !has_where || (x2[k].x >= wmin && x2[k].x <= wmax);  // inclusive both ends, DB.cpp:329
+                const bool p1 = !has_where || (x2[k].y >= wmin && x2[k].y <= wmax);
+                B.add(static_cast<unsigned>(k2[k].x - kmin), ok0[k], p0, x2[k].x - c);
+                B.add(static_cast<unsigned>(k2[k].y - kmin), ok1[k], p1, x2[k].y - c);
+            }
+            continue;
+        }
+        const u64 oi0 = j * kTileOrdinals + lane;
+        double x[kTileUnroll];
+        int key[kTileUnroll];
+        bool ok[kTileUnroll];
+        if (F.flags & kFamLinear) {
+            // short segments (pages) tiled along the ordinal axis, a tile spanning several segments (device_common.hpp, sweep_family)
+            const u64 T0 = j * kTileOrdinals;
+            const u64 seg0 = T0 / seg_len;
+            const unsigned r0 = static_cast<unsigned>(T0 - seg0 * seg_len), sl = static_cast<unsigned>(seg_len);
+            const float inv = 1.0f / static_cast<float>(sl);
+            const u64 col0 = F.row0 - a.sw.shard_lo;
 #pragma unroll
-                    for (unsigned g = 0; g < kRegBins; ++g) {
-                        if (g < nb) {
-                            const bool mine = ok[k] && b == g, counted = mine && pass;
-                            cv[g] += mine ? 1u : 0u;
-                            cn[g] += counted ? 1u : 0u;
-                            rs[g] += counted ? d : 0.0;
-                            rq[g] += counted ? d * d : 0.0;
-                        }
-                    }
-                } else if (ok[k] && b < a.nbins) {
-                    atomicAdd(&bins[3 * nb + b], 1.0);
-                    if (pass) {
-                        atomicAdd(&bins[b], 1.0);
-                        atomicAdd(&bins[nb + b], d);
-                        atomicAdd(&bins[2 * nb + b], d * d);
-                    }
-                }
+            for (int k = 0; k < kTileUnroll; ++k) {
+                const unsigned xx = r0 + static_cast<unsigned>(lane) + 64u * static_cast<unsigned>(k);
+                const unsigned qx = static_cast<unsigned>((static_cast<float>(xx) + 0.5f) * inv);
+                const u64 o = T0 + static_cast<unsigned>(lane) + 64u * static_cast<unsigned>(k);
+                ok[k] = o >= ord_lo && o < ord_hi;
+                const u64 off = ok[k] ? col0 + (seg0 + qx) * F.pitch + static_cast<u64>(xx - qx * sl) * step : 0;
+                x[k] = a.sw.amount[off];
+                key[k] = ok[k] ? a.keys[off] : kmin;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTileUnroll; ++k) {
+                const u64 oi = oi0 + static_cast<u64>(k) * 64;
+                const u64 o = seg_ord0 + oi;
+                ok[k] = oi < seg_len && o >= ord_lo && o < ord_hi;
+                const u64 off = ok[k] ? oi * step : 0;
+                x[k] = ok[k] ? base[off] : a.sw.amount[0];
+                key[k] = ok[k] ? kbase[off] : kmin;
             }
         }
-    }
-    if (in_regs) {
-        // the wave's totals, seven values at a time (value i = bins[i]: bin i / 4, component i % 4); lane 8 c of a
-        // batch holds its c-th total and adds it to the workgroup's bin
-        constexpr unsigned kVals = kRegBins * 4;
 #pragma unroll
-        for (unsigned i0 = 0; i0 < kVals; i0 += 7) {
-            if (i0 < nb * 4) {
-                double v[7];
-#pragma unroll
-                for (unsigned c7 = 0; c7 < 7; ++c7) {
-                    const unsigned i = i0 + c7, g = i / 4, comp = i % 4;  // compile-time after unrolling
-                    v[c7] = i >= kVals ? 0.0 : comp == 0 ? static_cast<double>(cn[g]) : comp == 1 ? rs[g] : comp == 2 ? rq[g] : static_cast<double>(cv[g]);
-                }
-                const double total = wave_sum7(v, lane);
-                const unsigned i = i0 + (static_cast<unsigned>(lane) >> 3);
-                if ((lane & 7) == 0 && lane < 56 && i < nb * 4 && total != 0.0) atomicAdd(&bins[(i % 4) * nb + i / 4], total);
-            }
+        for (int k = 0; k < kTileUnroll; ++k) {
+            const bool pass = !has_where || (x[k] >= wmin && x[k] <= wmax);
+            B.add(static_cast<unsigned>(key[k] - kmin), ok[k], pass, x[k] - c);
         }
     }
     __syncthreads();
-    double* out = a.partial + static_cast<size_t>(blockIdx.x) * a.nbins * 4;
-    for (unsigned i = threadIdx.x; i < a.nbins * 4; i += kBlockThreads) out[i] = bins[(i % 4) * nb + i / 4];  // out: [nbins][4]
+    double* out = a.partial + static_cast<size_t>(blockIdx.x) * nb * 4;  // [nbins][4]: n, S - c n, Q, visited
+    if (kPrivate) {
+        // thread (bin, component) adds the workgroup's 256 private words in thread order (four chains, fixed grouping)
+        if (threadIdx.x < nb * 4) {
+            const unsigned b = threadIdx.x >> 2, comp = threadIdx.x & 3;
+            double t4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (unsigned i = 0; i < kBlockThreads; i += 4) {
+#pragma unroll
+                for (unsigned u = 0; u < 4; ++u) {
+                    const unsigned w = b * kBlockThreads + i + u;
+                    t4[u] += comp == 0 ? static_cast<double>(B.n[w]) : comp == 1 ? B.s[w] : comp == 2 ? B.q[w] : static_cast<double>(B.v[w]);
+                }
+            }
+            out[threadIdx.x] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+        }
+    } else {
+        for (unsigned i = threadIdx.x; i < nb * 4; i += kBlockThreads) out[i] = lds[(i % 4) * nb + i / 4];
+    }
 }
 
 // One wave per (bin, component): lane l adds the workgroups l, l + 64, ... in order, then a fixed xor butterfly
@@ -261,7 +337,8 @@ unsigned grouped_grid(uint64_t ntiles) { return blocks_for(ntiles, kWavesPerBloc
 hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t* keys, int32_t key_min, uint32_t nbins, double* partial,
                           unsigned grid, hipStream_t s) {
     GroupLaunch a{sw, ntiles, keys, key_min, nbins, partial};
-    hipLaunchKernelGGL(k_grouped, dim3(grid), dim3(kBlockThreads), nbins * 4 * sizeof(double), s, a);
+    if (nbins <= kPrivBins) hipLaunchKernelGGL(k_grouped<true>, dim3(grid), dim3(kBlockThreads), static_cast<size_t>(nbins) * kBlockThreads * 3 * sizeof(double), s, a);
+    else hipLaunchKernelGGL(k_grouped<false>, dim3(grid), dim3(kBlockThreads), static_cast<size_t>(nbins) * 4 * sizeof(double), s, a);
     return hipGetLastError();
 }
 

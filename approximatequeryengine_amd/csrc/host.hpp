@@ -66,6 +66,17 @@ struct PlanScratch {
     aqe::DevFamily* d_fams_small = nullptr;  // room for a family table of up to kPoolFams entries
 };
 
+// One stride-major copy of the column (and, for GROUP BY, of the key columns in the same slot order).
+struct StrideView {
+    double* amount = nullptr;
+    int32_t* keys[2] = {nullptr, nullptr};  // [AQE_GROUP_REGION - 1], [AQE_GROUP_PRODUCT - 1], built on first use
+    uint64_t M = 0, q0 = 0;   // slot(r) = (r % step) * M + (r / step - q0)
+    uint64_t bytes = 0;       // HBM this view holds (amount + key views)
+    uint32_t refs = 0;        // plans laid out over it
+    uint32_t cache_refs = 0;  // ... of which the reduce cache's own (evictable with the view)
+    uint64_t last_use = 0;
+};
+
 struct aqe_ctx {
     std::vector<PlanScratch> scratch_pool;
     int device = 0;
@@ -81,8 +92,14 @@ struct aqe_ctx {
     double zone_var[10] = {0};
     double* sorted_amount = nullptr;
     uint32_t* sorted_row = nullptr;
-    // stride-major views of the amount column, one per step a CLT plan has asked for (table.hip ensure_stride_view)
-    std::map<uint64_t, double*> stride_views;
+    // stride-major views of the amount column, one per pointer step in use (table.hip ensure_stride_view): at most
+    // kMaxStrideViews per table; past that the least recently used view no live plan of the caller holds is evicted
+    // (plans of the reduce cache that use it go with it), and when every view is held the new step is swept in place
+    std::map<uint64_t, StrideView> stride_views;
+    uint64_t view_clock = 0;       // last_use stamps
+    uint64_t view_bytes = 0;       // HBM held by views (amount + key views), part of hbm_bytes
+    uint64_t view_evictions = 0;   // views dropped to make room, since the table was staged
+    uint64_t view_fallbacks = 0;   // plans that wanted a view and were laid out in place instead
     // GROUP BY: key columns (SoA int32), extracted from the AoS rows or generated for a synthetic table on first use
     int32_t* keycol[2] = {nullptr, nullptr};  // [AQE_GROUP_REGION - 1], [AQE_GROUP_PRODUCT - 1]
     int32_t key_min[2] = {0, 0}, key_max[2] = {-1, -1};
@@ -160,6 +177,8 @@ struct aqe_plan {
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
     const double* view_rounds = nullptr;  // stride-major view the rounds' families index (nullptr: the column itself)
     const double* view_topup = nullptr;   // ... and the top-up's
+    uint64_t view_step_rounds = 0, view_step_topup = 0;  // the steps of those views (0: none): the plan holds a reference on each
+    bool cached = false;                  // owned by the context's reduce cache
     unsigned grid = 0;          // workgroups of the persistent sweep for this plan (the context's, or half of it)
     SweepForm head;             // the first rounds only, on a few workgroups: the single launch of a query predicted to stop early
     volatile unsigned long long* h_seq = nullptr;  // behind h_result: the epoch of the launch whose result is there
@@ -198,6 +217,8 @@ int ensure_sorted(aqe_ctx* c);
 // The stride-major view of step `step` (built on first use): rows r = row0 + k step are contiguous in it.
 // slot(r) = (r % step) * M + (r / step - q0); M and q0 come back with the pointer.
 int ensure_stride_view(aqe_ctx* c, uint64_t step, const double** view, uint64_t* M, uint64_t* q0);
+void release_stride_view(aqe_ctx* c, uint64_t step, bool cached);  // a plan laid out over the view goes away
+int ensure_key_view(aqe_ctx* c, int column, uint64_t step, const int32_t** view);  // the key column in the view's slot order
 
 // plans.hip
 void destroy_plan(aqe_plan* p);

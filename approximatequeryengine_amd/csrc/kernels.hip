@@ -202,6 +202,61 @@ __global__ __launch_bounds__(kBlockThreads) void k_indexed(RoundLaunch a, const 
     finish_block(acc, a);
 }
 
+// The keyed bijection of AQE_M_RANDOM_DEVICE (planner.hpp, PermSpec): a row of [0, n) for ordinal k.
+__device__ __forceinline__ u64 perm_row(const PermSpec& p, u64 k) {
+    u64 x = k;
+    do {
+        x = (x + p.k0) & p.mask;
+        x = (x * kPermC1) & p.mask; x ^= x >> p.s1;
+        x = (x + p.k1) & p.mask;
+        x = (x * kPermC2) & p.mask; x ^= x >> p.s2;
+        x = (x * kPermC3) & p.mask; x ^= x >> p.s3;
+        x = (x * kPermC1) & p.mask; x ^= x >> p.s1;
+    } while (x >= p.n);  // cycle walking: the bijection of [0, 2^bits) restricted to [0, n); fewer than two turns on average
+    return x;
+}
+
+// A simple random sample without replacement drawn in the kernel: ordinal k -> row perm.lo + P(k).  No index list to
+// build, upload or read (k_indexed reads 8 bytes of index per 8 bytes of amount); a shard keeps the rows it holds.
+__global__ __launch_bounds__(kBlockThreads) void k_permuted(RoundLaunch a, PermSpec perm, u64 shard_lo, u64 shard_rows) {
+    u64 ord_limit;
+    note_start(a);
+    if (!launch_is_live(a, ord_limit)) return;
+    Acc acc;
+    constexpr u64 kChunk = static_cast<u64>(kBlockThreads) * kTileUnroll;
+    for (u64 c0 = static_cast<u64>(blockIdx.x) * kChunk; c0 < perm.target; c0 += static_cast<u64>(gridDim.x) * kChunk) {
+        u64 row[kTileUnroll];
+        bool ok[kTileUnroll];
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) {
+            const u64 i = c0 + threadIdx.x + static_cast<u64>(k) * kBlockThreads;
+            const u64 r = perm.lo + perm_row(perm, i < perm.target ? i : 0) - shard_lo;  // (wraps below the shard: fails the test)
+            ok[k] = i < perm.target && r < shard_rows;
+            row[k] = ok[k] ? r : 0;
+        }
+        double v[kTileUnroll];
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) v[k] = a.sw.amount[row[k]];
+        TileAcc ta;
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) accumulate(ta, v[k], ok[k], a.sw);
+        merge_tile(acc, ta, false);
+    }
+    finish_block(acc, a);
+}
+
+// record-returning form: out[k] = row perm.lo + P(k) (whole table in this context), in draw order
+__global__ __launch_bounds__(kBlockThreads) void k_gather_permuted(const aqe_record* __restrict__ aos, PermSpec perm, aqe_record* __restrict__ out) {
+    const uint4* src = reinterpret_cast<const uint4*>(aos);
+    uint4* dst = reinterpret_cast<uint4*>(out);
+    for (u64 i = static_cast<u64>(blockIdx.x) * kBlockThreads + threadIdx.x; i < perm.target; i += static_cast<u64>(gridDim.x) * kBlockThreads) {
+        const u64 row = perm.lo + perm_row(perm, i);
+        uint4 a = src[2 * row], b = src[2 * row + 1];
+        dst[2 * i] = a;
+        dst[2 * i + 1] = b;
+    }
+}
+
 __global__ void k_update(QueryState* s, const double* vec, FoldParams p, int reset_state) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     QueryState st;
@@ -377,6 +432,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_stride_view(const double* __r
     }
 }
 
+// ... and a key column in the same slot order (GROUP BY over a strided sample reads amounts and keys side by side)
+__global__ __launch_bounds__(kBlockThreads) void k_stride_view_keys(const int32_t* __restrict__ keys, u64 n, u64 shard_lo, u64 step, u64 M,
+                                                                    u64 q0, int32_t* __restrict__ out) {
+    for (u64 i = static_cast<u64>(blockIdx.x) * kBlockThreads + threadIdx.x; i < n; i += static_cast<u64>(gridDim.x) * kBlockThreads) {
+        const u64 r = shard_lo + i;
+        out[(r % step) * M + (r / step - q0)] = keys[i];
+    }
+}
+
 __device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 i) {
     u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -426,6 +490,19 @@ hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_
     unsigned grid = grid_for(n_idx, static_cast<u64>(kBlockThreads) * kTileUnroll);
     if (ev0) hipExtLaunchKernelGGL(k_indexed, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a, idx, static_cast<u64>(n_idx));
     else hipLaunchKernelGGL(k_indexed, dim3(grid), dim3(kBlockThreads), 0, s, a, idx, static_cast<u64>(n_idx));
+    return hipGetLastError();
+}
+
+hipError_t launch_permuted(const RoundLaunch& a, const PermSpec& perm, uint64_t shard_lo, uint64_t shard_rows, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    unsigned grid = grid_for(perm.target, static_cast<u64>(kBlockThreads) * kTileUnroll);
+    if (ev0) hipExtLaunchKernelGGL(k_permuted, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a, perm, static_cast<u64>(shard_lo), static_cast<u64>(shard_rows));
+    else hipLaunchKernelGGL(k_permuted, dim3(grid), dim3(kBlockThreads), 0, s, a, perm, static_cast<u64>(shard_lo), static_cast<u64>(shard_rows));
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_permuted(const aqe_record* aos, const PermSpec& perm, aqe_record* out, hipStream_t s) {
+    if (perm.target == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_permuted, dim3(grid_for(perm.target, kBlockThreads)), dim3(kBlockThreads), 0, s, aos, perm, out);
     return hipGetLastError();
 }
 
@@ -485,6 +562,14 @@ hipError_t launch_stride_view(const double* amount, uint64_t n, uint64_t shard_l
                               hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_stride_view, dim3(grid_for(n, kBlockThreads * 4)), dim3(kBlockThreads), 0, s, amount, static_cast<u64>(n),
+                       static_cast<u64>(shard_lo), static_cast<u64>(step), static_cast<u64>(M), static_cast<u64>(q0), out);
+    return hipGetLastError();
+}
+
+hipError_t launch_stride_view_keys(const int32_t* keys, uint64_t n, uint64_t shard_lo, uint64_t step, uint64_t M, uint64_t q0, int32_t* out,
+                                   hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stride_view_keys, dim3(grid_for(n, kBlockThreads * 4)), dim3(kBlockThreads), 0, s, keys, static_cast<u64>(n),
                        static_cast<u64>(shard_lo), static_cast<u64>(step), static_cast<u64>(M), static_cast<u64>(q0), out);
     return hipGetLastError();
 }

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "../../include/aqe_hip.h"
+#include "planner.hpp"
 
 namespace aqe {
 
@@ -210,6 +211,10 @@ hipError_t launch_replay_batch(const ReplayItem* items, uint32_t n, const double
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_indexed(const RoundLaunch& a, const uint64_t* idx, uint64_t n_idx, hipStream_t s, hipEvent_t ev0 = nullptr,
                           hipEvent_t ev1 = nullptr);
+// AQE_M_RANDOM_DEVICE: rows perm.lo + P(k), k < perm.target, drawn in the kernel (planner.hpp PermSpec)
+hipError_t launch_permuted(const RoundLaunch& a, const PermSpec& perm, uint64_t shard_lo, uint64_t shard_rows, hipStream_t s, hipEvent_t ev0 = nullptr,
+                           hipEvent_t ev1 = nullptr);
+hipError_t launch_gather_permuted(const aqe_record* aos, const PermSpec& perm, aqe_record* out, hipStream_t s);
 hipError_t launch_update(QueryState* state, const double* vec, const FoldParams& p, int reset_state, hipStream_t s);
 hipError_t launch_finalize(const QueryState* state, const FinalizeParams& p, aqe_result* out, hipStream_t s);
 
@@ -223,6 +228,8 @@ hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const
 hipError_t launch_id_bounds(const aqe_record* aos, uint64_t n, int64_t id_min, int64_t id_max, uint64_t* out, hipStream_t s);
 hipError_t launch_stride_view(const double* amount, uint64_t n, uint64_t shard_lo, uint64_t step, uint64_t M, uint64_t q0, double* out,
                               hipStream_t s);
+hipError_t launch_stride_view_keys(const int32_t* keys, uint64_t n, uint64_t shard_lo, uint64_t step, uint64_t M, uint64_t q0, int32_t* out,
+                                   hipStream_t s);
 hipError_t launch_split_amount(const aqe_record* aos, double* amount, uint64_t n, hipStream_t s);
 hipError_t launch_synth(aqe_record* aos_or_null, double* amount, uint64_t n, uint64_t first_row, uint64_t seed,
                         hipStream_t s);

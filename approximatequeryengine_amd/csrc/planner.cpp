@@ -184,6 +184,7 @@ int build_plan(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::st
     for (auto& rf : P.round_fams) for (auto& f : rf) { f.row0 += lo; if (f.flags & AQE_F_PAIR) f.row0_b += lo; }
     for (auto& f : P.topup_fams) f.row0 += lo;
     for (auto& i : P.random_idx) i += lo;
+    P.perm_lo = lo;
     return AQE_OK;
 }
 
@@ -432,6 +433,17 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
             if (rc != AQE_OK) return rc;
             int target = N ? target_of(N, pct) : 0;
             P.global_samples = target > 0 ? std::min<u64>(static_cast<u64>(target), N) : 0;
+            return AQE_OK;
+        }
+        case AQE_M_RANDOM_DEVICE: {  // sample_records' semantics (DB.cpp:345-363: a uniform prefix of a shuffle), drawn on the device
+            P.is_perm = true;
+            P.rounds = 1;
+            int target = N ? target_of(N, pct) : 0;
+            P.perm_n = N;
+            P.perm_lo = 0;
+            P.perm_target = target > 0 ? std::min<u64>(static_cast<u64>(target), N) : 0;
+            P.perm_seed = q.seed;
+            P.global_samples = P.perm_target;
             return AQE_OK;
         }
         case AQE_M_CLT_DUAL_POINTER: {  // DB.cpp:885-1043, round-synchronous

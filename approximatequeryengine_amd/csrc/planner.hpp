@@ -26,6 +26,8 @@ struct CltShape {
 
 struct HostPlan {
     bool is_random = false;   // RANDOM_POINTER: explicit index list instead of families
+    bool is_perm = false;     // RANDOM_DEVICE: rows = perm_lo + P(k), k < perm_target (PermSpec below), no list at all
+    uint64_t perm_n = 0, perm_lo = 0, perm_target = 0, perm_seed = 0;
     bool is_clt = false;
     bool has_topup = false;
     bool on_sorted = false;   // STRATIFIED_BLOCK: families index the amount-sorted table
@@ -38,6 +40,34 @@ struct HostPlan {
     uint64_t visible_rows = 0;    // M actually used
     double pct = 0.0;
 };
+
+// The keyed bijection of AQE_M_RANDOM_DEVICE on [0, n): x -> ((x + k0) C1 ^>> s1 + k1) C2 ^>> s2, C3 ^>> s3, C1 ^>> s1 on
+// `bits` = ceil(log2 n) bits (every step is a bijection of the bits-bit integers: add, multiply by an odd constant,
+// xor with a right shift), repeated while the result is >= n (cycle walking).  Host and device share this definition.
+struct PermSpec {
+    uint64_t n, lo, target, k0, k1, mask;
+    uint32_t s1, s2, s3, pad;
+};
+constexpr uint64_t kPermC1 = 0x9E3779B97F4A7C15ull, kPermC2 = 0xBF58476D1CE4E5B9ull, kPermC3 = 0x94D049BB133111EBull;
+inline uint64_t perm_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline PermSpec perm_spec(uint64_t n, uint64_t lo, uint64_t target, uint64_t seed) {
+    PermSpec p{};
+    uint32_t bits = 1;
+    while (bits < 64 && (n - 1) >> bits) ++bits;  // ceil(log2 n), at least 1
+    p.n = n; p.lo = lo; p.target = target;
+    p.k0 = perm_splitmix64(seed);
+    p.k1 = perm_splitmix64(seed ^ 0xA5A5A5A5A5A5A5A5ull);
+    p.mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+    p.s1 = bits / 2 ? bits / 2 : 1;
+    p.s2 = bits / 3 ? bits / 3 : 1;
+    p.s3 = (2 * bits) / 3 ? (2 * bits) / 3 : 1;
+    return p;
+}
 
 // Returns AQE_OK or AQE_ERR_INVALID (err gets the reason).  shard = [lo, hi) global rows.
 // zone_var: the ten zone variances ADAPTIVE_BLOCK needs (nullptr for every other method).

@@ -9,6 +9,11 @@ namespace aqe {
 void destroy_plan(aqe_plan* p) {
     if (!p) return;
     (void)hipDeviceSynchronize();  // fetch() may have returned before the plan's last launch had ended
+    if (p->ctx && p->table_epoch == p->ctx->table_epoch) {  // (a replaced table took its views with it)
+        if (p->view_step_rounds) release_stride_view(p->ctx, p->view_step_rounds, p->cached);
+        if (p->view_step_topup) release_stride_view(p->ctx, p->view_step_topup, p->cached);
+    }
+    p->view_step_rounds = p->view_step_topup = 0;
     if (p->d_fams && p->d_fams != p->d_fams_small) (void)hipFree(p->d_fams);
     if (p->d_idx) (void)hipFree(p->d_idx);
     if (p->ctx && p->d_fams_small && p->partials && p->counter && p->d_state && p->h_result && p->ev0 && p->ev1 && p->d_ctl && p->d_rehearsal &&
@@ -178,6 +183,8 @@ int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup,
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
     hipEvent_t e0 = prof ? p->lev[2 * p->lev_used] : nullptr, e1 = prof ? p->lev[2 * p->lev_used + 1] : nullptr;
     if (p->host.is_random && !topup) HIPCHK(c, launch_indexed(a, p->d_idx, p->host.random_idx.size(), s, e0, e1));
+    else if (p->host.is_perm && !topup)
+        HIPCHK(c, launch_permuted(a, perm_spec(p->host.perm_n, p->host.perm_lo, p->host.perm_target, p->host.perm_seed), c->shard_lo, c->n_local, s, e0, e1));
     else HIPCHK(c, launch_round(a, s, e0, e1));
     if (prof) p->lev_used++;
     return AQE_OK;
@@ -280,7 +287,7 @@ constexpr uint64_t kViewMaxStep = 1024;
 
 // Rewrites a list of single-segment strided families of one common step into dense families over that step's
 // stride-major view (a PAIR family becomes two: its pointers have different residues, i.e. two streams).
-int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, const double** view) {
+int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, const double** view, uint64_t* view_step) {
     uint64_t step = 0, total = 0;
     for (auto* L : lists)
         for (const aqe_family& f : *L) {
@@ -292,7 +299,9 @@ int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, co
     uint64_t M = 0, q0 = 0;
     int rc = ensure_stride_view(c, step, view, &M, &q0);
     if (rc != AQE_OK) return rc;
-    if (!*view) return AQE_OK;  // the table holds its quota of views: this step stays in place
+    if (!*view) return AQE_OK;  // the table holds its quota of views, all in use: this step stays in place
+    *view_step = step;
+    c->stride_views[step].refs++;  // released by destroy_plan
     auto slot0 = [&](uint64_t row0) { return (row0 % step) * M + row0 / step - q0; };  // wraps below the shard: the ordinal window brings it back
     for (auto* L : lists) {
         std::vector<aqe_family> out;
@@ -341,13 +350,13 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     }
     int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err, zone_var);
     if (rc != AQE_OK) return fail(c, rc, err);
-    if (!(q->flags & AQE_Q_NO_LAYOUT) && c->n_local && !p->host.is_random && !p->host.on_sorted) {
+    if (!(q->flags & AQE_Q_NO_LAYOUT) && c->n_local && !p->host.is_random && !p->host.is_perm && !p->host.on_sorted) {
         // strided pointers — a CLT query's rounds (one step) and its top-up (another), the strided samplers — read
         // stride-major views of the column: dense streams
         std::vector<std::vector<aqe_family>*> rounds;
         for (auto& rf : p->host.round_fams) rounds.push_back(&rf);
-        rc = families_to_view(c, rounds, &p->view_rounds);
-        if (rc == AQE_OK && p->host.has_topup) rc = families_to_view(c, {&p->host.topup_fams}, &p->view_topup);
+        rc = families_to_view(c, rounds, &p->view_rounds, &p->view_step_rounds);
+        if (rc == AQE_OK && p->host.has_topup) rc = families_to_view(c, {&p->host.topup_fams}, &p->view_topup, &p->view_step_topup);
         if (rc != AQE_OK) return rc;
     }
     uint64_t out_pos = 0;
@@ -361,6 +370,11 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         LaunchDesc L;
         L.samples = p->host.random_idx.size();
         p->rounds.assign(1, L);
+    }
+    if (p->host.is_perm) {  // (an empty sample keeps no launch: the query is a zero state, finalized)
+        LaunchDesc L;
+        L.samples = p->host.perm_target;  // over the whole table; a shard folds the rows it holds
+        if (p->host.perm_target) p->rounds.assign(1, L); else p->rounds.clear();
     }
     if (p->host.has_topup) {
         p->topup.fam_offset = p->h_fams.size();
@@ -408,7 +422,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         // side by side on the chip and one's hand-off tail hides behind the other's sweep — 133 k against 107 k
         // aggregates/s with 32 in flight — at the price of a longer launch when it runs alone (19.4 against 16.4 us).
         p->grid = (q->flags & AQE_Q_SHARE_GPU) ? std::max(16u, c->persist_grid / 2) : c->persist_grid;
-        const bool multi = !p->host.is_random && R >= 2 && p->grid > 0;
+        const bool multi = !p->host.is_random && !p->host.is_perm && R >= 2 && p->grid > 0;
         const bool whole = c->shard_lo == 0 && c->n_local == c->n_global;
         bool every_round_has_tiles = true;
         for (size_t r = 0; r < R; ++r) every_round_has_tiles = every_round_has_tiles && p->rounds[r].ntiles > 0;
@@ -481,11 +495,21 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
 
 int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     for (auto& kv : c->cache)
-        if (std::memcmp(&kv.first, q, sizeof(aqe_query)) == 0) { *out = kv.second; return AQE_OK; }
+        if (std::memcmp(&kv.first, q, sizeof(aqe_query)) == 0) {
+            for (uint64_t step : {kv.second->view_step_rounds, kv.second->view_step_topup}) {  // the views it reads were just used
+                auto it = step ? c->stride_views.find(step) : c->stride_views.end();
+                if (it != c->stride_views.end()) it->second.last_use = ++c->view_clock;
+            }
+            *out = kv.second;
+            return AQE_OK;
+        }
     aqe_plan* p = nullptr;
     int rc = create_plan(c, q, &p);
     if (rc != AQE_OK) return rc;
     if (c->cache.size() >= 64) { destroy_plan(c->cache.front().second); c->cache.erase(c->cache.begin()); }
+    p->cached = true;
+    for (uint64_t step : {p->view_step_rounds, p->view_step_topup})
+        if (step) c->stride_views[step].cache_refs++;
     c->cache.emplace_back(*q, p);
     *out = p;
     return AQE_OK;
@@ -826,7 +850,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
     for (size_t i = 0; i < n; ++i) {
         aqe_plan* p = b->plans[i];
         const size_t R = p->rounds.size();
-        if (p->host.is_random || R == 0 || R > static_cast<size_t>(kMaxPersistRounds))
+        if (p->host.is_random || p->host.is_perm || R == 0 || R > static_cast<size_t>(kMaxPersistRounds))
             return fail(c, AQE_ERR_UNSUPPORTED, "a plan of the batch has no single-launch form (seeded-random sampler, empty sample or more than 32 rounds)");
         bool every = true;
         for (size_t r = 0; r < R; ++r) every = every && p->rounds[r].ntiles > 0;

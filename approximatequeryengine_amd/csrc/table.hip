@@ -52,8 +52,14 @@ void free_table(aqe_ctx* c) {
         if (c->keycol[k]) (void)hipFree(c->keycol[k]);
         c->keycol[k] = nullptr;
     }
-    for (auto& kv : c->stride_views) (void)hipFree(kv.second);
+    for (auto& kv : c->stride_views) {
+        (void)hipFree(kv.second.amount);
+        for (int32_t* k : kv.second.keys)
+            if (k) (void)hipFree(k);
+    }
     c->stride_views.clear();
+    c->view_bytes = 0;
+    c->view_evictions = c->view_fallbacks = 0;
     c->synthetic = false;
     c->sorted_amount = nullptr;
     c->sorted_row = nullptr;
@@ -155,24 +161,107 @@ int ensure_sorted(aqe_ctx* c) {
 // memory system moves whole lines (at s = 5, with the fast and the slow pointer, 40 % of every line is wanted and
 // 100 % is moved).  HBM capacity is the cheap resource on this part, so the column is kept a second time in
 // stride-major order per step in use: the same rows, now contiguous — a dense stream, traffic = the sampled bytes.
+namespace {
+
+void free_view(aqe_ctx* c, StrideView& v) {
+    (void)hipFree(v.amount);
+    for (int32_t* k : v.keys)
+        if (k) (void)hipFree(k);
+    c->hbm_bytes -= v.bytes;
+    c->view_bytes -= v.bytes;
+}
+
+// Makes room for one more view: the least recently used view that no plan of the caller is laid out over goes, and
+// the reduce cache's plans that use it go with it.  False when every view is held by live plans.
+bool evict_one_view(aqe_ctx* c) {
+    auto victim = c->stride_views.end();
+    for (auto it = c->stride_views.begin(); it != c->stride_views.end(); ++it)
+        if (it->second.refs == it->second.cache_refs && (victim == c->stride_views.end() || it->second.last_use < victim->second.last_use)) victim = it;
+    if (victim == c->stride_views.end()) return false;
+    const uint64_t step = victim->first;
+    for (size_t i = 0; i < c->cache.size();) {
+        aqe_plan* p = c->cache[i].second;
+        if (p->view_step_rounds == step || p->view_step_topup == step) {
+            destroy_plan(p);  // (releases its references)
+            c->cache.erase(c->cache.begin() + static_cast<long>(i));
+        } else {
+            ++i;
+        }
+    }
+    victim = c->stride_views.find(step);
+    (void)hipDeviceSynchronize();
+    free_view(c, victim->second);
+    c->stride_views.erase(victim);
+    c->view_evictions++;
+    return true;
+}
+
+}  // namespace
+
 int ensure_stride_view(aqe_ctx* c, uint64_t step, const double** view, uint64_t* M_out, uint64_t* q0_out) {
     const uint64_t M = c->n_local / step + 2, q0 = c->shard_lo / step;
     *M_out = M;
     *q0_out = q0;
     auto it = c->stride_views.find(step);
-    if (it != c->stride_views.end()) { *view = it->second; return AQE_OK; }
+    if (it != c->stride_views.end()) {
+        it->second.last_use = ++c->view_clock;
+        *view = it->second.amount;
+        return AQE_OK;
+    }
     *view = nullptr;
-    if (c->stride_views.size() >= kMaxStrideViews) return AQE_OK;  // enough copies of the column: this step is swept in place
-    double* v = nullptr;
-    const size_t bytes = (static_cast<size_t>(step) * M + 2) * sizeof(double);  // + the spare rows the 16-byte loads park on
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&v), bytes));
-    hipError_t e = hipMemsetAsync(v, 0, bytes, c->stream);
-    if (e == hipSuccess) e = launch_stride_view(c->amount, c->n_local, c->shard_lo, step, M, q0, v, c->stream);
+    if (c->stride_views.size() >= kMaxStrideViews && !evict_one_view(c)) {
+        c->view_fallbacks++;  // every view is held by a live plan: this step is swept in place
+        return AQE_OK;
+    }
+    StrideView v;
+    v.M = M;
+    v.q0 = q0;
+    v.bytes = (static_cast<size_t>(step) * M + 2) * sizeof(double);  // + the spare rows the 16-byte loads park on
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&v.amount), v.bytes));
+    hipError_t e = hipMemsetAsync(v.amount, 0, v.bytes, c->stream);
+    if (e == hipSuccess) e = launch_stride_view(c->amount, c->n_local, c->shard_lo, step, M, q0, v.amount, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { (void)hipFree(v); return fail(c, AQE_ERR_HIP, std::string("stride-major view: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(v.amount); return fail(c, AQE_ERR_HIP, std::string("stride-major view: ") + hipGetErrorString(e)); }
+    v.last_use = ++c->view_clock;
+    c->hbm_bytes += v.bytes;
+    c->view_bytes += v.bytes;
+    *view = v.amount;
     c->stride_views[step] = v;
-    c->hbm_bytes += bytes;
-    *view = v;
+    return AQE_OK;
+}
+
+void release_stride_view(aqe_ctx* c, uint64_t step, bool cached) {
+    auto it = c->stride_views.find(step);
+    if (it == c->stride_views.end()) return;  // (the table was replaced: its views went with it)
+    if (it->second.refs) it->second.refs--;
+    if (cached && it->second.cache_refs) it->second.cache_refs--;
+}
+
+// The key column of a GROUP BY in the slot order of an existing view: the sampled rows' keys are contiguous beside
+// their amounts (12 bytes per sampled row instead of a 128-byte line of each column).
+int ensure_key_view(aqe_ctx* c, int column, uint64_t step, const int32_t** view) {
+    *view = nullptr;
+    auto it = c->stride_views.find(step);
+    if (it == c->stride_views.end()) return fail(c, AQE_ERR_INVALID, "internal: key view without its amount view");
+    StrideView& v = it->second;
+    const int k = column - 1;
+    if (!v.keys[k]) {
+        int rc = ensure_keys(c, column);
+        if (rc != AQE_OK) return rc;
+        const size_t bytes = (static_cast<size_t>(step) * v.M + 2) * sizeof(int32_t);
+        int32_t* kv = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&kv), bytes));
+        hipError_t e = hipMemsetAsync(kv, 0, bytes, c->stream);
+        if (e == hipSuccess) e = launch_stride_view_keys(c->keycol[k], c->n_local, c->shard_lo, step, v.M, v.q0, kv, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(kv); return fail(c, AQE_ERR_HIP, std::string("stride-major key view: ") + hipGetErrorString(e)); }
+        v.keys[k] = kv;
+        v.bytes += bytes;
+        c->hbm_bytes += bytes;
+        c->view_bytes += bytes;
+    }
+    v.last_use = ++c->view_clock;
+    *view = v.keys[k];
     return AQE_OK;
 }
 
@@ -508,6 +597,11 @@ int aqe_table_info_get(const aqe_ctx* c, aqe_table_info* out) {
     out->has_aos = c->aos != nullptr;
     out->device_id = c->device;
     out->hbm_bytes = c->hbm_bytes;
+    out->view_bytes = c->view_bytes;
+    out->n_views = static_cast<uint32_t>(c->stride_views.size());
+    out->view_evictions = static_cast<uint32_t>(c->view_evictions);
+    out->view_fallbacks = static_cast<uint32_t>(c->view_fallbacks);
+    out->reserved = 0;
     return AQE_OK;
 }
 

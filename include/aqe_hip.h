@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define AQE_API __attribute__((visibility("default")))
-#define AQE_ABI_VERSION 1
+#define AQE_ABI_VERSION 2
 
 typedef struct aqe_ctx aqe_ctx;   /* one GPU, one shard                              */
 typedef struct aqe_plan aqe_plan; /* a planned query: families, rounds, device state */
@@ -79,8 +79,16 @@ typedef enum aqe_method {
                                      full-table moments pre-pass on the device, cached per table)            */
     AQE_M_ROWID_MOD = 17,         /* the SQLite executor's sampler: rows with rowid % (100 / int(sample_percent)) == 0,
                                      rowid = row + 1 (executor.cpp:21-26, 36-41); sample_percent >= 100: every row */
-    AQE_M_STRATIFIED_BLOCK = 16   /* stratified_block_sample, DB.cpp:1331-1379: blocks of the amount-SORTED table (needs a
+    AQE_M_STRATIFIED_BLOCK = 16,  /* stratified_block_sample, DB.cpp:1331-1379: blocks of the amount-SORTED table (needs a
                                      device sort of the column, cached per table); num_threads = strata_count */
+    AQE_M_RANDOM_DEVICE = 18      /* a simple random sample WITHOUT replacement of int(N pct/100) rows, drawn on the device:
+                                     row = P_seed(k), k = 0 .. target-1, where P_seed is a keyed bijection of [0, N) (multiply /
+                                     xor-shift rounds on ceil(log2 N) bits, cycle-walked into [0, N)).  Counter-based: no host
+                                     index list (RANDOM_POINTER draws mt19937 + Lemire on the host, 4.7 ns per index), any grid,
+                                     any sharding, replayable from (seed, N).  It stands in for the reference's random_device-
+                                     seeded samplers (sample_records, DB.cpp:345-363: shuffle all rows, take a prefix — hence
+                                     parallel_{sum,avg,count}[_where]_sample, DB.cpp:276-343), which admit statistical parity
+                                     only; RANDOM_POINTER stays the bit-exact restatement of random_pointer_sample(seed) */
 } aqe_method;
 
 typedef enum aqe_agg { AQE_SUM = 0, AQE_AVG = 1, AQE_COUNT = 2 } aqe_agg;
@@ -174,7 +182,13 @@ typedef struct aqe_table_info {
     double shift;        /* c of the shifted moments (mean of the table's first <=1024 rows unless set) */
     int32_t has_aos;     /* 32-byte rows resident (record-returning samplers available)      */
     int32_t device_id;
-    uint64_t hbm_bytes;  /* bytes this context holds in HBM                                  */
+    uint64_t hbm_bytes;  /* bytes this context holds in HBM (table + views + key columns + sort)  */
+    uint64_t view_bytes; /* ... of which stride-major views of the column (and of key columns): one per pointer step in
+                            use, at most 8 per table; past that the least recently used view no live plan holds is evicted */
+    uint32_t n_views;
+    uint32_t view_evictions; /* views dropped to make room since the table was staged                        */
+    uint32_t view_fallbacks; /* plans that wanted a view while all 8 were held by live plans: swept in place  */
+    uint32_t reserved;
 } aqe_table_info;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -56,3 +56,45 @@ def oracle_indices(o, rows, call, cache_rows=None):
 
 def rel(a, b):
     return abs(a - b) / max(abs(a), abs(b), 1e-300)
+
+
+# ---- AQE_M_RANDOM_DEVICE: the keyed bijection of [0, N), restated in numpy from its definition in include/aqe_hip.h /
+#      csrc/planner.hpp (PermSpec).  It has no counterpart in the reference (whose random samplers are seeded from
+#      std::random_device): this restatement pins the device kernels' index set bit for bit; the statistical tests pin
+#      that the set behaves like the reference's shuffled prefix (sample_records, DB.cpp:345-363).
+_C1, _C2, _C3 = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def perm_rows(N, pct, seed):
+    """Rows (draw order) of AQE_M_RANDOM_DEVICE over a table (or row window) of N rows."""
+    target = min(int(N * pct / 100.0), N)
+    if N == 0 or target <= 0:
+        return np.zeros(0, dtype=np.uint64)
+    bits = max(1, int(N - 1).bit_length())
+    mask = np.uint64((1 << bits) - 1)
+    k0, k1 = np.uint64(_splitmix64(seed & _M64)), np.uint64(_splitmix64((seed ^ 0xA5A5A5A5A5A5A5A5) & _M64))
+    s1, s2, s3 = (np.uint64(max(1, v)) for v in (bits // 2, bits // 3, (2 * bits) // 3))
+    x = np.arange(target, dtype=np.uint64)
+    todo = np.ones(target, dtype=bool)
+    with np.errstate(over="ignore"):
+        while todo.any():
+            y = x[todo]
+            y = (y + k0) & mask
+            y = (y * np.uint64(_C1)) & mask; y ^= y >> s1
+            y = (y + k1) & mask
+            y = (y * np.uint64(_C2)) & mask; y ^= y >> s2
+            y = (y * np.uint64(_C3)) & mask; y ^= y >> s3
+            y = (y * np.uint64(_C1)) & mask; y ^= y >> s1
+            x[todo] = y
+            again = todo.copy()
+            again[todo] = y >= np.uint64(N)
+            todo = again
+    return x

@@ -134,7 +134,10 @@ def test_exact_and_cpp_reducers(db100k, golden, oracle, table):
     w = T["exact"]["where"][0]
     assert rel(db100k.sum_amount_where(*w["range"]), w["sum"]) <= 1e-12
     rows = table(100_000)
-    idx = oracle.idx_random_pointer(100_000, 1.0, 9)
+    # parallel_*_sample draw their rows on the device (AQE_M_RANDOM_DEVICE; the reference shuffles with random_device,
+    # DB.cpp:345-363): with a seed the sample is the keyed bijection's prefix, restated in tests/helpers.py
+    from helpers import perm_rows
+    idx = np.sort(perm_rows(100_000, 1.0, 9))
     m = oracle.moments_idx(rows, idx)
     assert rel(db100k.parallel_sum_sample(1.0, 4, seed=9), m.sum * 100.0) <= 1e-12        # DB.cpp:303
     assert rel(db100k.parallel_avg_sample(1.0, 4, seed=9), m.sum * 100.0 / 100_000) <= 1e-12

@@ -695,6 +695,127 @@ def test_run_to_run_bitwise_reproducible(nat, engines):
             assert (a.sum, a.sumsq, a.value, a.ci_lower, a.n) == (b.sum, b.sumsq, b.value, b.ci_lower, b.n)
 
 
+def test_device_side_seeded_sampler(nat, oracle, golden, table, engines):
+    """AQE_M_RANDOM_DEVICE: a simple random sample without replacement drawn in the kernel (keyed bijection of the rows,
+    no host index list).  Bit-exact against its numpy restatement (tests/helpers.perm_rows): the gathered rows are
+    exactly P_seed(0..target-1) in draw order, sums match the oracle's moments over those rows, WHERE and row windows
+    compose, shards partition the sample.  Statistically it must behave like the reference's own random samplers:
+    the recorded runs of parallel_sum_sample (random_device-seeded, DB.cpp:276-304) in the golden file."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    from helpers import perm_rows
+    for n in (10_000, 100_007, 1_000_000):
+        rows, eng = table(n), engines(n)
+        for pct, seed in ((1.0, 42), (7.5, 0), (100.0, 123456789), (0.001, 5)):
+            want = perm_rows(n, pct, seed)
+            q = make_query(nat.M_RANDOM_DEVICE, pct, seed=seed)
+            res = eng.reduce(q)
+            assert res.visited == len(want) == res.n
+            got = eng.gather(q)
+            assert np.array_equal((got["id"] - 1).astype(np.uint64), want)  # draw order
+            if len(want):
+                m = oracle.moments_idx(rows, np.sort(want))
+                assert rel(res.sum, m.sum) <= SUM_TOL and rel(res.sumsq, m.sumsq) <= SUM_TOL
+                assert rel(res.value, m.sum * n / m.n) <= EST_TOL
+                rw = eng.reduce(make_query(nat.M_RANDOM_DEVICE, pct, seed=seed, where=(250.0, 750.0), convention=nat.EST_CPP))
+                mw = oracle.moments_idx(rows, np.sort(want), where=(250.0, 750.0))
+                assert rw.n == mw.n and rw.visited == len(want) and (mw.n == 0 or rel(rw.sum, mw.sum) <= SUM_TOL)
+        # a row window is the table (key-range pruning)
+        lo, hi = n // 3, n // 3 + n // 2
+        r = eng.reduce(make_query(nat.M_RANDOM_DEVICE, 2.0, seed=9, rows=(lo, hi)))
+        want = perm_rows(hi - lo, 2.0, 9) + np.uint64(lo)
+        m = oracle.moments_idx(rows, np.sort(want))
+        assert r.visited == len(want) and rel(r.sum, m.sum) <= SUM_TOL
+    # shards: every shard keeps the rows it holds — the union is the single-device sample
+    n = 1_000_003
+    rows = oracle.synth(n, 42)
+    want = perm_rows(n, 1.0, 77)
+    tot_n, tot_s = 0, 0.0
+    for g, G in ((0, 3), (1, 3), (2, 3)):
+        lo, hi = (g * n) // G, ((g + 1) * n) // G
+        with Engine(0) as e:
+            e.stage_records(rows[lo:hi], shard_lo=lo, n_global=n, keep_aos=False)
+            import torch
+            vec = torch.zeros(8, dtype=torch.float64, device="cuda")
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                p = e.plan(make_query(nat.M_RANDOM_DEVICE, 1.0, seed=77))
+                assert p.rounds == 1
+                p.enqueue_round(0, vec.data_ptr(), side.cuda_stream)
+                side.synchronize()
+                v = vec.cpu().numpy()
+                p.close()
+            inside = want[(want >= lo) & (want < hi)]
+            assert int(v[0]) == len(inside) == int(v[6])
+            tot_n += int(v[0])
+            tot_s += float(v[1]) + e.info().shift * float(v[0])
+    assert tot_n == len(want) and rel(tot_s, float(np.sum(rows["amount"][want.astype(np.int64)]))) <= 1e-12
+    # statistical parity with the reference's random_device-seeded reducer (30 recorded runs, N = 1 M, pct 1)
+    d = golden["tables"]["1000000"]["distributions"]
+    exact = golden["tables"]["1000000"]["exact"]["sum_amount"]
+    ref = np.array(d["parallel_sum_pct1_T4"])
+    eng = engines(1_000_000)
+    ours = np.array([eng.reduce(make_query(nat.M_RANDOM_DEVICE, 1.0, seed=s_, convention=nat.EST_CPP)).value for s_ in range(30)])
+    sigma = 288.4 * 100 * math.sqrt(10_000)
+    assert np.all(np.abs(ours - exact) <= 4 * sigma) and np.all(np.abs(ref - exact) <= 4 * sigma)
+    assert abs(ours.mean() - exact) <= 4 * sigma / math.sqrt(30) and 0.5 * ref.std() <= ours.std() <= 2.0 * ref.std()
+
+
+def test_stride_view_lifecycle(nat, oracle, table):
+    """Stride-major views of the column (one per pointer step in use): at most 8 per table; a ninth step evicts the
+    least recently used view that only the reduce cache's plans hold; when live plans hold all eight, the new step is
+    swept in place (counted, same answer); restaging drops every view and invalidates the plans laid out over them."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 1_000_000
+    rows = table(n)
+
+    def q_of(step):
+        return make_query(nat.M_MEMORY_STRIDE, 100.0 / step + 1e-9, stride_bytes=32 * step)
+
+    def check(eng, step, res):
+        idx = oracle.idx_memory_stride(n, 100.0 / step + 1e-9, 32 * step)
+        m = oracle.moments_idx(rows, idx)
+        assert res.visited == len(idx) and res.n == m.n and rel(res.sum, m.sum) <= SUM_TOL and rel(res.sumsq, m.sumsq) <= SUM_TOL
+
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)
+        base = eng.info()
+        assert (base.n_views, base.view_bytes, base.view_evictions, base.view_fallbacks) == (0, 0, 0, 0)
+        for step in range(2, 10):  # eight steps, eight views (held by the reduce cache's plans only)
+            check(eng, step, eng.reduce(q_of(step)))
+        t = eng.info()
+        assert t.n_views == 8 and t.view_evictions == 0 and t.view_bytes >= 8 * 8 * n and t.hbm_bytes == base.hbm_bytes + t.view_bytes
+        check(eng, 2, eng.reduce(q_of(2)))  # touch step 2: step 3 is now the least recently used
+        check(eng, 10, eng.reduce(q_of(10)))  # the ninth step: one view goes
+        t = eng.info()
+        assert (t.n_views, t.view_evictions, t.view_fallbacks) == (8, 1, 0)
+        check(eng, 3, eng.reduce(q_of(3)))  # the evicted step comes back (and evicts another): same answer
+        assert eng.info().view_evictions == 2
+        # live plans hold their views: with all eight held, a new step is laid out in place
+        plans = []
+        for step in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+            p = eng.plan(q_of(step))
+            p.enqueue_all(0)
+            check(eng, step, p.fetch(0))
+            plans.append(p)
+        t = eng.info()
+        assert t.n_views == 8 and t.view_fallbacks >= 1, (t.n_views, t.view_fallbacks)
+        for p in plans[:4]:
+            p.close()
+        before = eng.info().view_evictions
+        check(eng, 13, eng.reduce(q_of(13)))  # released views can be evicted again
+        assert eng.info().view_evictions == before + 1
+        # restaging: views gone, plans over the old table refuse to run
+        eng.stage_records(rows[: n // 2], keep_aos=False)
+        t = eng.info()
+        assert (t.n_views, t.view_bytes, t.view_evictions, t.view_fallbacks) == (0, 0, 0, 0) and t.global_rows == n // 2
+        with pytest.raises(nat.AqeError):
+            plans[-1].enqueue_all(0)
+        for p in plans[4:]:
+            p.close()
+        r = eng.reduce(make_query(nat.M_MEMORY_STRIDE, 20.0))
+        assert r.visited == (n // 2) // 5 and eng.info().n_views == 1
+
+
 def test_file_staging_round_trip(nat, oracle, golden, table, tmp_path):
     """The reference's file format (DB.cpp:665-711): stage from a file, save, byte-identical."""
     from approximatequeryengine_amd.engine import Engine, make_query

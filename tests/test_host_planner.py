@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(nat):
     L = C.CDLL(str(nat.LIB))
     for n in names:
         assert hasattr(L, n), f"libaqe_hip.so does not export {n}"
-    assert L.aqe_abi_version() == 1
+    assert L.aqe_abi_version() == 2
     assert C.sizeof(nat.Query) == 144 and C.sizeof(nat.Family) == 80 and C.sizeof(nat.Result) == 120
 
 
@@ -286,3 +286,29 @@ def test_rowid_mod_sampler_is_the_sqlite_executors(nat):
             for G in (2, 3):
                 parts = [expand(nat.plan_families(q, n, (g * n) // G, ((g + 1) * n) // G)[0]) for g in range(G)]
                 assert np.array_equal(np.concatenate(parts) if parts else want, want), (n, pct, G)
+
+
+def test_device_sampler_permutation_is_a_uniform_sample_without_replacement():
+    """AQE_M_RANDOM_DEVICE's index set (numpy restatement of the keyed bijection, tests/helpers.py): every prefix is a
+    set of distinct rows, the whole domain is a permutation, the rows are spread evenly (chi-square over 20 slices and
+    over the low three bits), and the SUM estimate built on it scatters around the truth as a simple random sample
+    without replacement must — the behaviour of the reference's sample_records (DB.cpp:345-363)."""
+    import numpy as np
+    from helpers import perm_rows
+    for N in (1, 2, 3, 5, 64, 1000, 4097):
+        assert sorted(perm_rows(N, 100.0, 7).tolist()) == list(range(N))
+    for N in (100_007, 1_000_000):
+        for seed in (0, 1, 42, 2**31 - 1, 2**63 + 5):
+            r = perm_rows(N, 1.0, seed)
+            t = len(r)
+            assert t == int(N * 0.01) and len(np.unique(r)) == t and int(r.max()) < N
+            h = np.histogram(r, bins=20, range=(0, N))[0]
+            assert ((h - t / 20) ** 2 / (t / 20)).sum() < 50.0   # 19 dof: 50 is p < 1e-4
+            lb = np.bincount((r % 8).astype(int), minlength=8)
+            assert ((lb - t / 8) ** 2 / (t / 8)).sum() < 35.0      # 7 dof
+    rng = np.random.default_rng(0)
+    N, tgt = 1_000_000, 10_000
+    x = 1 + 999 * rng.random(N)
+    est = np.array([x[perm_rows(N, 1.0, s).astype(np.int64)].sum() * 100 for s in range(100)])
+    sd_theory = x.std() * 100 * np.sqrt(tgt) * np.sqrt(1 - tgt / N)
+    assert abs(est.mean() - x.sum()) < 4 * sd_theory / 10 and 0.75 * sd_theory < est.std() < 1.3 * sd_theory
