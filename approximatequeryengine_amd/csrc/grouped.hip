@@ -27,9 +27,23 @@ namespace {
 //     per-lane register bins need a masked add per bin and element (what this kernel did before: 73 us for the exact
 //     scan of 10 M rows, bound by those adds).  With a word of its own per lane and bin, an LDS add never conflicts,
 //     costs the same for every key, and the workgroup's totals are summed afterwards in thread order: bit-reproducible.
-//   * more keys (product_id: 100): bins shared by the workgroup, component-major, lanes add with ds_add_f64; the lanes
-//     of a wave instruction mostly hold different keys, so collisions are rare.
+//   * more keys (product_id: 100): bins shared by the workgroup, component-major, lanes add with ds_add_f64 — into one
+//     of up to 8 REPLICAS of the bins, picked by the lane (lane & 7), each replica an odd number of words long.  The
+//     lanes of a wave instruction hold rows 2 L or 2 L + 1 (16-byte loads): with keys that follow the row number
+//     (product_id = row % 100) that is a 16-byte stride in one copy of the bins — 8 lanes on each of 8 bank pairs,
+//     measured 34 us for the exact scan of 10 M rows, bound by the LDS — and an even spread over all banks with the
+//     replicas; lanes that hold the same key mostly add to different words.
 constexpr unsigned kPrivBins = 8;
+constexpr unsigned kMaxReplicas = 8;
+constexpr unsigned kSharedLdsBytes = 48u << 10;
+__host__ __device__ inline unsigned replica_stride(unsigned nbins) { return nbins | 1u; }  // odd: replicas start on different banks
+__host__ __device__ inline unsigned replicas_for(unsigned nbins) {
+    unsigned r = kSharedLdsBytes / (replica_stride(nbins) * 4u * 8u);
+    r = r > kMaxReplicas ? kMaxReplicas : r;
+    unsigned p = 1;
+    while (2 * p <= r) p *= 2;  // a power of two (lane & (p - 1))
+    return p;
+}
 
 template <bool kPrivate>
 struct Binner {
@@ -40,6 +54,7 @@ struct Binner {
     double* nd;     // shared mode: counts as f64 (one LDS atomic type)
     double* vd;
     unsigned nb, tid;
+    unsigned rep_off;  // shared mode: this lane's replica, as an offset into each component's array
     __device__ __forceinline__ void add(unsigned b, bool ok, bool pass, double d) const {
         if (kPrivate) {
             const unsigned i = b * kBlockThreads + tid;
@@ -52,11 +67,12 @@ struct Binner {
                 }
             }
         } else if (ok && b < nb) {
-            __hip_atomic_fetch_add(vd + b, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned i = rep_off + b;
+            __hip_atomic_fetch_add(vd + i, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (pass) {
-                __hip_atomic_fetch_add(nd + b, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(s + b, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(q + b, d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(nd + i, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s + i, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(q + i, d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -117,7 +133,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
     extern __shared__ double lds[];
     __shared__ DevFamily lds_fams[kMaxLdsFams];
     const unsigned nb = a.nbins;
-    const unsigned words = kPrivate ? nb * kBlockThreads * 3 : nb * 4;  // in doubles (private: s, q, and n + v as 2 x u32)
+    const unsigned reps = replicas_for(nb), rstride = replica_stride(nb), comp_len = reps * rstride;
+    const unsigned words = kPrivate ? nb * kBlockThreads * 3 : comp_len * 4;  // in doubles (private: s, q, and n + v as 2 x u32)
     for (unsigned i = threadIdx.x; i < words; i += kBlockThreads) lds[i] = 0.0;
     Binner<kPrivate> B;
     B.nb = nb;
@@ -129,8 +146,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
         B.v = B.n + nb * kBlockThreads;
         B.nd = B.vd = nullptr;
     } else {
-        B.nd = lds; B.s = lds + nb; B.q = lds + 2 * nb; B.vd = lds + 3 * nb;
+        B.nd = lds; B.s = lds + comp_len; B.q = lds + 2 * comp_len; B.vd = lds + 3 * comp_len;
         B.n = B.v = nullptr;
+        B.rep_off = (threadIdx.x & (reps - 1u)) * rstride;
     }
     const DevFamily* fams = stage_families(a.sw, lds_fams);
     __syncthreads();
@@ -225,21 +243,30 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
     __syncthreads();
     double* out = a.partial + static_cast<size_t>(blockIdx.x) * nb * 4;  // [nbins][4]: n, S - c n, Q, visited
     if (kPrivate) {
-        // thread (bin, component) adds the workgroup's 256 private words in thread order (four chains, fixed grouping)
-        if (threadIdx.x < nb * 4) {
-            const unsigned b = threadIdx.x >> 2, comp = threadIdx.x & 3;
-            double t4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (unsigned i = 0; i < kBlockThreads; i += 4) {
-#pragma unroll
-                for (unsigned u = 0; u < 4; ++u) {
-                    const unsigned w = b * kBlockThreads + i + u;
-                    t4[u] += comp == 0 ? static_cast<double>(B.n[w]) : comp == 1 ? B.s[w] : comp == 2 ? B.q[w] : static_cast<double>(B.v[w]);
+        // the workgroup's 256 private words per (bin, component), summed by a fixed binary tree over the threads
+        for (unsigned stride = kBlockThreads / 2; stride > 0; stride >>= 1) {
+            if (threadIdx.x < stride) {
+                for (unsigned b = 0; b < nb; ++b) {
+                    const unsigned i = b * kBlockThreads + threadIdx.x;
+                    B.s[i] += B.s[i + stride];
+                    B.q[i] += B.q[i + stride];
+                    B.n[i] += B.n[i + stride];
+                    B.v[i] += B.v[i + stride];
                 }
             }
-            out[threadIdx.x] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+            __syncthreads();
+        }
+        if (threadIdx.x < nb * 4) {
+            const unsigned b = threadIdx.x >> 2, comp = threadIdx.x & 3, w = b * kBlockThreads;
+            out[threadIdx.x] = comp == 0 ? static_cast<double>(B.n[w]) : comp == 1 ? B.s[w] : comp == 2 ? B.q[w] : static_cast<double>(B.v[w]);
         }
     } else {
-        for (unsigned i = threadIdx.x; i < nb * 4; i += kBlockThreads) out[i] = lds[(i % 4) * nb + i / 4];
+        for (unsigned i = threadIdx.x; i < nb * 4; i += kBlockThreads) {  // out: [nbins][4]; the replicas in order
+            const unsigned comp = i % 4, b = i / 4;
+            double t = 0.0;
+            for (unsigned r = 0; r < reps; ++r) t += lds[comp * comp_len + r * rstride + b];
+            out[i] = t;
+        }
     }
 }
 
@@ -338,7 +365,7 @@ hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t*
                           unsigned grid, hipStream_t s) {
     GroupLaunch a{sw, ntiles, keys, key_min, nbins, partial};
     if (nbins <= kPrivBins) hipLaunchKernelGGL(k_grouped<true>, dim3(grid), dim3(kBlockThreads), static_cast<size_t>(nbins) * kBlockThreads * 3 * sizeof(double), s, a);
-    else hipLaunchKernelGGL(k_grouped<false>, dim3(grid), dim3(kBlockThreads), static_cast<size_t>(nbins) * 4 * sizeof(double), s, a);
+    else hipLaunchKernelGGL(k_grouped<false>, dim3(grid), dim3(kBlockThreads), static_cast<size_t>(replicas_for(nbins)) * replica_stride(nbins) * 4 * sizeof(double), s, a);
     return hipGetLastError();
 }
 

@@ -331,12 +331,18 @@ __device__ __forceinline__ void leave_round(const PersistLaunch& P, KargPtr K, u
     if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 7), static_cast<unsigned long long>(P.epoch), AQE_RLX);
 }
 
+constexpr unsigned long long kGiveUpTicks = 3000000000ull;  // 30 s of the 100 MHz device clock
+
 // The monitor's whole life (wave 0 of workgroup 0; it sweeps nothing).
 __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) {
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_s_setprio(3);
     stamp_wave(P, 0, lane);
+#ifndef AQE_OLD_GIVEUP
+    if (lane == 0) lds_t0 = __builtin_amdgcn_s_memrealtime();  // (the query's device-clock timing, and the give-up bound below)
+#else
     if (K->want_ticks && lane == 0) lds_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     unsigned judged = 0, polls = 0;  // rounds [0, judged) are folded and judged
     double run = 0.0;                // this lane's running sum over every step folded so far
     // nothing can be complete yet: rehearse the fold, so that the real one finds its code in the instruction cache
@@ -349,13 +355,29 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
             const FoldOut o = monitor_fold(K, judged, complete, run, 0u);  // does not return if the query ends here
             run = o.run;
             judged = o.judged;
-        } else if (++polls > (1u << 21)) {  // cannot happen: every workgroup publishes every round it owns tiles of
-            if (lane == 0) {  // report it (aqe_result.device_status) instead of hanging
+#ifndef AQE_OLD_GIVEUP
+        } else if ((++polls & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - lds_t0 > kGiveUpTicks) {
+            // Cannot happen in a healthy launch: every workgroup publishes every round it owns tiles of.  The bound is
+            // TIME (the device's 100 MHz clock, looked at every 1024 polls), not a poll count: this launch's other
+            // workgroups may sit behind other streams' kernels for as long as those take.  Report it
+            // (aqe_result.device_status) instead of hanging, and raise should_stop so the sweepers leave as well.
+            if (lane == 0) {
+                QueryState st{};
+                st.error = 1;
+                state_store(P.state, st);
+                finalize(st, P.fin, P.result);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&P.ctl->stop_word, (P.epoch << 8) | 1ull, AQE_RLX);
+            }
+#else
+        } else if (++polls > (1u << 21)) {  // (A/B build: the round-1 bound, a poll count)
+            if (lane == 0) {
                 QueryState st{};
                 st.error = 1;
                 state_store(P.state, st);
                 finalize(st, P.fin, P.result);
             }
+#endif
             break;
         }
     }
@@ -481,7 +503,7 @@ __device__ __forceinline__ void leave_round_multi(KargPtr K, unsigned bid, unsig
 // The monitor of one group.  Its wait is bounded by the device clock, not by a poll count: groups of a large batch
 // may sit behind other groups' workgroups for as long as those take.  On give-up it also raises should_stop, so the
 // group's sweepers leave instead of finishing a query nobody will report.
-constexpr unsigned long long kMultiGiveUpTicks = 3000000000ull;  // 30 s of the 100 MHz clock
+constexpr unsigned long long kMultiGiveUpTicks = kGiveUpTicks;
 __device__ __forceinline__ void monitor_main_multi(KargPtr K, unsigned long long epoch) {
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_s_setprio(3);
