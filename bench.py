@@ -254,7 +254,40 @@ def measure_config(eng, st, name, q, reps=20, note=None):
         plan.close()
 
 
-def run_configs(eng, nat, make_query, st, max_rows):
+def measure_batch(eng, Batch, st, name, queries, reps=20):
+    """A batch of queries in ONE launch (k_sweep_multi): launch time from the dispatch's events, every result fetched."""
+    import statistics
+    plans = [eng.plan(q) for q in queries]
+    b = Batch(plans)
+    try:
+        for _ in range(3):
+            b.enqueue_all(st)
+            rs = b.fetch()
+        b.set_profiling(True)
+        ms, lat = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            b.enqueue_all(st)
+            rs = b.fetch()
+            lat.append(time.perf_counter() - t0)
+            m, swept, wgs = b.launch_info()
+            ms.append(m)
+        b.set_profiling(False)
+        us = 1e3 * statistics.median(ms)
+        nbytes = 8.0 * sum(r.visited for r in rs)
+        wall = statistics.median(lat)
+        return {"config": name, "queries_per_launch": len(queries), "samples": int(sum(r.visited for r in rs)), "kernel_us": us,
+                "kernel_us_min": 1e3 * min(ms), "workgroups": int(wgs), "algorithmic_bytes": nbytes,
+                "achieved_GBps": nbytes / (us * 1e-6) / 1e9, "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "closed_loop_us_p50": 1e6 * wall, "aggregates_per_sec_one_batch_in_flight": len(queries) / wall,
+                "value0": rs[0].value, "ci0": [rs[0].ci_lower, rs[0].ci_upper]}
+    finally:
+        b.close()
+        for p in plans:
+            p.close()
+
+
+def run_configs(eng, nat, make_query, st, max_rows, Batch=None):
     """SURVEY §8d configs 1, 3-local, 4-local, 5 + the dense scans: launch time from dispatch events, 8 B per sampled row."""
     out = []
     lib = nat.lib()
@@ -270,8 +303,18 @@ def run_configs(eng, nat, make_query, st, max_rows):
                               note="latency-bound: 100 k samples, 0.8 MB"))
     out.append(measure_config(eng, st, f"config0 {tag} random 1% seed 42 SUM (random_pointer_sample, host mt19937 index list)",
                               make_query(nat.M_RANDOM_POINTER, 1.0, seed=42), note="sparse gather: 8 B useful of every 64-B sector"))
+    out.append(measure_config(eng, st, f"config0 {tag} random 1% seed 42 SUM drawn ON THE DEVICE (AQE_M_RANDOM_DEVICE: keyed bijection, no index list)",
+                              make_query(nat.M_RANDOM_DEVICE, 1.0, seed=42), note="statistical parity with the reference's random samplers; same sparse gather"))
     out.append(measure_config(eng, st, f"{tag} block 1% B=1000 SUM", make_query(nat.M_BLOCK, 1.0)))
     out.append(measure_config(eng, st, f"{tag} exact SUM (full scan)", make_query(nat.M_EXACT, 100.0)))
+    q_inplace = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.01, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
+    q_inplace.flags |= nat.Q_NO_LAYOUT
+    out.append(measure_config(eng, st, f"{tag} CLT AVG e=0.01% swept IN PLACE (what a plan gets when all 8 stride-major views of a table are held)",
+                              q_inplace, note="rows 0 and 2 of every 5: 40 % of every line touched; the view form of the same query is the headline"))
+    if Batch is not None:  # configs[0] as a service: 32 different 1 % queries per launch
+        qs = [make_query(nat.M_MEMORY_STRIDE, 1.0, agg=(nat.SUM, nat.AVG, nat.COUNT)[i % 3], rows=(100_000 * i, n - 50_000 * i)) for i in range(16)]  # key-range windows
+        qs += [make_query(nat.M_BLOCK, 1.0, block_size=500 + 100 * i, where=(100.0 + i, 900.0 - i), convention=nat.EST_CPP) for i in range(16)]
+        out.append(measure_batch(eng, Batch, st, f"config0 {tag}: batch of 32 different 1% queries (16 strided, 16 block + WHERE) in ONE launch", qs))
     for rows in (100_000_000, 1_000_000_000):
         if rows > max_rows:
             continue
@@ -598,7 +641,7 @@ def main():
         if extras and not use_dist:
             if not args.no_configs:
                 try:
-                    line["configs"] = run_configs(eng, nat, make_query, st, args.max_config_rows)
+                    line["configs"] = run_configs(eng, nat, make_query, st, args.max_config_rows, Batch)
                 except Exception as ex:
                     line["configs"] = [{"error": repr(ex)}]
             try:
