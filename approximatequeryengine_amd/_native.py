@@ -124,6 +124,9 @@ def lib() -> C.CDLL:
         "aqe_table_info_get": (C.c_int, [vp, P(TableInfo)]),
         "aqe_key_range_rows": (C.c_int, [vp, C.c_int64, C.c_int64, P(u64), P(u64)]),
         "aqe_release_table": (C.c_int, [vp]),
+        "aqe_device_malloc": (C.c_int, [vp, C.c_size_t, P(vp)]),
+        "aqe_device_free": (C.c_int, [vp, vp]),
+        "aqe_device_read": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
         "aqe_query_defaults": (None, [P(Query)]),
         "aqe_plan_families": (C.c_int, [P(Query), u64, u64, u64, u32, P(Family), u32, P(u32), P(u32), P(u64)]),
         "aqe_plan_random_indices": (C.c_int, [u64, dbl, u32, u64, u64, P(u64), u64, P(u64)]),

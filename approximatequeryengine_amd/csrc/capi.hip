@@ -25,6 +25,31 @@ const char* aqe_status_string(int s) {
 
 const char* aqe_last_error(const aqe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// ---- device scratch for hosts without a HIP runtime of their own -----------------------------------
+int aqe_device_malloc(aqe_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(out, bytes ? bytes : 8));
+    HIPCHK(c, hipMemset(*out, 0, bytes ? bytes : 8));
+    return AQE_OK;
+}
+
+int aqe_device_free(aqe_ctx* c, void* p) {
+    if (!c) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (p) HIPCHK(c, hipFree(p));
+    return AQE_OK;
+}
+
+int aqe_device_read(aqe_ctx* c, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!c || !dst || !src) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return AQE_OK;
+}
+
 // ---- host planning ------------------------------------------------------------------------------
 void aqe_query_defaults(aqe_query* q) {
     if (!q) return;

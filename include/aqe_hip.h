@@ -227,6 +227,12 @@ AQE_API int aqe_table_info_get(const aqe_ctx* ctx, aqe_table_info* out);
 AQE_API int aqe_key_range_rows(aqe_ctx* ctx, int64_t id_min, int64_t id_max, uint64_t* row_lo, uint64_t* row_hi);
 AQE_API int aqe_release_table(aqe_ctx* ctx);
 
+/* Device scratch for hosts that do not link the HIP runtime themselves (the moment vectors and total buffers of the
+ * multi-GPU entry points live in device memory): plain hipMalloc / hipFree / a synchronous copy to the host. */
+AQE_API int aqe_device_malloc(aqe_ctx* ctx, size_t bytes, void** out);
+AQE_API int aqe_device_free(aqe_ctx* ctx, void* dev_ptr);
+AQE_API int aqe_device_read(aqe_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, void* stream);
+
 /* ---- host-side planning (no GPU needed) ------------------------------------------------------ */
 AQE_API void aqe_query_defaults(aqe_query* q); /* reference defaults of BIND:56-101 */
 /* Families of `q` over a table of n_global rows, clipped to rows [shard_lo, shard_hi).  For the CLT

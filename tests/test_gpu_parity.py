@@ -1233,6 +1233,21 @@ def test_rccl_communicator_behind_the_c_abi(nat, oracle, table):
         c2.close()
 
 
+def test_plain_c_host_program(nat, tmp_path):
+    """a plain-C host (gcc, no HIP headers, no Python in the data path) drives the C ABI — aqe_reduce, a
+    batch of queries in ONE launch, and the sharded path through the library's own RCCL communicator."""
+    import os, subprocess
+    from approximatequeryengine_amd.build import LIB, ROOT
+    exe = tmp_path / "host_demo"
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-std=c99", "-I", str(ROOT / "include"), str(ROOT / "tests" / "c_host" / "host_demo.c"),
+                           "-o", str(exe), "-L", str(LIB.parent), "-laqe_hip", f"-Wl,-rpath,{LIB.parent}", "-lm"])
+    env = dict(os.environ)  # (a process without torch: the system's HIP runtime and RCCL, one consistent pair)
+    env["LD_LIBRARY_PATH"] = os.pathsep.join(["/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    out = subprocess.run([str(exe), "1000000"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host_demo ok" in out.stdout
+
+
 def test_group_by_with_per_group_interval(nat, oracle, table):
     """GROUP BY region / product_id (executor.cpp:202-321): per-group (n, S, Q) against what SQLite returned for the
     reference's statements (tests/golden/groupby_sqlite.json), estimate and interval against the oracle's
