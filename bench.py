@@ -315,6 +315,12 @@ def run_configs(eng, nat, make_query, st, max_rows, Batch=None):
         qs = [make_query(nat.M_MEMORY_STRIDE, 1.0, agg=(nat.SUM, nat.AVG, nat.COUNT)[i % 3], rows=(100_000 * i, n - 50_000 * i)) for i in range(16)]  # key-range windows
         qs += [make_query(nat.M_BLOCK, 1.0, block_size=500 + 100 * i, where=(100.0 + i, 900.0 - i), convention=nat.EST_CPP) for i in range(16)]
         out.append(measure_batch(eng, Batch, st, f"config0 {tag}: batch of 32 different 1% queries (16 strided, 16 block + WHERE) in ONE launch", qs))
+    if Batch is not None and max_rows >= 320_000_000:
+        # k_sweep_multi where no byte can be shared between the queries of a batch and nothing fits a cache: 32 exact
+        # SUMs over DISJOINT 10 M-row key ranges (id BETWEEN ...) of a 320 M-row table = 2.56 GB per launch from HBM
+        eng.generate_synthetic(320_000_000)
+        qs = [make_query(nat.M_EXACT, 100.0, agg=(nat.SUM, nat.AVG)[i % 2], rows=(10_000_000 * i, 10_000_000 * (i + 1))) for i in range(32)]
+        out.append(measure_batch(eng, Batch, st, "320M-row table: batch of 32 exact SUM/AVG over DISJOINT 10M-row key ranges in ONE launch (no shared bytes, HBM proper)", qs, reps=10))
     for rows in (100_000_000, 1_000_000_000):
         if rows > max_rows:
             continue
@@ -626,14 +632,20 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "k_sweep_multi", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
+                "algorithmic_over_traffic": (bytes_per_launch / traffic) if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms, "min_launch_us": 1e3 * ms_min,
                 "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps,
                 "note": "8 B per sampled row (SoA f64 amount column) x the rows all queries of the batch sweep / mean duration of the ONE "
                         "launch that serves the batch; the duration is the dispatch's own begin/end timestamps (HIP events attached to "
                         "the launch, hipExtLaunchKernelGGL, on the launch stream) - the clock rocprofv3 reports "
-                        "(profiles/round2_bench_kernel_stats.csv).  A 10 M-row column and its stride-major views (80 MB each) stay in "
-                        "the 256 MiB Infinity Cache between queries and the groups of a batch walk the same views side by side, so this "
-                        "is cache-assisted bandwidth priced against the HBM peak; the 100 M- and 1 B-row lines under `configs` are HBM proper",
+                        "(profiles/round2_bench_kernel_stats.csv).  READ WITH `traffic`: every query executes all of its own loads "
+                        "(algorithmic bytes = what the load instructions ask for), but the reference's samplers are deterministic in "
+                        "(N, pct) - every `--e 0.01` query samples the SAME rows - so the groups of a batch walk the same stride-major "
+                        "views side by side and most of their loads hit in L2: the fabric moves about a fifth of the algorithmic bytes "
+                        "(PMC), and a 10 M-row column with its views (80 MB each) sits in the 256 MiB Infinity Cache anyway.  This is "
+                        "cache-assisted bandwidth priced against the HBM peak.  HBM proper: `configs` has the same kernel on a batch "
+                        "whose queries share no byte (32 disjoint 10 M-row key ranges of a 320 M-row table) and the 100 M / 1 B-row lines",
             },
             "single_query": single,
             "early_termination_reading": other,

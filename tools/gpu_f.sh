@@ -17,7 +17,9 @@ echo "--- PMC FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/pmc_probe.py > /dev/null 2> $O/pmc_fetch.err || { tail -5 $O/pmc_fetch.err; exit 1; }
 echo "--- PMC WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/pmc_probe.py > /dev/null 2> $O/pmc_write.err || { tail -5 $O/pmc_write.err; exit 1; }
-python tools/pmc_summarize.py $O/pmc_fetch $O/pmc_write $O/round2_pmc_raw.json 32
+echo "--- PMC FETCH_SIZE, disjoint batch on 320 M rows"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_disjoint -o d -- python3 tools/pmc_probe_disjoint.py > /dev/null 2> $O/pmc_disjoint.err || { tail -5 $O/pmc_disjoint.err; exit 1; }
+python tools/pmc_summarize.py $O/pmc_fetch $O/pmc_write $O/round2_pmc_raw.json 32 $O/pmc_disjoint
 # keep what travels back small: traces of the bench only
-rm -f $O/configs/c_kernel_trace.csv $O/pmc_fetch/f_kernel_trace.csv $O/pmc_write/w_kernel_trace.csv
+rm -f $O/configs/c_kernel_trace.csv $O/pmc_fetch/f_kernel_trace.csv $O/pmc_write/w_kernel_trace.csv $O/pmc_disjoint/d_kernel_trace.csv
 du -sh $O

@@ -16,7 +16,7 @@ def medians(d):
     out = {}
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            m = re.search(r"::(k_\w+)\(", r["Kernel_Name"])
+            m = re.search(r"::(k_\w+(?:<[^>]*>)?)\(", r["Kernel_Name"])
             if not m:
                 continue
             out.setdefault((r["Counter_Name"], f'{m.group(1)} grid_threads={r["Grid_Size"]}'), []).append(float(r["Counter_Value"]))
@@ -44,6 +44,16 @@ def traffic(prefix):
 doc["k_sweep_multi_traffic_bytes_per_launch"] = traffic("k_sweep_multi")
 doc["k_sweep_persist_traffic_bytes_per_launch"] = traffic("k_sweep_persist")
 doc["k_indexed_traffic_bytes_per_launch"] = traffic("k_indexed")
-doc["k_grouped_traffic_bytes_per_launch (largest grouped sweep: the exact scan)"] = traffic("k_grouped")
+# grouped sweeps (tools/pmc_probe.py runs, per key column, the reference's 10 % rowid sample — 1 M sampled rows, 12 B each: amount + key —
+# and the exact scan — 10 M rows): per template instance, the smaller median is the sample, the larger the scan
+for inst in ("k_grouped<true>", "k_grouped<false>"):
+    ks = sorted((k for k in F if k.startswith(inst + " ")), key=lambda k: F[k]["median_KB"])
+    for k in ks:
+        doc.setdefault("k_grouped_traffic_bytes_per_launch", {})[k] = F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
+if len(sys.argv) > 5:  # a third pass: the batch of 32 exact scans over disjoint key ranges of a 320 M-row table (tools/pmc_probe_disjoint.py)
+    D = medians(sys.argv[5])["FETCH_SIZE"]
+    k = max((k for k in D if k.startswith("k_sweep_multi ")), key=lambda k: D[k]["median_KB"])
+    doc["k_sweep_multi_disjoint_320M"] = {"kernel": k, "launches": D[k]["launches"], "fetch_raw_KB": D[k]["median_KB"],
+                                          "traffic_bytes_per_launch": D[k]["median_KB"] * 1024.0 * corr, "algorithmic_bytes_per_launch": 8.0 * 320_000_000}
 json.dump(doc, open(dst, "w"), indent=1)
 print(json.dumps({k: v for k, v in doc.items() if not isinstance(v, dict) or k == "calibration"}, indent=1))
