@@ -183,18 +183,25 @@ class PipelinedBatches:
         self._k = 0
         self._pending = None
 
-    def enqueue(self) -> None:
+    def enqueue(self):
+        """One step.  Returns the batch whose collective and replays were just enqueued (its results may be fetched
+        now: the fetch waits for them while the next batch's sweeps run), or None on the first step."""
         cur = self.batches[self._k % len(self.batches)]
         self._k += 1
         cur.enqueue_sweeps()
-        if self._pending is not None:
-            self._pending.finish()
+        done = self._pending
+        if done is not None:
+            done.finish()
         self._pending = cur
+        return done
 
-    def flush(self) -> None:
-        if self._pending is not None:
-            self._pending.finish()
+    def flush(self):
+        """Finishes the step still in flight; returns its batch (or None)."""
+        done = self._pending
+        if done is not None:
+            done.finish()
             self._pending = None
+        return done
 
     def fetch(self):
         self.flush()

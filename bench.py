@@ -439,13 +439,18 @@ def main():
                 sbs.append(ShardedBatch(ps, buf, torch_all_reduce(), stream=st, batch=nb))
             pipe = PipelinedBatches(sbs)
             collectives_per_step = 1
-            k_state = {"k": 0}
+            k_state = {"k": 0, "results": None}
 
-            def step():           # sweeps of one batch; collective + replays of the previous one
-                pipe.enqueue()
+            def step():           # sweeps of one batch; collective + replays of the previous one, whose results are then read
+                done = pipe.enqueue()
+                if done is not None:
+                    k_state["results"] = done.fetch()
 
             def drain():
-                return pipe.fetch()
+                done = pipe.flush()
+                if done is not None:
+                    k_state["results"] = done.fetch()
+                return k_state["results"]
 
             def one():            # one batch, start to end (profiling / latency)
                 sbs[0].enqueue()
@@ -570,6 +575,34 @@ def main():
                 for p in ps:
                     p.close()
 
+        # ---- open loop by batch size (Q in {1, 16, 256}): one launch per batch, results fetched, one batch in flight ----
+        open_loop = None
+        if not use_dist and extras:
+            import statistics
+            open_loop = []
+            for Qn in (1, 16, 256):
+                qs_ = headline_queries(nat, make_query, Qn, 1, e)
+                ps_ = [eng.plan(q) for q in qs_]
+                b_ = Batch(ps_)
+                for _ in range(3):
+                    b_.enqueue_all(st)
+                    b_.fetch()
+                b_.set_profiling(True)
+                ms_, lat_ = [], []
+                for _ in range(30):
+                    t1 = time.perf_counter()
+                    b_.enqueue_all(st)
+                    b_.fetch()
+                    lat_.append(time.perf_counter() - t1)
+                    ms_.append(b_.launch_info()[0])
+                b_.set_profiling(False)
+                med = statistics.median(lat_)
+                open_loop.append({"queries_per_launch": Qn, "launch_us_median": 1e3 * statistics.median(ms_), "closed_loop_us_median": 1e6 * med,
+                                  "aggregates_per_sec": Qn / med, "workgroups": int(b_.launch_info(False)[2])})
+                b_.close()
+                for p_ in ps_:
+                    p_.close()
+
         # ---- the timed region: K steps, every result fetched ----
         for _ in range(max(args.warmup, 1)):
             step()
@@ -648,6 +681,7 @@ def main():
                         "whose queries share no byte (32 disjoint 10 M-row key ranges of a 320 M-row table) and the 100 M / 1 B-row lines",
             },
             "single_query": single,
+            "open_loop_by_batch_size": open_loop,
             "early_termination_reading": other,
         }
         if extras and not use_dist:

@@ -228,6 +228,15 @@ def test_cli_end_to_end(tmp_path, oracle, table):
     val = float(out.getvalue().split("value:")[1].split()[0].replace(",", ""))
     assert abs(val - exact) < 1e-3
     assert p.stat().st_size == 24 + 32 * 100_000  # the CLI never rewrites the database
+    # scalar queries honour WHERE amount ... (the reference CLI drops it); the CLT sampler has no WHERE form and says so
+    out = io.StringIO()
+    cli.run(cli.build_parser().parse_args(["SELECT SUM(amount) FROM sales WHERE amount BETWEEN 250 AND 750", "--db", str(p)]), out)
+    val = float(out.getvalue().split("value:")[1].split()[0].replace(",", ""))
+    a = rows["amount"]
+    assert abs(val - math.fsum(a[(a >= 250.0) & (a <= 750.0)])) < 1e-3
+    out = io.StringIO()
+    assert cli.run(cli.build_parser().parse_args(["SELECT AVG(amount) FROM sales WHERE amount > 500", "--db", str(p), "--e", "2"]), out) == 0
+    assert "WHERE clause is ignored" in out.getvalue()
 
 
 @pytest.mark.gpu

@@ -1155,6 +1155,21 @@ def test_batch_in_one_launch_matches_single_plans_and_oracle(nat, oracle, table)
                 for ps in plan_sets:
                     for p in ps:
                         p.close()
+        # more queries than compute units: groups of one workgroup each (15 sweeper waves + the monitor), a grid the chip
+        # cannot hold at once — later groups wait for earlier ones to leave, every monitor outlasts the wait
+        many = [qs[i % len(qs)] for i in range(300)]
+        plans = [eng.plan(q) for q in many]
+        big = Batch(plans)
+        for _ in range(2):
+            big.enqueue_all(side.cuda_stream)
+            for i, r in enumerate(big.fetch()):
+                w = want[i % len(qs)]
+                assert (r.n, r.visited, r.converged, r.rounds, r.topup, r.topup_pending, r.device_status) == (w.n, w.visited, w.converged, w.rounds, w.topup, 0, 0), i
+                assert rel(r.sum, w.sum) <= 1e-13 and rel(r.ci_lower, w.ci_lower) <= 1e-12
+        assert big.launch_info(False)[2] >= 300
+        big.close()
+        for p in plans:
+            p.close()
         # a seeded-random plan has no single-launch form
         pr = eng.plan(make_query(nat.M_RANDOM_POINTER, 1.0, seed=7))
         br = Batch([pr])
