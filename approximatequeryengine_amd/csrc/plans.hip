@@ -892,7 +892,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
     }
     m.forms.resize(n);
     std::vector<PersistLaunch> table(n);
-    std::vector<unsigned long long> wgmap;
+    std::vector<unsigned long long> wgmap, monitors;
     m.samples = 0;
     for (size_t i = 0; i < n; ++i) {
         aqe_plan* p = b->plans[i];
@@ -917,10 +917,16 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
         fill_form(p, F, kind == 1, kind == 1 ? dev_totals + i * row_stride : nullptr, 0, false, table[i]);
         table[i].stamps = nullptr;  // (the stamp layout is per launch grid: single launches only)
         table[i].want_ticks = 0;
-        for (uint32_t k = 0; k < g; ++k)
+        // Workgroup order: every group's sweeper-only workgroups first, the monitors' workgroups (index 0 of each group)
+        // last.  Sweepers never wait for anybody; a monitor waits for its group's sweepers only — dispatched in this
+        // order, a workgroup that waits never holds a compute unit that something it waits for still needs, however
+        // many launches are in flight and however the grid compares with the chip.
+        for (uint32_t k = 1; k < g; ++k)
             wgmap.push_back((static_cast<unsigned long long>(i) << 32) | (static_cast<unsigned long long>(g) << 16) | k);
+        monitors.push_back((static_cast<unsigned long long>(i) << 32) | (static_cast<unsigned long long>(g) << 16));
         m.samples += F.samples;
     }
+    wgmap.insert(wgmap.end(), monitors.begin(), monitors.end());
     m.grid = static_cast<unsigned>(wgmap.size());
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_table), n * sizeof(PersistLaunch)));
     HIPCHK(c, hipMemcpy(m.d_table, table.data(), n * sizeof(PersistLaunch), hipMemcpyHostToDevice));
