@@ -434,9 +434,17 @@ def main():
             if not width:
                 raise SystemExit("the bench query has no batched (totals) form on this shard")
             sbs = []
+            # the collective: torch.distributed's RCCL by default; AQE_BENCH_NATIVE_COMM=1 takes the library's own
+            # communicator (aqe_comm_*, what a C++ host uses) — its id travels through the torch group once
+            native_comm = None
+            if os.environ.get("AQE_BENCH_NATIVE_COMM") == "1" and not rehearsal:
+                from approximatequeryengine_amd.distributed import comm_from_torch_group, native_all_reduce
+                native_comm = comm_from_torch_group(eng)
+                collective = {"backend": "aqe_comm (librccl, dlopen)", "ranks": native_comm.nranks}
             for ps, nb in zip(plan_sets, natives):
                 buf = torch.zeros(B, width, dtype=torch.float64, device="cuda")
-                sbs.append(ShardedBatch(ps, buf, torch_all_reduce(), stream=st, batch=nb))
+                ar = native_all_reduce(native_comm, st) if native_comm is not None else torch_all_reduce()
+                sbs.append(ShardedBatch(ps, buf, ar, stream=st, batch=nb))
             pipe = PipelinedBatches(sbs)
             collectives_per_step = 1
             k_state = {"k": 0, "results": None}

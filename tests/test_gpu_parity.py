@@ -852,6 +852,38 @@ def test_file_staging_round_trip(nat, oracle, golden, table, tmp_path):
                 eng.stage_file(bad, shard_lo=0, n_local=1, keep_aos=True)
 
 
+def test_file_staging_several_pinned_chunks(nat, oracle, tmp_path):
+    """Config 3's staging path at a size that needs several pinned bounce buffers (2 Mi rows = 64 MiB each): a 5 M-row
+    file in the reference's format, mmap -> pinned double buffers -> HBM, whole and as the middle shard of three; the
+    exact SUM, a strided sample and the rows themselves against the host copy."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 5_000_000
+    rows = oracle.synth(n, 7)
+    p = tmp_path / "big.db"
+    assert oracle.file_write(p, rows) == 0
+    with Engine(0) as eng:
+        eng.stage_file(p, keep_aos=True)
+        assert eng.info().global_rows == n and eng.info().has_aos == 1
+        r = eng.reduce(make_query(nat.M_EXACT, 100.0))
+        assert r.n == n and rel(r.value, math.fsum(rows["amount"])) <= SUM_TOL
+        got = eng.gather(make_query(nat.M_MEMORY_STRIDE, 1.0))
+        assert got.tobytes() == rows[::100][: len(got)].tobytes() and len(got) == n // 100
+        lo, hi = n // 3, 2 * n // 3
+        eng.stage_file(p, shard_lo=lo, n_local=hi - lo, keep_aos=False)  # amounts only: a quarter of the bytes cross PCIe
+        t = eng.info()
+        assert (t.global_rows, t.shard_lo, t.local_rows, t.has_aos) == (n, lo, hi - lo, 0)
+        import torch
+        vec = torch.zeros(8, dtype=torch.float64, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            pl = eng.plan(make_query(nat.M_EXACT, 100.0))
+            pl.enqueue_round(0, vec.data_ptr(), side.cuda_stream)
+            side.synchronize()
+            v = vec.cpu().numpy()
+            pl.close()
+        assert int(v[0]) == hi - lo and rel(float(v[1]) + t.shift * float(v[0]), math.fsum(rows["amount"][lo:hi])) <= SUM_TOL
+
+
 def test_synthetic_generator_matches_oracle(nat, oracle):
     from approximatequeryengine_amd.engine import Engine, make_query
     n = 300_001
