@@ -467,7 +467,9 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
 // PersistLaunch in device memory, written once when the batch is made), its own partial list, its own monitor wave
 // (wave 0 of the group's first workgroup), its own should_stop word — and the start and the tails of all Q queries
 // are paid once, side by side.  Only the launch epoch changes from launch to launch: it travels as an argument.
-// A workgroup finds its place through wg_map[blockIdx.x] = query << 32 | group size << 16 | index in the group.
+// A workgroup finds its place through wg_map[blockIdx.x] = query << 32 | group size << 16 | index in the group; the host
+// lists every group's sweeper-only workgroups first and the monitors' workgroups (index 0) last, so a workgroup that
+// waits is never dispatched ahead of one it waits for (plans.hip, build_multi).
 __device__ __forceinline__ void leave_round_multi(KargPtr K, unsigned bid, unsigned G, unsigned long long epoch, unsigned r, const Acc& acc, int lane,
                                                   unsigned wave, double (*lds_part)[kPersistWaves][kVec], unsigned* lds_cnt) {
     const double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,

@@ -515,6 +515,34 @@ def main():
         bytes_per_launch = 8.0 * swept
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
 
+        # ---- the same batch with each group's workgroups contiguous (AQE_MULTI_LAYOUT=xcd: workgroup k of every group on
+        #      compute die k mod 8, so queries that sample the same rows share that die's L2) — reported, not the default ----
+        xcd = None
+        if not use_dist and extras:
+            os.environ["AQE_MULTI_LAYOUT"] = "xcd"
+            try:
+                ps_x = [eng.plan(q) for q in batch_queries(e)]
+                bx = Batch(ps_x)
+                for _ in range(5):
+                    bx.enqueue_all(st)
+                    bx.fetch()
+                bx.set_profiling(True)
+                acc_x = []
+                for _ in range(30):
+                    bx.enqueue_all(st)
+                    bx.fetch()
+                    acc_x.append(bx.launch_info()[0])
+                bx.set_profiling(False)
+                x_ms = sum(acc_x) / len(acc_x)
+                xcd = {"avg_launch_us": 1e3 * x_ms, "achieved_GBps": bytes_per_launch / (x_ms * 1e-3) / 1e9,
+                       "note": "every group's workgroups contiguous: the groups read the same rows out of each die's L2 together "
+                               "(PMC: 205 MB of fabric traffic per launch against 898 MB in the default layout)"}
+                bx.close()
+                for p_ in ps_x:
+                    p_.close()
+            finally:
+                del os.environ["AQE_MULTI_LAYOUT"]
+
         # ---- a single query on the whole chip (k_sweep_persist), one in flight: launch time and closed loop ----
         single = None
         if not use_dist:
@@ -676,17 +704,17 @@ def main():
                 "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
                 "algorithmic_over_traffic": (bytes_per_launch / traffic) if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms, "min_launch_us": 1e3 * ms_min,
-                "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps,
+                "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps, "xcd_aligned_layout": xcd,
                 "note": "8 B per sampled row (SoA f64 amount column) x the rows all queries of the batch sweep / mean duration of the ONE "
                         "launch that serves the batch; the duration is the dispatch's own begin/end timestamps (HIP events attached to "
                         "the launch, hipExtLaunchKernelGGL, on the launch stream) - the clock rocprofv3 reports "
-                        "(profiles/round2_bench_kernel_stats.csv).  READ WITH `traffic`: every query executes all of its own loads "
-                        "(algorithmic bytes = what the load instructions ask for), but the reference's samplers are deterministic in "
-                        "(N, pct) - every `--e 0.01` query samples the SAME rows - so the groups of a batch walk the same stride-major "
-                        "views side by side and most of their loads hit in L2: the fabric moves about a fifth of the algorithmic bytes "
-                        "(PMC), and a 10 M-row column with its views (80 MB each) sits in the 256 MiB Infinity Cache anyway.  This is "
-                        "cache-assisted bandwidth priced against the HBM peak.  HBM proper: `configs` has the same kernel on a batch "
-                        "whose queries share no byte (32 disjoint 10 M-row key ranges of a 320 M-row table) and the 100 M / 1 B-row lines",
+                        "(profiles/round2_bench_kernel_stats.csv).  Every query executes all of its own loads and the fabric moves "
+                        "nearly all of them (`traffic`: PMC, 0.88 of the algorithmic bytes - the queries of a batch sample the same rows, "
+                        "the reference's samplers being deterministic in (N, pct), and some loads meet in L2); but a 10 M-row column "
+                        "with its stride-major views (80 MB each) stays in the 256 MiB Infinity Cache between queries, so this is "
+                        "Infinity-Cache bandwidth priced against the HBM peak.  HBM proper: `configs` has the same kernel on a batch whose "
+                        "queries share no byte (32 disjoint 10 M-row key ranges of a 320 M-row table: traffic = algorithmic) and the "
+                        "100 M / 1 B-row lines",
             },
             "single_query": single,
             "open_loop_by_batch_size": open_loop,
