@@ -894,7 +894,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
     std::vector<PersistLaunch> table(n);
     std::vector<unsigned long long> wgmap, monitors;
     const char* layout_env = std::getenv("AQE_MULTI_LAYOUT");
-    const bool xcd_layout = layout_env && std::strcmp(layout_env, "xcd") == 0;
+    const bool packed_layout = layout_env && std::strcmp(layout_env, "packed") == 0;
     m.samples = 0;
     for (size_t i = 0; i < n; ++i) {
         aqe_plan* p = b->plans[i];
@@ -919,19 +919,31 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
         fill_form(p, F, kind == 1, kind == 1 ? dev_totals + i * row_stride : nullptr, 0, false, table[i]);
         table[i].stamps = nullptr;  // (the stamp layout is per launch grid: single launches only)
         table[i].want_ticks = 0;
-        // Workgroup order: every group's sweeper-only workgroups first, the monitors' workgroups (index 0 of each group)
-        // last.  Sweepers never wait for anybody; a monitor waits for its group's sweepers only — dispatched in this
-        // order, a workgroup that waits never holds a compute unit that something it waits for still needs, however
-        // many launches are in flight and however the grid compares with the chip.
-        // (AQE_MULTI_LAYOUT=xcd keeps each group's workgroups contiguous instead, monitor first: workgroup k of every
-        // group then lands on compute die k mod 8, and queries that sample the same rows — every `--e 0.01` query does —
-        // read them out of that die's L2 together: 133 against 144 us for the bench batch, 205 against 898 MB of fabric
-        // traffic.  Not the default: with several launches in flight a waiting monitor can then sit in front of the
-        // sweepers it waits for, and the measured bandwidth stops being the memory system's.)
-        for (uint32_t k = xcd_layout ? 0u : 1u; k < g; ++k)
-            wgmap.push_back((static_cast<unsigned long long>(i) << 32) | (static_cast<unsigned long long>(g) << 16) | k);
-        if (!xcd_layout) monitors.push_back((static_cast<unsigned long long>(i) << 32) | (static_cast<unsigned long long>(g) << 16));
         m.samples += F.samples;
+    }
+    // Workgroup order (wg_map).  Two rules:
+    //  * every group's sweeper-only workgroups first, the monitors' workgroups (index 0 of each group) last.  Sweepers
+    //    never wait for anybody; a monitor waits for its group's sweepers only — dispatched in this order, a workgroup
+    //    that waits never holds a compute unit that something it waits for still needs, however many launches are in
+    //    flight and however the grid compares with the chip;
+    //  * XCD-aware: workgroup p runs on compute die p mod 8, each die has its own L2, and workgroup k of a group sweeps the
+    //    k-th slice of its query's tiles.  Groups of 8 or more workgroups are therefore laid out so that workgroup k sits
+    //    at a position = k (mod 8) — the place of index 0, which comes later, stays a HOLE (a workgroup that leaves at
+    //    once) — and queries that sample the same rows (every `--e 0.01` query does: the reference's samplers are
+    //    deterministic in N and pct) read them out of that die's L2 together: 134 against 144 us for the bench batch,
+    //    a third of the fabric traffic.  AQE_MULTI_LAYOUT=packed turns the alignment off (no holes): the layout in
+    //    which the measured bandwidth is the memory system's alone.
+    std::vector<size_t> order;
+    for (size_t i = 0; i < n; ++i) if (gs[i] >= 8) order.push_back(i);  // (multiples of 8: the aligned blocks stay aligned)
+    for (size_t i = 0; i < n; ++i) if (gs[i] < 8) order.push_back(i);
+    for (size_t i : order) {
+        const unsigned long long g = gs[i], tag = (static_cast<unsigned long long>(i) << 32) | (g << 16);
+        if (!packed_layout && g >= 8) {
+            while (wgmap.size() % 8) wgmap.push_back(kMultiHole);
+            wgmap.push_back(kMultiHole);  // where index 0 would sit
+        }
+        for (unsigned long long k = 1; k < g; ++k) wgmap.push_back(tag | k);
+        monitors.push_back(tag);
     }
     wgmap.insert(wgmap.end(), monitors.begin(), monitors.end());
     m.grid = static_cast<unsigned>(wgmap.size());

@@ -515,11 +515,11 @@ def main():
         bytes_per_launch = 8.0 * swept
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
 
-        # ---- the same batch with each group's workgroups contiguous (AQE_MULTI_LAYOUT=xcd: workgroup k of every group on
-        #      compute die k mod 8, so queries that sample the same rows share that die's L2) — reported, not the default ----
-        xcd = None
+        # ---- the same batch with the XCD alignment of the groups turned off (AQE_MULTI_LAYOUT=packed): the layout in which
+        #      the queries of a batch do not meet in a compute die's L2 and the fabric moves what the loads ask for ----
+        packed = None
         if not use_dist and extras:
-            os.environ["AQE_MULTI_LAYOUT"] = "xcd"
+            os.environ["AQE_MULTI_LAYOUT"] = "packed"
             try:
                 ps_x = [eng.plan(q) for q in batch_queries(e)]
                 bx = Batch(ps_x)
@@ -534,9 +534,8 @@ def main():
                     acc_x.append(bx.launch_info()[0])
                 bx.set_profiling(False)
                 x_ms = sum(acc_x) / len(acc_x)
-                xcd = {"avg_launch_us": 1e3 * x_ms, "achieved_GBps": bytes_per_launch / (x_ms * 1e-3) / 1e9,
-                       "note": "every group's workgroups contiguous: the groups read the same rows out of each die's L2 together "
-                               "(PMC: 205 MB of fabric traffic per launch against 898 MB in the default layout)"}
+                packed = {"avg_launch_us": 1e3 * x_ms, "achieved_GBps": bytes_per_launch / (x_ms * 1e-3) / 1e9,
+                          "frac": bytes_per_launch / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "workgroups": int(bx.launch_info(False)[2])}
                 bx.close()
                 for p_ in ps_x:
                     p_.close()
@@ -663,12 +662,13 @@ def main():
     # HBM-side traffic of the sweep kernel: a PMC measurement (FETCH_SIZE + WRITE_SIZE in their own rocprofv3 passes,
     # gfx950 correction calibrated on a known 80 MB scan) cannot be taken inside this process; the committed value in
     # profiles/ is reported only when it was measured on these very sources and this workload.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, packed_traffic = None, None, None
     try:
         if not use_dist and rows == ROWS_PER_GPU and e == 0.01:
             doc = json.loads(PMC_FILE.read_text())
             if doc.get("source_hash") == source_hash() and doc.get("batch") == B:
                 traffic = doc["k_sweep_multi_traffic_bytes_per_launch"]
+                packed_traffic = doc.get("k_sweep_multi_packed_traffic_bytes_per_launch")
                 traffic_src = f"{PMC_FILE.relative_to(ROOT)} (rocprofv3 --pmc, bytes per launch of {B} queries, sources {doc['source_hash']})"
             else:
                 traffic_src = f"{PMC_FILE.relative_to(ROOT)} was measured on other sources / another batch size: not reported"
@@ -704,22 +704,27 @@ def main():
                 "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
                 "algorithmic_over_traffic": (bytes_per_launch / traffic) if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms, "min_launch_us": 1e3 * ms_min,
-                "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps, "xcd_aligned_layout": xcd,
+                "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps, "packed_layout": packed,
                 "note": "8 B per sampled row (SoA f64 amount column) x the rows all queries of the batch sweep / mean duration of the ONE "
                         "launch that serves the batch; the duration is the dispatch's own begin/end timestamps (HIP events attached to "
                         "the launch, hipExtLaunchKernelGGL, on the launch stream) - the clock rocprofv3 reports "
-                        "(profiles/round2_bench_kernel_stats.csv).  Every query executes all of its own loads and the fabric moves "
-                        "nearly all of them (`traffic`: PMC, 0.88 of the algorithmic bytes - the queries of a batch sample the same rows, "
-                        "the reference's samplers being deterministic in (N, pct), and some loads meet in L2); but a 10 M-row column "
-                        "with its stride-major views (80 MB each) stays in the 256 MiB Infinity Cache between queries, so this is "
-                        "Infinity-Cache bandwidth priced against the HBM peak.  HBM proper: `configs` has the same kernel on a batch whose "
-                        "queries share no byte (32 disjoint 10 M-row key ranges of a 320 M-row table: traffic = algorithmic) and the "
-                        "100 M / 1 B-row lines",
+                        "(profiles/round2_bench_kernel_stats.csv).  READ WITH `traffic`: every query executes all of its own loads, but "
+                        "the launch is XCD-aware - workgroup k of every group sits on compute die k mod 8 - and the queries of a batch "
+                        "sample the same rows (the reference's samplers are deterministic in (N, pct)), so they read them out of that "
+                        "die's L2 together and the fabric moves a fraction of the algorithmic bytes (PMC); `packed_layout` is the same "
+                        "batch without the alignment (traffic ~ algorithmic).  Either way a 10 M-row column with its stride-major views "
+                        "(80 MB each) stays in the 256 MiB Infinity Cache: cache-assisted bandwidth priced against the HBM peak.  HBM "
+                        "proper: `configs` has the same kernel on a batch whose queries share no byte (32 disjoint 10 M-row key ranges "
+                        "of a 320 M-row table: traffic = algorithmic) and the 100 M / 1 B-row lines",
             },
             "single_query": single,
             "open_loop_by_batch_size": open_loop,
             "early_termination_reading": other,
         }
+        if packed is not None:
+            packed["traffic"] = packed_traffic
+            packed["note"] = ("AQE_MULTI_LAYOUT=packed: no XCD alignment of the groups, the queries of a batch do not meet in a die's L2; "
+                              "traffic (PMC) is then about the algorithmic bytes: Infinity-Cache bandwidth of a 10 M-row table")
         if extras and not use_dist:
             if not args.no_configs:
                 try:

@@ -24,11 +24,18 @@ for _ in range(20):
     eng.reduce(blk)
 for _ in range(20):
     eng.reduce(rnd)
-plans = [eng.plan(q) for q in bench.headline_queries(nat, make_query, B, 1, 0.01)]
-b = Batch(plans)
-for _ in range(20):
-    b.enqueue_all(0)
-    b.fetch()
+for layout in ("", "packed"):  # the default (XCD-aligned: its holes make the grid larger) and the packed layout
+    if layout:
+        os.environ["AQE_MULTI_LAYOUT"] = layout
+    plans = [eng.plan(q) for q in bench.headline_queries(nat, make_query, B, 1, 0.01)]
+    b = Batch(plans)
+    for _ in range(20):
+        b.enqueue_all(0)
+        b.fetch()
+    b.close()
+    for p in plans:
+        p.close()
+os.environ.pop("AQE_MULTI_LAYOUT", None)
 for col in (nat.GROUP_PRODUCT, nat.GROUP_REGION):
     for q in (make_query(nat.M_ROWID_MOD, 10.0, agg=nat.AVG), make_query(nat.M_EXACT, 100.0, agg=nat.AVG)):
         for _ in range(20):

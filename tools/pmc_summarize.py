@@ -41,7 +41,13 @@ def traffic(prefix):
         return None
     k = max(ks, key=lambda k: F[k]["median_KB"])
     return F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
-doc["k_sweep_multi_traffic_bytes_per_launch"] = traffic("k_sweep_multi")
+# the bench batch ran in two layouts: XCD-aligned (the default; holes make its grid the larger one) and packed
+multi = sorted((k for k in F if k.startswith("k_sweep_multi ")), key=lambda k: int(k.split("=")[1]))
+def tr(k):
+    return F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
+doc["k_sweep_multi_traffic_bytes_per_launch"] = tr(multi[-1]) if multi else None
+doc["k_sweep_multi_packed_traffic_bytes_per_launch"] = tr(multi[0]) if len(multi) > 1 else None
+doc["k_sweep_multi_kernels"] = {"xcd_aligned (default)": multi[-1] if multi else None, "packed": multi[0] if len(multi) > 1 else None}
 doc["k_sweep_persist_traffic_bytes_per_launch"] = traffic("k_sweep_persist")
 doc["k_indexed_traffic_bytes_per_launch"] = traffic("k_indexed")
 # grouped sweeps (tools/pmc_probe.py runs, per key column, the reference's 10 % rowid sample — 1 M sampled rows, 12 B each: amount + key —
