@@ -191,7 +191,6 @@ struct PersistLaunch {
 // ev0/ev1 (optional): events that receive the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL)
 static_assert(sizeof(PersistLaunch) <= 4096, "kernel arguments are limited to 4 KB");
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-constexpr unsigned long long kMultiHole = ~0ull;  // wg_map entry of a workgroup with nothing to do (keeps the others' positions)
 // A batch of queries in one launch: table[q] describes query q (as a launch of its own on `group size` workgroups would be
 // described; its epoch field is ignored), wg_map[b] = q << 32 | group size << 16 | index within the group for workgroup b.
 hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, hipStream_t s,

@@ -468,9 +468,8 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
 // (wave 0 of the group's first workgroup), its own should_stop word — and the start and the tails of all Q queries
 // are paid once, side by side.  Only the launch epoch changes from launch to launch: it travels as an argument.
 // A workgroup finds its place through wg_map[blockIdx.x] = query << 32 | group size << 16 | index in the group; the host
-// lists every group's sweeper-only workgroups first and the monitors' workgroups (index 0) last, so a workgroup that
-// waits is never dispatched ahead of one it waits for, and places workgroup k of a group at a position = k (mod 8): on
-// the compute die whose L2 the same slice of other queries' tiles goes through (plans.hip, build_multi).
+// keeps a group's workgroups contiguous and its blocks aligned, so that workgroup k of every group sits on compute die
+// k mod 8 — where the same slice of other queries' tiles goes through the same L2 (plans.hip, build_multi).
 __device__ __forceinline__ void leave_round_multi(KargPtr K, unsigned bid, unsigned G, unsigned long long epoch, unsigned r, const Acc& acc, int lane,
                                                   unsigned wave, double (*lds_part)[kPersistWaves][kVec], unsigned* lds_cnt) {
     const double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
@@ -547,7 +546,6 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_multi(const PersistLa
     __shared__ DevFamily lds_fams[kMaxLdsFams];
     if (threadIdx.x < kMaxPersistRounds) lds_cnt[threadIdx.x] = 0;
     const u64 me = uniform64(wg_map[blockIdx.x]);
-    if (me == kMultiHole) return;  // a place kept free so that the others sit on the compute die of their slice (plans.hip)
     const unsigned G = static_cast<unsigned>(me >> 16) & 0xffffu, bid = static_cast<unsigned>(me) & 0xffffu;
     const KargPtr K = (KargPtr)(table + (me >> 32));
     SweepCommon sw;

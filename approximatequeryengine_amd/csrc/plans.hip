@@ -921,29 +921,25 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
         table[i].want_ticks = 0;
         m.samples += F.samples;
     }
-    // Workgroup order (wg_map).  Two rules:
-    //  * every group's sweeper-only workgroups first, the monitors' workgroups (index 0 of each group) last.  Sweepers
-    //    never wait for anybody; a monitor waits for its group's sweepers only — dispatched in this order, a workgroup
-    //    that waits never holds a compute unit that something it waits for still needs, however many launches are in
-    //    flight and however the grid compares with the chip;
-    //  * XCD-aware: workgroup p runs on compute die p mod 8, each die has its own L2, and workgroup k of a group sweeps the
-    //    k-th slice of its query's tiles.  Groups of 8 or more workgroups are therefore laid out so that workgroup k sits
-    //    at a position = k (mod 8) — the place of index 0, which comes later, stays a HOLE (a workgroup that leaves at
-    //    once) — and queries that sample the same rows (every `--e 0.01` query does: the reference's samplers are
-    //    deterministic in N and pct) read them out of that die's L2 together: 134 against 144 us for the bench batch,
-    //    a third of the fabric traffic.  AQE_MULTI_LAYOUT=packed turns the alignment off (no holes): the layout in
-    //    which the measured bandwidth is the memory system's alone.
+    // Workgroup order (wg_map): XCD-aware.  Workgroup p runs on compute die p mod 8, each die has its own L2, and
+    // workgroup k of a group sweeps the k-th slice of its query's tiles.  A group's workgroups are therefore contiguous,
+    // index 0 (the monitor's) first, groups of 8 or more first of all (their blocks then start at multiples of 8):
+    // workgroup k of every such group sits on die k mod 8, and queries that sample the same rows — every `--e 0.01` query
+    // does: the reference's samplers are deterministic in N and pct — read them out of that die's L2 together (134
+    // against 144 us for the bench batch, a fifth of the fabric traffic).  Every die gets its share of every group, and
+    // dispatch is in order per die: ahead of anything a monitor waits for there are only sweepers of its own group and
+    // workgroups of earlier groups, so a waiting monitor never sits in front of what it waits for.
+    // AQE_MULTI_LAYOUT=packed lists every group's sweeper-only workgroups first and all the monitors' workgroups last
+    // instead: no alignment, the queries of a batch do not meet in a die's L2, and the measured bandwidth is the memory
+    // system's alone (the bench reports that layout beside the default).
     std::vector<size_t> order;
-    for (size_t i = 0; i < n; ++i) if (gs[i] >= 8) order.push_back(i);  // (multiples of 8: the aligned blocks stay aligned)
+    for (size_t i = 0; i < n; ++i) if (gs[i] >= 8) order.push_back(i);
     for (size_t i = 0; i < n; ++i) if (gs[i] < 8) order.push_back(i);
     for (size_t i : order) {
         const unsigned long long g = gs[i], tag = (static_cast<unsigned long long>(i) << 32) | (g << 16);
-        if (!packed_layout && g >= 8) {
-            while (wgmap.size() % 8) wgmap.push_back(kMultiHole);
-            wgmap.push_back(kMultiHole);  // where index 0 would sit
-        }
+        if (packed_layout) monitors.push_back(tag);
+        else wgmap.push_back(tag);
         for (unsigned long long k = 1; k < g; ++k) wgmap.push_back(tag | k);
-        monitors.push_back(tag);
     }
     wgmap.insert(wgmap.end(), monitors.begin(), monitors.end());
     m.grid = static_cast<unsigned>(wgmap.size());

@@ -24,7 +24,7 @@ for _ in range(20):
     eng.reduce(blk)
 for _ in range(20):
     eng.reduce(rnd)
-for layout in ("", "packed"):  # the default (XCD-aligned: its holes make the grid larger) and the packed layout
+for layout in ("", "packed"):  # the default (XCD-aligned) and the packed layout
     if layout:
         os.environ["AQE_MULTI_LAYOUT"] = layout
     plans = [eng.plan(q) for q in bench.headline_queries(nat, make_query, B, 1, 0.01)]

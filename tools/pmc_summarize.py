@@ -41,13 +41,21 @@ def traffic(prefix):
         return None
     k = max(ks, key=lambda k: F[k]["median_KB"])
     return F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
-# the bench batch ran in two layouts: XCD-aligned (the default; holes make its grid the larger one) and packed
-multi = sorted((k for k in F if k.startswith("k_sweep_multi ")), key=lambda k: int(k.split("=")[1]))
-def tr(k):
-    return F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
-doc["k_sweep_multi_traffic_bytes_per_launch"] = tr(multi[-1]) if multi else None
-doc["k_sweep_multi_packed_traffic_bytes_per_launch"] = tr(multi[0]) if len(multi) > 1 else None
-doc["k_sweep_multi_kernels"] = {"xcd_aligned (default)": multi[-1] if multi else None, "packed": multi[0] if len(multi) > 1 else None}
+# the bench batch ran in two layouts, same grid: XCD-aligned (the default, first) and packed (second) — told apart by the
+# order of the dispatches in the trace (tools/pmc_probe.py runs 20 launches of one, then 20 of the other)
+def multi_halves(d):
+    vals = []
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(path)) if "k_sweep_multi" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        vals = [float(r["Counter_Value"]) for r in rows]
+    h = len(vals) // 2
+    return (statistics.median(vals[:h]), statistics.median(vals[h:])) if h else (None, None)
+fa, fp = multi_halves(fetch_dir)
+wa, wp = multi_halves(write_dir)
+doc["k_sweep_multi_traffic_bytes_per_launch"] = fa * 1024.0 * corr + (wa or 0.0) * 1024.0 if fa else None
+doc["k_sweep_multi_packed_traffic_bytes_per_launch"] = fp * 1024.0 * corr + (wp or 0.0) * 1024.0 if fp else None
+doc["k_sweep_multi_raw_KB"] = {"xcd_aligned (default)": {"FETCH_SIZE": fa, "WRITE_SIZE": wa}, "packed": {"FETCH_SIZE": fp, "WRITE_SIZE": wp}}
 doc["k_sweep_persist_traffic_bytes_per_launch"] = traffic("k_sweep_persist")
 doc["k_indexed_traffic_bytes_per_launch"] = traffic("k_indexed")
 # grouped sweeps (tools/pmc_probe.py runs, per key column, the reference's 10 % rowid sample — 1 M sampled rows, 12 B each: amount + key —
