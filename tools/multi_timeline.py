@@ -10,7 +10,7 @@ print("# rocprofv3 --kernel-trace of `python3 bench.py --headline-only --steps 2
 print("# microseconds from the window's first dispatch.  Two batches of 32 queries alternate on two streams; each line is ONE")
 print("# launch serving 32 queries (a step enqueues one batch and fetches the previous one's 32 results): the launches follow")
 print("# one another without a gap - the step is bound by the kernel, not by the host.")
-print("#    start       end     dur  queue  grid(threads)  kernel")
+print("#    start       end     dur  queue  kernel")
 for r in rows[lo:lo + 24]:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
-    print(f'{s:10.2f} {e:9.2f} {e - s:7.2f}  q{r.get("Queue_Id", "?"):>3}  {r.get("Grid_Size", "?"):>13}  {name(r)}')
+    print(f'{s:10.2f} {e:9.2f} {e - s:7.2f}  q{r.get("Queue_Id", "?"):>3}  {name(r)}')
