@@ -359,8 +359,10 @@ AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
  * start of the launch and the decision tails of all Q queries are paid once instead of Q times.  This is what
  * replaces the reference's thread creation per call (std::async workers per query, DB.cpp:918-1029) when queries
  * arrive in batches.  A plan predicted to stop early takes its head form (first rounds + the top-up) as its group.
- * Any plan with a family sampler and 1..32 rounds qualifies (not RANDOM_POINTER); the context must hold the whole
- * table.  Results: aqe_batch_fetch (each plan's result is picked up as soon as its monitor has written it).
+ * Any plan with a family sampler and 1..32 rounds qualifies (not RANDOM_POINTER / RANDOM_DEVICE); the context must
+ * hold the whole table.  Results: aqe_batch_fetch (each plan's result is picked up as soon as its monitor has written
+ * it).  A plan has ONE state and ONE result block: it may be part of several batches, but only one execution of it —
+ * through a batch or on its own — may be in flight at a time (fetch before enqueueing it again elsewhere).
  * aqe_batch_enqueue_sweeps is the same launch with the decisions left to the replay after the all-reduce. */
 AQE_API int aqe_batch_enqueue_all(aqe_batch* batch, void* stream);
 /* Timing of the one-launch forms for roofline reports: with profiling on, the launch carries an event pair on its
