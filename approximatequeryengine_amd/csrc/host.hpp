@@ -231,6 +231,6 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
 int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
 int enqueue_all(aqe_plan* p, hipStream_t s, bool timed);
 int run_sync(aqe_plan* p, hipStream_t s, bool timed);
-int fetch(aqe_plan* p, aqe_result* out, hipStream_t s);
+int fetch(aqe_plan* p, aqe_result* out, hipStream_t s, bool already_synced = false);
 
 }  // namespace aqe

@@ -644,7 +644,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
     return AQE_OK;
 }
 
-int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
+int fetch(aqe_plan* p, aqe_result* out, hipStream_t s, bool already_synced) {
     aqe_ctx* c = p->ctx;
     // A persistent launch writes its result into pinned host memory and a check word beside it (kernels.hpp,
     // result_check): the host reads the result from there as soon as all of it has landed, instead of waiting for the
@@ -667,7 +667,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s) {
         landed = landed && snap.topup_pending == 0 && snap.device_status == 0;  // more to launch, or to report: the ordinary way
     }
     p->poll_epoch = 0;  // consumed: only aqe_plan_enqueue_all arms it
-    if (!landed) HIPCHK(c, hipStreamSynchronize(s));
+    if (!landed && !already_synced) HIPCHK(c, hipStreamSynchronize(s));
     p->want_ticks = p->timed && p->tick_timed;  // launches made from here continue the device-clock timing
     if (p->last_exec == 1 && p->h_result->topup_pending == 2) {
         // the head form ran out of rounds before the query stopped (the prediction failed): the remaining rounds go
@@ -1136,7 +1136,7 @@ int aqe_batch_enqueue_sweeps(aqe_batch* b, double* dev_totals, uint64_t row_stri
     // previous replay precedes it there (aqe_batch_enqueue_replays makes the side streams wait for it)
     int rc = launch_multi(b, 1, c->lanes[0]);
     if (rc != AQE_OK) return rc;
-    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipEventRecord(b->swept[l], c->lanes[l]));
+    HIPCHK(c, hipEventRecord(b->swept[0], c->lanes[0]));  // (one launch on one side stream: one event)
     return AQE_OK;
 }
 
@@ -1203,7 +1203,7 @@ int aqe_batch_join(aqe_batch* b, void* stream) {
     aqe_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t main_s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(main_s, b->swept[l], 0));
+    HIPCHK(c, hipStreamWaitEvent(main_s, b->swept[0], 0));
     return AQE_OK;
 }
 
@@ -1220,18 +1220,24 @@ int aqe_batch_enqueue_replays(aqe_batch* b, const double* dev_totals, uint64_t r
     // streams then wait for it before they sweep again (their plans' state, result and buffer row are read here)
     HIPCHK(c, launch_replay_batch(b->d_items, static_cast<uint32_t>(b->plans.size()), dev_totals, row_stride, main_s));
     HIPCHK(c, hipEventRecord(b->reduced, main_s));
-    for (size_t l = 0; l < kBatchLanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->lanes[l], b->reduced, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->lanes[0], b->reduced, 0));  // the side stream sweeps again only behind the replays
     return AQE_OK;
 }
 
 int aqe_batch_fetch(aqe_batch* b, aqe_result* out_n) {
     if (!b || !out_n) return AQE_ERR_INVALID;
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    // totals form: the replay ran on the caller's stream and the side streams wait for it — one synchronisation per side
+    // stream serves every plan (a synchronisation per plan was most of the host's time per step); one-launch form: each
+    // result is polled out of its pinned block, the launch's stream is the fallback
+    const bool totals = b->last_kind != 0;
+    // (the event behind this batch's replays — not the side stream: that one may already hold the NEXT batch's sweeps,
+    // and waiting for those would keep the host from enqueueing the step after)
+    if (totals) HIPCHK(b->ctx, hipEventSynchronize(b->reduced));
     for (size_t i = 0; i < b->plans.size(); ++i) {
         int rc = plan_is_current(b->plans[i]);
-        // (totals form: the replay ran on the caller's stream and the side streams wait for it; one-launch form: its stream)
-        hipStream_t s = b->last_kind == 0 ? b->last_stream : b->ctx->lanes[i % kBatchLanes];
-        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, s);
+        hipStream_t s = totals ? b->ctx->lanes[0] : b->last_stream;
+        if (rc == AQE_OK) rc = fetch(b->plans[i], out_n + i, s, totals);
         if (rc != AQE_OK) return rc;
     }
     return AQE_OK;
