@@ -334,15 +334,15 @@ AQE_API int aqe_plan_totals_len(const aqe_plan* plan, uint32_t* n_doubles);
 AQE_API int aqe_plan_enqueue_sweep_totals(aqe_plan* plan, double* dev_totals, void* stream);
 AQE_API int aqe_plan_enqueue_replay(aqe_plan* plan, const double* dev_totals, void* stream);
 /* A batch of plans of ONE context driven through the batched form together, so that one collective serves all
- * of them and the host pays a few calls per step instead of two per query.  The context owns three side streams
- * and a batch deals its plans over them: sweeps run concurrently (one query's hand-off tail overlaps the next
- * query's sweep), the caller's `stream` — where it issues the collective — is made to wait for them, and after
- * the collective one launch on `stream` replays every plan; the side streams wait for it before sweeping again.
+ * of them and the host pays a few calls per step instead of two per query.  The sweeps of the whole batch are ONE
+ * launch (a group of workgroups per plan, see aqe_batch_enqueue_all) on a side stream the context owns; the caller's
+ * `stream` — where it issues the collective — is made to wait for it, and after the collective one launch on
+ * `stream` replays every plan; the side stream waits for that before it sweeps again.
  *     aqe_batch_enqueue_sweeps(b, totals, row_stride)            row i = plan i's round totals
  *     aqe_batch_join(b, stream)                                  `stream` waits for the batch's sweeps
  *     <ONE all-reduce SUM of the whole [n, row_stride] buffer on `stream`>
  *     aqe_batch_enqueue_replays(b, totals, row_stride, stream)   one replay launch on `stream` for all plans
- *     ... next step ...   aqe_batch_fetch(b, results) synchronises and returns every plan's result
+ *     ... next step ...   aqe_batch_fetch(b, results) waits for the replays (their event) and returns every plan's result
  * Two batches (each with its own buffer) can be software-pipelined — sweeps of B, then join/collective/replays of
  * A, then sweeps of A, ... — so that one batch's collective runs under the other's sweeps.
  * (topup_pending results are finished per plan with the stepwise calls, as above). */
