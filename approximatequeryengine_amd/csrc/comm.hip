@@ -80,6 +80,7 @@ struct aqe_comm {
     aqe_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    int device = 0;  // (kept beside ctx: a communicator may be destroyed after its context)
 };
 
 extern "C" {
@@ -105,6 +106,7 @@ int aqe_comm_create(aqe_ctx* c, const void* id, int nranks, int rank, aqe_comm**
     std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     std::unique_ptr<aqe_comm> m(new aqe_comm);
     m->ctx = c;
+    m->device = c->device;
     m->nranks = nranks;
     m->rank = rank;
     RCCLCHK(c, rccl().CommInitRank(&m->comm, nranks, u, rank));
@@ -130,6 +132,7 @@ int aqe_comm_create_all(aqe_ctx* const* ctxs, int n, aqe_comm** out_n) {
     for (int i = 0; i < n; ++i) {
         aqe_comm* m = new aqe_comm;
         m->ctx = ctxs[i];
+        m->device = ctxs[i]->device;
         m->comm = comms[i];
         m->nranks = n;
         m->rank = i;
@@ -141,7 +144,7 @@ int aqe_comm_create_all(aqe_ctx* const* ctxs, int n, aqe_comm** out_n) {
 void aqe_comm_destroy(aqe_comm* m) {
     if (!m) return;
     if (m->comm && rccl().CommDestroy) {
-        (void)hipSetDevice(m->ctx->device);
+        (void)hipSetDevice(m->device);
         (void)rccl().CommDestroy(m->comm);
     }
     delete m;
