@@ -187,7 +187,7 @@ struct aqe_plan {
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
-    const SweepForm* last_form = nullptr;  // ... and the form itself (the plan's own, or a batch's group form)
+    uint32_t last_first_unswept = 0;  // ... and the first round that form (the plan's own, or a batch's group form) did NOT sweep
     size_t r_head = 0;          // rounds the head form covers (per_round plans)
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch
     bool profile = false;

@@ -561,7 +561,7 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     p->poll_epoch = totals_only ? 0 : a.epoch;
     p->last_exec = totals_only ? 2 : 1;
     p->last_grid = F.grid;
-    p->last_form = &F;
+    p->last_first_unswept = F.slots - F.topup_slot;
     if (c->d_stamps) {
         HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 8 * (8 * static_cast<size_t>(c->persist_grid) * kPersistWaves + 8 * kMaxPersistRounds), s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -672,8 +672,7 @@ int fetch(aqe_plan* p, aqe_result* out, hipStream_t s, bool already_synced) {
     if (p->last_exec == 1 && p->h_result->topup_pending == 2) {
         // the head form ran out of rounds before the query stopped (the prediction failed): the remaining rounds go
         // out one launch each, the top-up behind them — and from now on this plan takes the full single launch
-        const SweepForm& H = p->last_form ? *p->last_form : p->head;
-        for (uint32_t i = H.slots - H.topup_slot; i < p->rounds.size(); ++i) {
+        for (uint32_t i = p->last_first_unswept; i < p->rounds.size(); ++i) {
             int rc = enqueue_launch(p, p->rounds[i], i, false, true, nullptr, s);
             if (rc != AQE_OK) return rc;
         }
@@ -961,7 +960,7 @@ int launch_multi(aqe_batch* b, int kind, hipStream_t s) {
         aqe_plan* p = b->plans[i];
         p->poll_epoch = kind == 0 ? epoch : 0;
         p->last_exec = kind == 0 ? 1 : 2;
-        p->last_form = &m.forms[i];
+        p->last_first_unswept = m.forms[i].slots - m.forms[i].topup_slot;
         p->last_grid = m.forms[i].grid;
         p->lev_used = 0;
         p->timed = false;
@@ -1075,8 +1074,6 @@ void aqe_batch_destroy(aqe_batch* b) {
     }
     if (b->ctx) (void)hipDeviceSynchronize();  // fetch() may have returned before the batch's last launch had ended
     for (BatchMulti& m : b->multi) free_multi(m);
-    for (aqe_plan* p : b->plans)
-        if (p) p->last_form = nullptr;  // (pointed into this batch's forms)
     if (b->pev0) (void)hipEventDestroy(b->pev0);
     if (b->pev1) (void)hipEventDestroy(b->pev1);
     for (hipEvent_t e : b->swept) (void)hipEventDestroy(e);
