@@ -133,6 +133,33 @@ def test_golden_calls_reduce_and_gather(nat, oracle, golden, table, engines, n):
         assert got.tobytes() == rows[(got["id"] - 1)].tobytes()
 
 
+def test_golden_calls_at_one_hundred_million_rows(nat, oracle, golden):
+    """BASELINE.json configs 2 and 4 at their own size (100 M rows): the reference's C++ run on the seeded table
+    (oracle/make_golden_100m.py) against the HIP reduce on the same table generated on the device — sample counts,
+    sums, the WHERE-filtered block sample — and, through the gather kernels, the reference's exact index sets."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    T = golden["tables"]["100000000"]
+    n = T["N"]
+    with Engine(0) as eng:
+        eng.generate_synthetic(n, seed=42, keep_aos=True)  # (the generator is the oracle's, row for row: test_synthetic_generator_matches_oracle)
+        ex = eng.reduce(make_query(nat.M_EXACT, 100.0))
+        assert ex.n == n and rel(ex.value, T["exact_sum"]) <= SUM_TOL
+        for call in T["calls"]:
+            q = _query_for(nat, call)
+            res = eng.reduce(q)
+            g = call["idx"]
+            assert res.visited == g["n"], call["method"]
+            assert rel(res.sum, call["fsum"]) <= SUM_TOL and rel(res.sumsq, call["fsumsq"]) <= SUM_TOL, call["method"]
+            if "where" in call:
+                w = call["where"]
+                q.has_where, q.where_min, q.where_max = 1, w["range"][0], w["range"][1]
+                rw = eng.reduce(q)
+                assert rw.n == w["n"] and rw.visited == g["n"] and rel(rw.sum, w["fsum"]) <= SUM_TOL
+                q.has_where = 0
+            got = eng.gather(q)
+            assert digest((got["id"] - 1).astype(np.uint64)) == g, call["method"]
+
+
 @pytest.mark.parametrize("n", [10_000, 1_000_000])
 def test_seeded_random_pointer_seeds(nat, golden, table, engines, n):
     from approximatequeryengine_amd.engine import make_query

@@ -91,6 +91,17 @@ def test_ten_million_rows_scalars(oracle, golden, table):
         _check_call(oracle, rows, call, 10_000_000)
 
 
+@pytest.mark.slow
+def test_hundred_million_rows_index_sets(oracle, golden):
+    """BASELINE.json configs 2 and 4 at their own size: the oracle's index sets (digest over all 1 M sampled rows) and
+    exactly-rounded sums against the reference's C++ run on the seeded 100 M-row table (oracle/make_golden_100m.py)."""
+    T = golden["tables"]["100000000"]
+    rows = oracle.synth(100_000_000, 42)
+    assert oracle.moments_range(rows, 0, len(rows)).sum == T["exact_sum"]
+    for call in T["calls"]:
+        _check_call(oracle, rows, call, 100_000_000)
+
+
 def test_clt_fast_worker_stop_points(oracle, golden, table):
     """DB.cpp:936-961 decision function, pinned by where the reference's single fast worker stopped."""
     rows = table(1_000_000)
