@@ -51,8 +51,8 @@ PMC_FILE = ROOT / "profiles" / "round2_pmc_raw.json"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--error-percent", type=float, default=0.01, help="--e of the reference CLI, in percent")
     ap.add_argument("--batch", type=int, default=32, help="independent queries per step (one launch serves them all)")
