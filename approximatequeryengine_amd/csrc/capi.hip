@@ -248,7 +248,7 @@ int aqe_grouped_finish(aqe_ctx* c, const aqe_query* q, int32_t key_min, uint32_t
     *n_groups = 0;
     int rc = ensure_group_out(c);
     if (rc != AQE_OK) return rc;
-    HIPCHK(c, launch_grouped_finish(dev_bins, nbins, key_min, c->shift, q->sample_percent, q->agg, c->grp_out, s));
+    HIPCHK(c, launch_grouped_finish(dev_bins, nbins, key_min, query_shift(c, *q), q->sample_percent, q->agg, c->grp_out, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return collect_groups(c, nbins, out, cap, n_groups);
 }
@@ -276,7 +276,7 @@ int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_gro
     if (grid == 0) return AQE_OK;  // nothing sampled: no groups
     rc = ensure_group_out(c);
     if (rc != AQE_OK) return rc;
-    HIPCHK(c, launch_grouped_sum_finish(c->grp_partial, grid, nbins, kmin, c->shift, q->sample_percent, q->agg, c->grp_out, c->stream));
+    HIPCHK(c, launch_grouped_sum_finish(c->grp_partial, grid, nbins, kmin, query_shift(c, *q), q->sample_percent, q->agg, c->grp_out, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return collect_groups(c, nbins, out, cap, n_groups);
 }

@@ -96,7 +96,7 @@ void add_family(std::vector<DevFamily>& out, LaunchDesc& L, const aqe_family& f,
 
 FoldParams fold_params(const aqe_plan* p, bool topup) {
     FoldParams f{};
-    f.shift = p->ctx->shift;
+    f.shift = query_shift(p->ctx, p->q);
     f.z = p->host.clt.z;
     f.e = p->host.clt.e;
     f.base = p->host.clt.base;
@@ -109,7 +109,7 @@ FinalizeParams finalize_params(const aqe_plan* p) {
     FinalizeParams f{};
     f.n_global = p->q.row_hi > p->q.row_lo ? p->q.row_hi - p->q.row_lo : p->ctx->n_global;  // a row window is the table
     f.pct = p->q.sample_percent;
-    f.shift = p->ctx->shift;
+    f.shift = query_shift(p->ctx, p->q);
     f.agg = p->q.agg;
     f.convention = p->q.convention;
     f.is_exact = p->q.method == AQE_M_EXACT;
@@ -128,7 +128,7 @@ SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam
     s.has_where = p->q.has_where ? 1 : 0;
     s.wmin = p->q.where_min;
     s.wmax = p->q.where_max;
-    s.shift = c->shift;
+    s.shift = query_shift(c, p->q);
     s.dense16 = c->dense16 ? 1 : 0;
     return s;
 }

@@ -311,7 +311,8 @@ AQE_API int aqe_grouped_finish(aqe_ctx* ctx, const aqe_query* q, int32_t key_min
  * the same stop decision, and a round enqueued after the stop is a device-side no-op.
  * `stream` is a hipStream_t passed as void* (NULL = the context's own stream, a non-blocking stream: it is NOT
  * ordered against a framework's default/null stream — pass the explicit stream your collectives run on). */
-#define AQE_MOMENT_VEC 8 /* {n_a, S_a-c n_a, Q_a (shifted), n_b, S_b.., Q_b.., visited, 0} */
+#define AQE_MOMENT_VEC 8 /* {n_a, S_a-c n_a, Q_a (shifted), n_b, S_b.., Q_b.., visited, 0}; c = aqe_table_info.shift, moved into
+                            the WHERE range when the query has one and the table's shift lies outside it (the same on every shard) */
 AQE_API int aqe_plan_create(aqe_ctx* ctx, const aqe_query* q, aqe_plan** out);
 AQE_API void aqe_plan_destroy(aqe_plan* plan);
 AQE_API int aqe_plan_rounds(const aqe_plan* plan, uint32_t* rounds, int32_t* has_topup);

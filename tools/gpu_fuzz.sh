@@ -2,6 +2,8 @@
 # Dev helper (GPU box): the seeded parameter sweeps of tests/test_gpu_parity.py widened through the environment (other seeds,
 # more and larger tables): a one-off hunt; the default suite keeps its fixed seeds.
 cd "$(dirname "$0")/.."
-for seed in 11 12 13 14; do
-  AQE_FUZZ_SEED=$seed AQE_FUZZ_TABLES=60 AQE_FUZZ_MAXN=3000000 timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "randomised or key_ranges_nobody" 2>&1 | tail -2 || exit 1
+set -o pipefail
+for seed in ${FUZZ_SEEDS:-11 12 13 14 15 16 17 18}; do
+  echo "seed $seed"
+  AQE_FUZZ_SEED=$seed AQE_FUZZ_TABLES=60 AQE_FUZZ_MAXN=3000000 timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "randomised or key_ranges_nobody" 2>&1 | tail -25 | grep -v "^$" | tail -12 || exit 1
 done
