@@ -419,6 +419,17 @@ class CustomBPlusDB:
         Lemire index list, DB.cpp:856-882); "random_device" draws a simple random sample on the device (no index list).
         ``error_percent`` (CLT) is in percent, as the reference CLI's --e (enhanced_aqe_cli.py:414-415); the
         sample percentage then follows enhanced_aqe_cli.py:243-250."""
+        q = self._approx_query(agg, method, sample_percent, error_percent, where, seed, num_threads, block_size, confidence_level,
+                               check_interval, round0, growth, convention, id_between)
+        res = self._reduce(q)
+        if res.visited == 0:
+            raise RuntimeError("No samples collected")
+        return ApproxResult(res, method)
+
+    def _approx_query(self, agg, method="stride", sample_percent=10.0, error_percent=None, where=None, seed=42, num_threads=4,
+                      block_size=1000, confidence_level=0.95, check_interval=10, round0=4096, growth=4, convention="cli",
+                      id_between=None):
+        """The aqe_query behind approx(...)."""
         a = _AGG[agg.upper()]
         conv = {"cli": nat.EST_CLI, "cpp": nat.EST_CPP, "raw": nat.EST_RAW}[convention]
         if self._n == 0:
@@ -449,10 +460,39 @@ class CustomBPlusDB:
             bs = 4096 if (method == "page" and block_size == 1000) else block_size
             q = make_query(m, sample_percent, agg=a, convention=conv, where=where, seed=int(seed),
                            num_threads=int(num_threads), block_size=int(bs), rows=rows)
-        res = self._reduce(q)
-        if res.visited == 0:
-            raise RuntimeError("No samples collected")
-        return ApproxResult(res, method)
+        return q
+
+    def approx_batch(self, queries: "List[dict]") -> "List[ApproxResult]":
+        """Several APPROX queries in ONE launch (aqe_batch_enqueue_all: a group of workgroups, a monitor wave and a
+        should_stop word per query): each entry is the keyword dictionary approx() takes, e.g.
+        ``[{"agg": "AVG", "method": "clt", "error_percent": 0.01}, {"agg": "SUM", "method": "block", "sample_percent": 1, "where": (250, 750)}]``.
+        What replaces the reference's thread creation per call (custom_bplus_db.cpp:918-1029) when queries arrive in
+        batches; the seeded samplers that need a host index list ("random") run on their own."""
+        from .engine import Batch
+        eng = self._eng()
+        specs = [dict(kw) for kw in queries]
+        qs = [self._approx_query(**kw) for kw in specs]
+        out: "List[Optional[ApproxResult]]" = [None] * len(qs)
+        fused = [i for i, kw in enumerate(specs) if kw.get("method", "stride") not in ("random", "random_device")]
+        for i in set(range(len(qs))) - set(fused):
+            out[i] = ApproxResult(self._reduce(qs[i]), specs[i].get("method", "stride"))
+        if fused:
+            plans = [eng.plan(qs[i]) for i in fused]
+            batch = None
+            try:
+                batch = Batch(plans)
+                batch.enqueue_all(0)
+                for i, r in zip(fused, batch.fetch()):
+                    out[i] = ApproxResult(r, specs[i].get("method", "stride"))
+            finally:
+                if batch is not None:
+                    batch.close()
+                for p in plans:
+                    p.close()
+        for r in out:
+            if r is None or r.visited == 0:
+                raise RuntimeError("No samples collected")
+        return out
 
     def approx_group_by(self, agg: str, group_by: str = "region", sample_percent: float = 10.0, method: str = "rowid",
                         where: Optional[Tuple[float, float]] = None, block_size: int = 1000) -> "dict[str, GroupEstimate]":

@@ -240,6 +240,20 @@ def test_cli_end_to_end(tmp_path, oracle, table):
 
 
 @pytest.mark.gpu
+def test_approx_batch_is_approx_in_one_launch(db100k):
+    """approx_batch: the keyword dictionaries of approx(), served by ONE launch; same answers as one call each."""
+    specs = [dict(agg="AVG", method="clt", error_percent=2.0), dict(agg="SUM", method="clt", error_percent=0.0, round0=64, growth=2),
+             dict(agg="SUM", method="stride", sample_percent=1.0), dict(agg="COUNT", method="block", sample_percent=5.0, where=(250.0, 750.0), convention="cpp"),
+             dict(agg="AVG", method="exact"), dict(agg="SUM", method="random", sample_percent=1.0, seed=7),
+             dict(agg="AVG", method="page", sample_percent=5.0, id_between=(1000, 60_000))]
+    got = db100k.approx_batch(specs)
+    for kw, g in zip(specs, got):
+        w = db100k.approx(**kw)
+        assert (g.n, g.visited, g.converged, g.rounds, g.topup) == (w.n, w.visited, w.converged, w.rounds, w.topup), kw
+        assert rel(g.value, w.value) <= 1e-12 and rel(g.ci_lower, w.ci_lower) <= 1e-11 and g.method == kw["method"]
+
+
+@pytest.mark.gpu
 def test_group_by_entry_point(db100k, oracle, table):
     """approx_group_by: the reference's GroupResultWithCI shape (key string -> value, ci_lower, ci_upper)."""
     rows = table(100_000)
