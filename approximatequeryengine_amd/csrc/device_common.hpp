@@ -313,7 +313,12 @@ __device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F,
             // both rows must be readable: fall back to row 0/1 of the shard when the pair leaves the window
             const bool both = ok0[k] && ok1[k];
             const Row2* p = reinterpret_cast<const Row2*>(both ? base + oi : a.amount);
+#ifdef AQE_NT_LOADS  // (A/B build: non-temporal loads on the dense path)
+            v2[k].x = __builtin_nontemporal_load(&p->x);
+            v2[k].y = __builtin_nontemporal_load(&p->y);
+#else
             v2[k] = *p;
+#endif
             if (!both) {  // window edge (at most one lane per tile side): single 8-byte reads
                 v2[k].x = ok0[k] ? base[oi] : 0.0;
                 v2[k].y = ok1[k] ? base[oi + 1] : 0.0;
