@@ -283,7 +283,12 @@ __device__ __forceinline__ unsigned find_family(FamPtr fams, unsigned nfam, u64 
     return lo;
 }
 
-template <typename Fam>
+// kNT: the dense path loads non-temporally.  A column (or view) beyond the 256 MiB Infinity Cache is read once per
+// query and nothing of it is found again: streaming it through the caches with the default policy costs 9-11 % of the
+// bandwidth (1 B rows, exact scan: 1 300 -> 1 180 us = 6.8 TB/s; A/B on one box).  Tables that fit the cache keep the
+// default policy: there the next query — or the neighbour group of a batch — finds the lines again (10 M rows, the
+// bench batch: 140 us default, 155 us non-temporal).  The host picks the instantiation by the size of what is swept.
+template <bool kNT = false, typename Fam>
 __device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F, u64 t, int lane, u64 ord_limit, Acc& acc) {
     const u64 lt = t - F.tile_begin;
     u64 seg, j;
@@ -313,12 +318,12 @@ __device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F,
             // both rows must be readable: fall back to row 0/1 of the shard when the pair leaves the window
             const bool both = ok0[k] && ok1[k];
             const Row2* p = reinterpret_cast<const Row2*>(both ? base + oi : a.amount);
-#ifdef AQE_NT_LOADS  // (A/B build: non-temporal loads on the dense path)
-            v2[k].x = __builtin_nontemporal_load(&p->x);
-            v2[k].y = __builtin_nontemporal_load(&p->y);
-#else
-            v2[k] = *p;
-#endif
+            if (kNT) {
+                v2[k].x = __builtin_nontemporal_load(&p->x);
+                v2[k].y = __builtin_nontemporal_load(&p->y);
+            } else {
+                v2[k] = *p;
+            }
             if (!both) {  // window edge (at most one lane per tile side): single 8-byte reads
                 v2[k].x = ok0[k] ? base[oi] : 0.0;
                 v2[k].y = ok1[k] ? base[oi + 1] : 0.0;
@@ -392,9 +397,9 @@ __device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F,
     merge_tile(acc, ta, group_b);
 }
 
-template <typename FamPtr>
+template <bool kNT = false, typename FamPtr>
 __device__ __forceinline__ void sweep_tile(const SweepCommon& a, FamPtr fams, u64 t, int lane, u64 ord_limit, Acc& acc) {
-    sweep_family(a, fams[find_family(fams, a.nfam, t)], t, lane, ord_limit, acc);
+    sweep_family<kNT>(a, fams[find_family(fams, a.nfam, t)], t, lane, ord_limit, acc);
 }
 
 }  // namespace

@@ -44,6 +44,7 @@ struct LaunchDesc {
 constexpr size_t kStageChunkRows = 1u << 21;  // 2 Mi rows: 64 MiB of AoS per pinned buffer
 constexpr size_t kMaxStrideViews = 8;  // stride-major copies of the column a table may hold (one per pointer step in use)
 constexpr size_t kBatchLanes = 3;  // side streams of the batched multi-GPU form (see ensure_lanes)
+constexpr size_t kInfinityCacheBytes = 256ull << 20;  // MI355X: a column beyond it is streamed with non-temporal loads
 constexpr size_t kGraphMinRounds = 4, kGraphMaxRounds = 8192;  // one-launch-per-round plans replayed as a HIP graph
 
 }  // namespace aqe

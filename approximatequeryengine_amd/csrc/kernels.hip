@@ -159,6 +159,7 @@ __device__ __forceinline__ bool launch_is_live(const RoundLaunch& a, u64& ord_li
 }
 
 // One wave folds one tile (64 * kTileUnroll ordinals of one segment of one family) per iteration.
+template <bool kNT>
 __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
     __shared__ DevFamily lds_fams[kMaxLdsFams];
     u64 ord_limit;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
     // (the table is staged through LDS also when it has a single entry: passing it in the kernel arguments, as the
     // persistent sweep does, measured 0.5 us SLOWER here — a cold scalar load per wave against one staged copy)
     const DevFamily* fams = stage_families(a.sw, lds_fams);
-    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) sweep_tile(a.sw, fams, t, lane, ord_limit, acc);
+    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) sweep_tile<kNT>(a.sw, fams, t, lane, ord_limit, acc);
     finish_block(acc, a);
 }
 
@@ -481,8 +482,13 @@ inline unsigned grid_for(u64 work_items, u64 per_block) {
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     unsigned grid = grid_for(a.ntiles, kWavesPerBlock);
     // with events: they take the dispatch's own begin/end timestamps (what rocprofv3 reports as the kernel's duration)
-    if (ev0) hipExtLaunchKernelGGL(k_round, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL(k_round, dim3(grid), dim3(kBlockThreads), 0, s, a);
+    if (a.sw.nt) {
+        if (ev0) hipExtLaunchKernelGGL(k_round<true>, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL(k_round<true>, dim3(grid), dim3(kBlockThreads), 0, s, a);
+    } else {
+        if (ev0) hipExtLaunchKernelGGL(k_round<false>, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL(k_round<false>, dim3(grid), dim3(kBlockThreads), 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -92,7 +92,7 @@ struct SweepCommon {
     double wmin, wmax;
     double shift;           // c of the shifted sums
     int32_t dense16;        // 16-byte loads allowed on dense families (rows 0..1 of the column are readable)
-    int32_t pad;
+    int32_t nt;             // 1: what this launch sweeps is larger than the Infinity Cache: non-temporal loads on the dense path
 };
 
 struct RoundLaunch {
@@ -193,8 +193,8 @@ static_assert(sizeof(PersistLaunch) <= 4096, "kernel arguments are limited to 4 
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // A batch of queries in one launch: table[q] describes query q (as a launch of its own on `group size` workgroups would be
 // described; its epoch field is ignored), wg_map[b] = q << 32 | group size << 16 | index within the group for workgroup b.
-hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, hipStream_t s,
-                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, bool nt,
+                              hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);
 

@@ -384,6 +384,7 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
     stamp_wave(P, 3, lane);
 }
 
+template <bool kNT>
 __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch P) {
     __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];
     __shared__ unsigned lds_cnt[kMaxPersistRounds];
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
             const DevFamily& F = lfams[find_family(lfams, P.sw.nfam, t)];
             r = __builtin_amdgcn_readfirstlane(F.round);
             round_end = uniform64(F.round_end);
-            sweep_family(P.sw, F, t, lane, ~0ull, acc);
+            sweep_family<kNT>(P.sw, F, t, lane, ~0ull, acc);
         } else {
             const unsigned t32 = static_cast<unsigned>(t);
             unsigned i = 0;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_persist(PersistLaunch
             const auto& F = kfams[i];
             r = F.round;
             round_end = F.round_end;
-            sweep_family(P.sw, F, t, lane, ~0ull, acc);
+            sweep_family<kNT>(P.sw, F, t, lane, ~0ull, acc);
         }
         if (t + 1u == w) stamp_wave(P, 1, lane);
         stamp_wave(P, 2, lane);
@@ -540,6 +541,7 @@ __device__ __forceinline__ void monitor_main_multi(KargPtr K, unsigned long long
     }
 }
 
+template <bool kNT>
 __global__ __launch_bounds__(kPersistThreads) void k_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch) {
     __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];
     __shared__ unsigned lds_cnt[kMaxPersistRounds];
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_multi(const PersistLa
     const KargPtr K = (KargPtr)(table + (me >> 32));
     SweepCommon sw;
     sw.amount = K->sw.amount; sw.shard_lo = K->sw.shard_lo; sw.fams = K->sw.fams; sw.nfam = K->sw.nfam; sw.has_where = K->sw.has_where;
-    sw.wmin = K->sw.wmin; sw.wmax = K->sw.wmax; sw.shift = K->sw.shift; sw.dense16 = K->sw.dense16; sw.pad = 0;
+    sw.wmin = K->sw.wmin; sw.wmax = K->sw.wmax; sw.shift = K->sw.shift; sw.dense16 = K->sw.dense16; sw.nt = kNT ? 1 : 0;
     const DevFamily* fams = stage_families(sw, lds_fams);
     if (sw.nfam > kMaxLdsFams) __syncthreads();  // (stage_families took the barrier otherwise: lds_cnt is published either way)
 
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_multi(const PersistLa
         const DevFamily& F = fams[find_family(fams, nfam, t)];
         r = __builtin_amdgcn_readfirstlane(F.round);
         round_end = uniform64(F.round_end);
-        sweep_family(sw, F, t, lane, ~0ull, acc);
+        sweep_family<kNT>(sw, F, t, lane, ~0ull, acc);
         open = true;
         t += V;
         if (sw_word == stop_tag) break;  // this query's monitor ended it: nothing is owed to anybody
@@ -595,15 +597,25 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_multi(const PersistLa
 }  // namespace
 
 hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (ev0) hipExtLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL(k_sweep_persist, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    if (a.sw.nt) {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_persist<true>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL(k_sweep_persist<true>, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    } else {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_persist<false>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL(k_sweep_persist<false>, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, hipStream_t s,
-                              hipEvent_t ev0, hipEvent_t ev1) {
-    if (ev0) hipExtLaunchKernelGGL(k_sweep_multi, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, table, wg_map, epoch);
-    else hipLaunchKernelGGL(k_sweep_multi, dim3(grid), dim3(kPersistThreads), 0, s, table, wg_map, epoch);
+hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, bool nt,
+                              hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (nt) {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_multi<true>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, table, wg_map, epoch);
+        else hipLaunchKernelGGL(k_sweep_multi<true>, dim3(grid), dim3(kPersistThreads), 0, s, table, wg_map, epoch);
+    } else {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_multi<false>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, table, wg_map, epoch);
+        else hipLaunchKernelGGL(k_sweep_multi<false>, dim3(grid), dim3(kPersistThreads), 0, s, table, wg_map, epoch);
+    }
     return hipGetLastError();
 }
 

@@ -130,6 +130,9 @@ SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam
     s.wmax = p->q.where_max;
     s.shift = query_shift(c, p->q);
     s.dense16 = c->dense16 ? 1 : 0;
+    // what a query sweeps of a column (or view) beyond the Infinity Cache is read once and never found again: stream it
+    // past the caches (device_common.hpp, sweep_family<kNT>); a table that fits keeps the default policy
+    s.nt = (c->n_local * sizeof(double) > kInfinityCacheBytes) ? 1 : 0;
     return s;
 }
 
@@ -967,7 +970,8 @@ int launch_multi(aqe_batch* b, int kind, hipStream_t s) {
         p->tick_timed = false;
     }
     b->profiled = b->profile;
-    HIPCHK(c, launch_sweep_multi(m.d_table, m.d_wgmap, epoch, m.grid, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
+    const bool nt = c->n_local * sizeof(double) > kInfinityCacheBytes;
+    HIPCHK(c, launch_sweep_multi(m.d_table, m.d_wgmap, epoch, m.grid, nt, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
     b->last_stream = s;
     b->last_kind = kind;
     return AQE_OK;
