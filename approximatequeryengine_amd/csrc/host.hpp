@@ -180,6 +180,7 @@ struct aqe_plan {
     const double* view_topup = nullptr;   // ... and the top-up's
     uint64_t view_step_rounds = 0, view_step_topup = 0;  // the steps of those views (0: none): the plan holds a reference on each
     bool cached = false;                  // owned by the context's reduce cache
+    bool nt = false;                      // one execution sweeps more than the Infinity Cache holds: non-temporal loads
     unsigned grid = 0;          // workgroups of the persistent sweep for this plan (the context's, or half of it)
     SweepForm head;             // the first rounds only, on a few workgroups: the single launch of a query predicted to stop early
     volatile unsigned long long* h_seq = nullptr;  // behind h_result: the epoch of the launch whose result is there

@@ -130,9 +130,10 @@ SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam
     s.wmax = p->q.where_max;
     s.shift = query_shift(c, p->q);
     s.dense16 = c->dense16 ? 1 : 0;
-    // what a query sweeps of a column (or view) beyond the Infinity Cache is read once and never found again: stream it
-    // past the caches (device_common.hpp, sweep_family<kNT>); a table that fits keeps the default policy
-    s.nt = (c->n_local * sizeof(double) > kInfinityCacheBytes) ? 1 : 0;
+    // a query that sweeps more than the Infinity Cache holds finds nothing of it again: its loads go past the caches
+    // (device_common.hpp, sweep_family<kNT>); smaller sweeps keep the default policy — the next execution, or a
+    // neighbour in a batch, reads the same lines
+    s.nt = p->nt ? 1 : 0;
     return s;
 }
 
@@ -418,6 +419,11 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_idx), p->host.random_idx.size() * sizeof(uint64_t)));
         HIPCHK(c, hipMemcpy(p->d_idx, p->host.random_idx.data(), p->host.random_idx.size() * sizeof(uint64_t),
                             hipMemcpyHostToDevice));
+    }
+    {   // (what one execution sweeps, in bytes of this shard: decides the load policy, sweep_common)
+        uint64_t swept = p->host.has_topup ? p->topup.samples : 0;
+        for (const LaunchDesc& L : p->rounds) swept += L.samples;
+        p->nt = swept * sizeof(double) > kInfinityCacheBytes;
     }
     {   // persistent single-launch forms of the rounds
         const size_t R = p->rounds.size();
@@ -800,6 +806,7 @@ struct BatchMulti {
     unsigned long long* d_wgmap = nullptr; // [grid] workgroup -> (plan, group size, index in the group)
     unsigned grid = 0;
     uint64_t samples = 0;                  // rows one launch sweeps (all plans)
+    bool nt = false;                       // the launch's loads go past the caches (build_multi)
     const double* totals = nullptr;        // kind 1: the buffer the descriptors were written for
     uint64_t stride = 0;
 };
@@ -949,6 +956,28 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
     HIPCHK(c, hipMemcpy(m.d_table, table.data(), n * sizeof(PersistLaunch), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_wgmap), wgmap.size() * sizeof(unsigned long long)));
     HIPCHK(c, hipMemcpy(m.d_wgmap, wgmap.data(), wgmap.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    {   // Load policy of the launch.  The groups of a batch that sweep the same rows find each other's lines in the caches
+        // (default policy); groups over (nearly) disjoint row windows that together exceed the Infinity Cache find
+        // nothing again: non-temporal.  Overlap = sum of the plans' row ranges over the length of their union.
+        std::vector<std::pair<uint64_t, uint64_t>> iv;
+        uint64_t sum_len = 0, swept = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const aqe_query& q = b->plans[i]->q;
+            const uint64_t lo = q.row_hi > q.row_lo ? q.row_lo : 0, hi = q.row_hi > q.row_lo ? q.row_hi : c->n_global;
+            iv.emplace_back(lo, hi);
+            sum_len += hi - lo;
+            swept += m.forms[i].samples;
+        }
+        std::sort(iv.begin(), iv.end());
+        uint64_t uni = 0, cur_lo = 0, cur_hi = 0;
+        for (const auto& x : iv) {
+            if (x.first > cur_hi) { uni += cur_hi - cur_lo; cur_lo = x.first; cur_hi = x.second; }
+            else cur_hi = std::max(cur_hi, x.second);
+        }
+        uni += cur_hi - cur_lo;
+        const double overlap = uni ? static_cast<double>(sum_len) / static_cast<double>(uni) : 1.0;
+        m.nt = overlap < 1.5 && static_cast<double>(swept) * sizeof(double) / overlap > static_cast<double>(kInfinityCacheBytes);
+    }
     m.totals = dev_totals;
     m.stride = row_stride;
     m.built = true;
@@ -970,8 +999,7 @@ int launch_multi(aqe_batch* b, int kind, hipStream_t s) {
         p->tick_timed = false;
     }
     b->profiled = b->profile;
-    const bool nt = c->n_local * sizeof(double) > kInfinityCacheBytes;
-    HIPCHK(c, launch_sweep_multi(m.d_table, m.d_wgmap, epoch, m.grid, nt, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
+    HIPCHK(c, launch_sweep_multi(m.d_table, m.d_wgmap, epoch, m.grid, m.nt, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
     b->last_stream = s;
     b->last_kind = kind;
     return AQE_OK;
