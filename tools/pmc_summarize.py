@@ -31,12 +31,14 @@ doc = {"source_hash": bench.source_hash(), "batch": batch}
 doc.update(medians(fetch_dir))
 doc.update(medians(write_dir))
 F, W = doc["FETCH_SIZE"], doc.get("WRITE_SIZE", {})
-scan = max((k for k in F if k.startswith("k_round ")), key=lambda k: F[k]["median_KB"])  # the exact scan is the biggest k_round
+def named(k, name):  # "k_round<false> grid_threads=..." is kernel k_round
+    return re.split(r"[<\s]", k, maxsplit=1)[0] == name
+scan = max((k for k in F if named(k, "k_round")), key=lambda k: F[k]["median_KB"])  # the exact scan is the biggest k_round
 known = 80_000_000
 corr = known / (F[scan]["median_KB"] * 1024.0)
 doc["calibration"] = {"known_bytes": known, "kernel": f"{scan} (exact scan of the 10M-row amount column)", "fetch_correction": corr}
 def traffic(prefix):
-    ks = [k for k in F if k.startswith(prefix + " ")]
+    ks = [k for k in F if named(k, prefix)]
     if not ks:
         return None
     k = max(ks, key=lambda k: F[k]["median_KB"])
@@ -66,7 +68,7 @@ for inst in ("k_grouped<true>", "k_grouped<false>"):
         doc.setdefault("k_grouped_traffic_bytes_per_launch", {})[k] = F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
 if len(sys.argv) > 5:  # a third pass: the batch of 32 exact scans over disjoint key ranges of a 320 M-row table (tools/pmc_probe_disjoint.py)
     D = medians(sys.argv[5])["FETCH_SIZE"]
-    k = max((k for k in D if k.startswith("k_sweep_multi ")), key=lambda k: D[k]["median_KB"])
+    k = max((k for k in D if named(k, "k_sweep_multi")), key=lambda k: D[k]["median_KB"])
     doc["k_sweep_multi_disjoint_320M"] = {"kernel": k, "launches": D[k]["launches"], "fetch_raw_KB": D[k]["median_KB"],
                                           "traffic_bytes_per_launch": D[k]["median_KB"] * 1024.0 * corr, "algorithmic_bytes_per_launch": 8.0 * 320_000_000}
 json.dump(doc, open(dst, "w"), indent=1)
