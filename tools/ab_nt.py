@@ -10,7 +10,7 @@ out = [os.path.basename(os.environ.get("AQE_HIP_LIB", "default"))]
 def med(q, reps=15):
     for _ in range(3): eng.reduce(q)
     return statistics.median(eng.reduce(q).kernel_ms for _ in range(reps)) * 1e3
-for n, tag in ((10_000_000, "10M"), (1_000_000_000, "1B")):
+for n, tag in ((100_000_000, "100M"), (1_000_000_000, "1B")):
     eng.generate_synthetic(n)
     out.append(f"{tag} exact {med(make_query(nat.M_EXACT, 100.0)):.1f}")
     out.append(f"stride20 {med(make_query(nat.M_MEMORY_STRIDE, 20.0)):.1f}")
