@@ -319,16 +319,8 @@ __device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F,
             const bool both = ok0[k] && ok1[k];
             const Row2* p = reinterpret_cast<const Row2*>(both ? base + oi : a.amount);
             if (kNT) {
-#ifdef AQE_NT16  // (A/B build: one 16-byte non-temporal load instead of two 8-byte ones)
-                typedef double D2 __attribute__((ext_vector_type(2)));
-                typedef D2 D2a8 __attribute__((aligned(8)));
-                const D2 t2 = __builtin_nontemporal_load(reinterpret_cast<const D2a8*>(p));
-                v2[k].x = t2.x;
-                v2[k].y = t2.y;
-#else
-                v2[k].x = __builtin_nontemporal_load(&p->x);
+                v2[k].x = __builtin_nontemporal_load(&p->x);  // (the two halves leave as ONE global_load_dwordx4 ... nt)
                 v2[k].y = __builtin_nontemporal_load(&p->y);
-#endif
             } else {
                 v2[k] = *p;
             }

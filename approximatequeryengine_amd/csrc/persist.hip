@@ -338,11 +338,7 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_s_setprio(3);
     stamp_wave(P, 0, lane);
-#ifndef AQE_OLD_GIVEUP
     if (lane == 0) lds_t0 = __builtin_amdgcn_s_memrealtime();  // (the query's device-clock timing, and the give-up bound below)
-#else
-    if (K->want_ticks && lane == 0) lds_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     unsigned judged = 0, polls = 0;  // rounds [0, judged) are folded and judged
     double run = 0.0;                // this lane's running sum over every step folded so far
     // nothing can be complete yet: rehearse the fold, so that the real one finds its code in the instruction cache
@@ -355,7 +351,6 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
             const FoldOut o = monitor_fold(K, judged, complete, run, 0u);  // does not return if the query ends here
             run = o.run;
             judged = o.judged;
-#ifndef AQE_OLD_GIVEUP
         } else if ((++polls & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - lds_t0 > kGiveUpTicks) {
             // Cannot happen in a healthy launch: every workgroup publishes every round it owns tiles of.  The bound is
             // TIME (the device's 100 MHz clock, looked at every 1024 polls), not a poll count: this launch's other
@@ -369,15 +364,6 @@ __device__ __forceinline__ void monitor_main(const PersistLaunch& P, KargPtr K) 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&P.ctl->stop_word, (P.epoch << 8) | 1ull, AQE_RLX);
             }
-#else
-        } else if (++polls > (1u << 21)) {  // (A/B build: the round-1 bound, a poll count)
-            if (lane == 0) {
-                QueryState st{};
-                st.error = 1;
-                state_store(P.state, st);
-                finalize(st, P.fin, P.result);
-            }
-#endif
             break;
         }
     }
