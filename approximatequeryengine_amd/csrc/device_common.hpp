@@ -3,7 +3,7 @@
 //
 // Reference lines restated here (DB.cpp = /root/reference/src/aqe_backend/core/custom_bplus_db.cpp):
 //   reducer loops       DB.cpp:285-294, 324-335, 2024-2036  -> sweep_tile
-//   CLT error rule      DB.cpp:936-961                      -> fold(), rule A on the pooled triple
+//   CLT error rule      DB.cpp:936-961                      -> fold(), rule A on the leader's own triple (group a)
 //   CLT cross-check     DB.cpp:993-1016                     -> fold(), rule B
 //   top-up              DB.cpp:1031-1040                    -> fold() with FoldParams::is_topup
 //   estimators + CI     enhanced_aqe_cli.py:189-200, 277-291; DB.cpp:303-315 -> finalize()
@@ -95,15 +95,16 @@ __device__ __forceinline__ void mean_m2(double n, double sd, double qd, double c
     if (m2 < 0.0) m2 = 0.0;
 }
 
-// The monitor's decision on the moments gathered so far (fast group a, slow group b, pooled a+b):
-// 1 = error rule (DB.cpp:936-961 on the pooled, all-reduced triple), 2 = cross-validation rule
-// (DB.cpp:993-1016), 0 = go on.  The reference's own expressions:
+// The monitor's decision on the moments gathered so far.  Group a is the LEADER — fast worker 0 — group b every other
+// worker.  1 = error rule on the leader's OWN samples (DB.cpp:936-961: a fast thread judges the samples it took itself),
+// 2 = cross-validation of the others' mean against the leader's, once the leader holds base/2 rows (DB.cpp:993-1016:
+// the gate is the publishing fast thread's own count), 0 = go on.  The reference's own expressions:
 __device__ __forceinline__ int clt_rules_exact(double n_a, double sd_a, double qd_a, double n_b, double sd_b, double qd_b,
                                                const FoldParams& p) {
-    const double n = n_a + n_b;
+    const double n = n_a;
     if (n >= 30.0) {
         double mean, m2;
-        mean_m2(n, sd_a + sd_b, qd_a + qd_b, p.shift, mean, m2);
+        mean_m2(n, sd_a, qd_a, p.shift, mean, m2);
         const double var = m2 / (n - 1.0);
         const double se = sqrt(var / n);
         const double err = (p.z * se / mean) * 100.0;
@@ -129,7 +130,7 @@ __device__ __forceinline__ int clt_rules_exact(double n_a, double sd_a, double q
 // decide; the decision is therefore the same one, a dozen multiplications away instead of five divisions.
 __device__ __forceinline__ int clt_rules(double n_a, double sd_a, double qd_a, double n_b, double sd_b, double qd_b,
                                          const FoldParams& p) {
-    const double n = n_a + n_b, sd = sd_a + sd_b, qd = qd_a + qd_b, c = p.shift;
+    const double n = n_a, sd = sd_a, qd = qd_a, c = p.shift;  // rule A: the leader's own triple
     int a = 0, b = 0;  // 1/2: holds, 0: does not, -1: too close to call
     if (n >= 30.0) {
         const double M = n * c + sd, Q = qd * n - sd * sd;
@@ -357,7 +358,7 @@ __device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F,
         TileAcc ta, tb;
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) { accumulate(ta, va[k], oka[k], a); accumulate(tb, vb[k], okb[k], a); }
-        merge_tile(acc, ta, false);
+        merge_tile(acc, ta, F.group != 0);  // (the first pointer is the leader's only in the leader's region)
         merge_tile(acc, tb, true);
         return;
     }

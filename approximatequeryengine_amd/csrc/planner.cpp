@@ -466,7 +466,9 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
             for (int t = 0; t < F; ++t) {  // DB.cpp:925-927
                 u64 a = (N * static_cast<u64>(t)) / static_cast<u64>(F), b = (N * static_cast<u64>(t + 1)) / static_cast<u64>(F);
                 u64 step = static_cast<u64>(std::max(3, static_cast<int>((b - a) / static_cast<u64>(P.clt.base / F))));
-                ws.push_back({a, step, prog_count(a, b, step), 0});
+                // group 0 is the LEADER — fast worker 0, the one whose own statistics decide rule A (DB.cpp:936-961: a fast
+                // thread judges its own samples); every other worker, fast or slow, is group 1
+                ws.push_back({a, step, prog_count(a, b, step), t == 0 ? 0u : 1u});
             }
             for (int t = 0; t < S; ++t) {  // DB.cpp:983-990
                 u64 a = (N * static_cast<u64>(t)) / static_cast<u64>(S), b = (N * static_cast<u64>(t + 1)) / static_cast<u64>(S);
@@ -495,7 +497,7 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
                         u64 lo2, hi2;
                         window(v, lo2, hi2);
                         if (hi <= lo && hi2 <= lo2) continue;
-                        aqe_family f = strided(w.first, w.step, std::max(w.count, v.count), 0);
+                        aqe_family f = strided(w.first, w.step, std::max(w.count, v.count), w.group);
                         f.ord_lo = lo; f.ord_hi = hi;
                         f.flags = AQE_F_PAIR;
                         f.row0_b = v.first; f.ord_lo_b = lo2; f.ord_hi_b = hi2;

@@ -446,11 +446,15 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             // predicted to stop early gets the HEAD form below.  AQE_Q_NO_PERSIST / AQE_Q_FORCE_PERSIST override.
             if (p->host.is_clt && !(q->flags & AQE_Q_FORCE_PERSIST) && c->head_cv > 0.0 && q->max_error_percent > 0.0) {
                 const double root = p->host.clt.z * c->head_cv * 100.0 / q->max_error_percent;
-                const double n_stop = std::max(50.0, root * root);  // samples before rule A can hold (n >= 50, DB.cpp:958)
-                double swept = 0.0;
-                size_t r_stop = 0;  // rounds swept when the rule is predicted to hold
-                for (; r_stop < R && swept < n_stop; ++r_stop) swept += static_cast<double>(p->rounds[r_stop].samples);
-                p->per_round = swept * 4.0 <= static_cast<double>(p->decide.samples);
+                const double n_stop = std::max(50.0, root * root);  // samples the LEADER needs before rule A can hold (n >= 50, DB.cpp:958)
+                const double workers = static_cast<double>(std::max(1, p->host.clt.n_workers));
+                double swept = 0.0, leader = 0.0;
+                size_t r_stop = 0;  // rounds swept when the rule is predicted to hold (a round gives every worker the same number of rows)
+                for (; r_stop < R && leader < n_stop; ++r_stop) {
+                    swept += static_cast<double>(p->rounds[r_stop].samples);
+                    leader += static_cast<double>(p->rounds[r_stop].samples) / workers;
+                }
+                p->per_round = p->host.clt.n_fast > 0 && swept * 4.0 <= static_cast<double>(p->decide.samples);
                 if (p->per_round) {
                     // The HEAD form: ONE launch that sweeps the predicted rounds plus one of margin (four times the rows:
                     // twice the predicted cv) on just enough workgroups for one tile per wave.  If the query has not

@@ -151,7 +151,8 @@ typedef struct aqe_result {
     uint64_t n;        /* samples folded into (S, Q) (pass WHERE)                            */
     uint64_t visited;  /* samples drawn (== n without WHERE)                                 */
     uint64_t topup;    /* CLT: rows added by the top-up                                      */
-    int32_t converged; /* CLT: 0 no, 1 error rule (DB.cpp:958), 2 cross-validation (DB.cpp:1009) */
+    int32_t converged; /* CLT: 0 no, 1 error rule on the leader's own samples (DB.cpp:958), 2 cross-validation of the others' mean
+                          against the leader's (DB.cpp:1009) */
     int32_t rounds;    /* CLT: rounds folded before the stop                                 */
     double kernel_ms;  /* aqe_reduce / timed executions: device time of the query by the device's own 100 MHz clock,
                           from its first launch starting (the monitor wave, for a persistent launch) to the result
@@ -166,12 +167,13 @@ typedef struct aqe_result {
  * for ordinals o in [ord_lo, ord_hi).  Every deterministic sampler is a short list of these.
  * A PAIR family carries a second pointer with the same step over the same rows — the reference's
  * fast and slow pointer of one region (DB.cpp:925-927 / 983-987) — so one sweep serves both:
- * row_b(o) = row0_b + o * step for o in [ord_lo_b, ord_hi_b), folded into group 1. */
+ * row_b(o) = row0_b + o * step for o in [ord_lo_b, ord_hi_b), folded into group 1 (the first pointer into `group`). */
 typedef struct aqe_family {
     uint64_t row0, pitch, seg_len, step;
     uint64_t ord_lo, ord_hi;
     uint64_t row0_b, ord_lo_b, ord_hi_b; /* AQE_F_PAIR only */
-    uint32_t group; /* 0 = fast pointers / default, 1 = slow pointers */
+    uint32_t group; /* 0 = default; CLT: the LEADER (fast worker 0, whose own statistics decide the error rule,
+                       DB.cpp:936-961), 1 = every other worker (the other fast pointers and the slow ones) */
     uint32_t flags; /* AQE_F_* */
 } aqe_family;
 #define AQE_F_TOPUP 1u /* ord_hi is further limited on the device to base - collected */
@@ -311,7 +313,7 @@ AQE_API int aqe_grouped_finish(aqe_ctx* ctx, const aqe_query* q, int32_t key_min
  * the same stop decision, and a round enqueued after the stop is a device-side no-op.
  * `stream` is a hipStream_t passed as void* (NULL = the context's own stream, a non-blocking stream: it is NOT
  * ordered against a framework's default/null stream — pass the explicit stream your collectives run on). */
-#define AQE_MOMENT_VEC 8 /* {n_a, S_a-c n_a, Q_a (shifted), n_b, S_b.., Q_b.., visited, 0}; c = aqe_table_info.shift, moved into
+#define AQE_MOMENT_VEC 8 /* {n_a, S_a-c n_a, Q_a (shifted), n_b, S_b.., Q_b.., visited, 0}: a = group 0, b = group 1; c = aqe_table_info.shift, moved into
                             the WHERE range when the query has one and the table's shift lies outside it (the same on every shard) */
 AQE_API int aqe_plan_create(aqe_ctx* ctx, const aqe_query* q, aqe_plan** out);
 AQE_API void aqe_plan_destroy(aqe_plan* plan);

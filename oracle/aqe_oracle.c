@@ -575,6 +575,7 @@ int aqo_clt_make_plan(uint64_t N, double pct, double conf, int check_interval, i
         int step = imax(3, (int)((b - a) / (uint64_t)(p->base / F)));
         aqo_clt_worker* w = &p->w[t];
         w->first = a; w->end = b; w->step = (uint64_t)step; w->is_fast = 1;
+        w->group = t == 0 ? 0 : 1;
         w->count = prog_count(w->first, w->end, w->step);
     }
     for (int t = 0; t < S; ++t) { /* DB.cpp:983-990 */
@@ -582,6 +583,7 @@ int aqo_clt_make_plan(uint64_t N, double pct, double conf, int check_interval, i
         int step = imax(1, (int)((b - a) / (uint64_t)(p->base / S)));
         aqo_clt_worker* w = &p->w[F + t];
         w->first = a + (uint64_t)(step / 2); w->end = b; w->step = (uint64_t)step; w->is_fast = 0;
+        w->group = 1;
         w->count = prog_count(w->first, w->end, w->step);
     }
     return 0;
@@ -603,7 +605,7 @@ void aqo_clt_round_partial(const aqo_record* rows_at_lo, uint64_t lo, uint64_t h
         for (uint64_t k = ord_begin; k < k1; ++k) {
             uint64_t i = w->first + k * w->step;
             if (i < lo || i >= hi) continue;
-            acc(w->is_fast ? fast : slow, rows_at_lo[i - lo].amount);
+            acc(w->group == 0 ? fast : slow, rows_at_lo[i - lo].amount);
         }
     }
 }
@@ -651,19 +653,20 @@ int aqo_clt_run(const aqo_record* rows, uint64_t N, double pct, double conf, int
                 double x = rows[i].amount;
                 emit(&s, i);
                 acc(&A, x); va[na++] = x;
-                if (w->is_fast) { acc(&F, x); vf[nf++] = x; } else { acc(&S, x); vs[ns++] = x; }
+                if (w->group == 0) { acc(&F, x); vf[nf++] = x; } else { acc(&S, x); vs[ns++] = x; }
             }
         }
         res->rounds++;
         b = b1;
         R = (R > (UINT64_MAX / 4) / growth) ? UINT64_MAX / 4 : R * growth;
-        /* rule A on the pooled moments (DB.cpp:936-961 applied to the all-reduced triple) */
+        /* rule A on the LEADER's own samples — fast worker 0 (DB.cpp:936-961: a fast thread judges the samples it took
+         * itself; F = its moments, vf its values, two-pass variance as the reference takes it) */
         finish_moments(&A); finish_moments(&F); finish_moments(&S);
-        if (A.n >= 30) {
-            double var = m2_of(va, na, A.mean) / (double)(A.n - 1);
-            if (aqo_clt_fast_rule(A.n, A.mean, var, plan.z, e)) { res->converged = 1; break; }
+        if (F.n >= 30) {
+            double var = m2_of(vf, nf, F.mean) / (double)(F.n - 1);
+            if (aqo_clt_fast_rule(F.n, F.mean, var, plan.z, e)) { res->converged = 1; break; }
         }
-        /* rule B: slow group cross-validates the fast group (DB.cpp:993-1016) */
+        /* rule B: the others' mean cross-validates the leader's, once the leader holds base/2 rows (DB.cpp:993-1016) */
         if (aqo_clt_slow_rule(S.n, S.mean, F.n, F.mean, e, plan.base)) { res->converged = 2; break; }
     }
     A.m2 = m2_of(va, na, A.mean);

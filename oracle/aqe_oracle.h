@@ -103,6 +103,7 @@ typedef struct {
     uint64_t step;
     uint64_t count; /* samples in [first,end) */
     int is_fast;
+    int group; /* 0: the LEADER (fast worker 0: its own samples decide the error rule, DB.cpp:936-961), 1: every other worker */
 } aqo_clt_worker;
 
 typedef struct {

@@ -50,7 +50,7 @@ class Moments(C.Structure):
 
 class CltWorker(C.Structure):
     _fields_ = [("first", C.c_uint64), ("end", C.c_uint64), ("step", C.c_uint64), ("count", C.c_uint64),
-                ("is_fast", C.c_int)]
+                ("is_fast", C.c_int), ("group", C.c_int)]
 
 
 class CltPlan(C.Structure):

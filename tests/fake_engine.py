@@ -76,7 +76,7 @@ class OracleShardPlan:
             k = np.arange(min(b0, w.count), min(b1, w.count), dtype=np.int64)
             idx = w.first + k * w.step
             idx = idx[(idx >= self.lo) & (idx < self.hi)] - self.lo
-            (fa if w.is_fast else sl).append(amt[idx])
+            (fa if w.group == 0 else sl).append(amt[idx])  # group 0: the leader (fast worker 0), group 1: everyone else
         fa = np.concatenate(fa) if fa else np.zeros(0)
         sl = np.concatenate(sl) if sl else np.zeros(0)
         v[0:3] = self._shifted(fa); v[3:6] = self._shifted(sl); v[6] = len(fa) + len(sl); v[7] = 0
@@ -96,10 +96,10 @@ class OracleShardPlan:
         s["visited"] += v[6]; s["rounds"] += 1
         if self.kind != "clt":
             return
-        n = s["n_p"]
+        n = s["n_a"]  # rule A: the leader's own samples (device_common.hpp clt_rules)
         if n >= 30:
-            mean = self.c + s["sd_p"] / n
-            m2 = max(s["qd_p"] - s["sd_p"] ** 2 / n, 0.0)
+            mean = self.c + s["sd_a"] / n
+            m2 = max(s["qd_a"] - s["sd_a"] ** 2 / n, 0.0)
             if self.o.lib.aqo_clt_fast_rule(int(n), mean, m2 / (n - 1), self.z, self.e):
                 s["converged"], s["stop"] = 1, 1
                 return

@@ -250,18 +250,28 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     assert np.array_equal(np.sort(got["id"] - 1), np.sort(idx.astype(np.int64)))
 
 
-def test_clt_collected_rows_lie_within_the_reference_runs(nat, golden, engines):
-    """The converging regime of the reference is a race; what can be pinned is the range its 30 recorded
-    runs show.  Rows collected before the stop (returned - base/4 top-up, DB.cpp:1032-1040): reference 395 ... 49 885;
-    the pooled, round-synchronous monitor on the device must land inside (it stops when the POOL satisfies the rule
-    one fast thread satisfies alone in the reference — fewer rows than the reference's typical run)."""
+@pytest.mark.parametrize("n", [1_000_000, 10_000_000])
+def test_clt_stop_points_of_the_reference(nat, golden, engines, n):
+    """Where the CLT monitor stops, against the reference's own runs (golden clt_fast_stop, distributions), at 1 M rows and
+    at the bench's 10 M.  T = 2 — the race-free regime: ONE fast thread, whose own statistics decide (DB.cpp:936-961) —
+    the device's leader must stop on exactly the row count the reference's fast thread had taken.  T = 4 at e = 1 % —
+    the racy regime — the rows collected before the stop must lie within what the reference's 30 recorded runs show
+    (they equal T x the fast thread's count: every worker takes the same number of rows per round)."""
     from approximatequeryengine_amd.engine import make_query
-    runs = golden["tables"]["1000000"]["distributions"]["clt_e1_pct20_T4"]
-    eng = engines(1_000_000)
+    T = golden["tables"][str(n)]
+    eng = engines(n)
+    for g in T["clt_fast_stop"]:
+        q = make_query(nat.M_CLT_DUAL_POINTER, g["pct"], agg=nat.AVG, confidence_level=0.95, check_interval=g["check_interval"], num_threads=2,
+                       max_error_percent=g["e"])
+        r = eng.reduce(q)
+        assert r.converged == 1 and r.rounds == g["n_fast_at_stop"] // g["check_interval"], (g, r.rounds)
+        assert r.n - r.topup == 2 * g["n_fast_at_stop"]  # the leader and the one slow pointer, row for row
+    runs = T["distributions"]["clt_e1_pct20_T4"]
+    base4 = int(n * 0.2) // 4
     r = eng.reduce(make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, confidence_level=0.95, check_interval=10, num_threads=4, max_error_percent=1.0))
-    ref_collected = [x["n"] - 50_000 for x in runs]
-    assert r.converged == 1 and r.topup == 50_000
-    assert min(ref_collected) <= r.n - r.topup <= max(ref_collected)
+    ref_collected = [x["n"] - base4 for x in runs]
+    assert r.converged == 1 and r.topup == base4
+    assert min(ref_collected) <= r.n - r.topup <= max(ref_collected), (r.n - r.topup, min(ref_collected), max(ref_collected))
     avgs = np.array([x["avg"] for x in runs])
     assert abs(r.value - avgs.mean()) <= 3 * max(avgs.std(), 0.5)
 
@@ -308,7 +318,7 @@ def test_clt_decision_table_near_the_thresholds(nat, oracle, engines):
     z = oracle.lib.aqo_clt_zscore(0.95)
 
     def literal(n_a, sd_a, qd_a, n_b, sd_b, qd_b, e, base):
-        n, sd, qd = n_a + n_b, sd_a + sd_b, qd_a + qd_b
+        n, sd, qd = n_a, sd_a, qd_a  # rule A: the leader's own samples (group a), DB.cpp:936-961
         if n >= 30:
             mean, m2 = c + sd / n, max(qd - sd * sd / n, 0.0)
             err = (z * math.sqrt(m2 / (n - 1.0) / n) / mean) * 100.0
@@ -338,14 +348,14 @@ def test_clt_decision_table_near_the_thresholds(nat, oracle, engines):
         var0 = (e * mean / (100.0 * z)) ** 2 * n  # err == e exactly (in exact arithmetic)
         for d in (0.0, 1e-15, 1e-13, 1e-10, 1e-8, 1e-5, 1e-2):
             for sgn in (-1.0, 1.0):
-                cases.append(("A", d, vec(n // 2, mean, var0 * (1 + sgn * d), n - n // 2, mean, var0 * (1 + sgn * d))))
+                cases.append(("A", d, vec(n, mean, var0 * (1 + sgn * d), n // 3, mean * 1.5, var0)))  # (group b must not matter)
     for n_a in (base // 2 - 1, base // 2, base):
         mean_a = 480.0
         for d in (0.0, 1e-15, 1e-12, 1e-9, 1e-5, 1e-2):
             for sgn in (-1.0, 1.0):
                 mean_b = mean_a * (1 + (e / 100.0) * (1 + sgn * d))
                 cases.append(("B", d, vec(n_a, mean_a, 1e7, 25, mean_b, 1e7)))  # huge variance: rule A stays off
-    cases.append(("neg", 1.0, vec(40, -5.0, 1.0, 40, -5.0, 1.0)))  # mean < 0: err < 0 <= e in the reference's expression
+    cases.append(("neg", 1.0, vec(80, -5.0, 1.0, 40, -5.0, 1.0)))  # mean < 0: err < 0 <= e in the reference's expression
     seen = set()
     for kind, d, v in cases:
         dev.copy_(torch.tensor(v, dtype=torch.float64))
@@ -356,8 +366,8 @@ def test_clt_decision_table_near_the_thresholds(nat, oracle, engines):
         assert got == literal(*v[:6], e, base), (kind, d, v)
         seen.add((kind, got))
         if kind == "A" and d >= 1e-5:
-            n = int(v[0] + v[3])
-            mean, m2 = c + (v[1] + v[4]) / n, (v[2] + v[5]) - (v[1] + v[4]) ** 2 / n
+            n = int(v[0])
+            mean, m2 = c + v[1] / n, v[2] - v[1] ** 2 / n
             assert (got == 1) == bool(oracle.lib.aqo_clt_fast_rule(n, mean, m2 / (n - 1), z, e)) or n < 50
     assert {("A", 0), ("A", 1), ("B", 0), ("B", 2), ("neg", 1)} <= seen
     plan.close()

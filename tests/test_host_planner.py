@@ -202,6 +202,7 @@ def test_clt_round_plans_equal_oracle(nat, oracle, table, case):
                    max_error_percent=0.0)
     rc, plan = oracle.clt_plan(n, pct, 0.95, ci, T)
     assert rc == 0
+    assert [plan.w[i].group for i in range(T)] == [0 if (i == 0 and T >= 2) else 1 for i in range(T)]
     _, rounds, samples = nat.plan_families(q, n)
     assert samples == sum(plan.w[i].count for i in range(T))
     b, R = 0, R0
@@ -209,9 +210,9 @@ def test_clt_round_plans_equal_oracle(nat, oracle, table, case):
     for r in range(rounds):
         b1 = min(b + R, maxc)
         fams = nat.plan_families(q, n, round=r)[0]
-        for grp, fast in ((0, 1), (1, 0)):
+        for grp in (0, 1):  # group 0: the leader (fast worker 0, whose own samples decide rule A); group 1: every other worker
             want = [plan.w[i].first + np.arange(min(b, plan.w[i].count), min(b1, plan.w[i].count), dtype=np.uint64) * np.uint64(plan.w[i].step)
-                    for i in range(T) if plan.w[i].is_fast == fast]
+                    for i in range(T) if plan.w[i].group == grp]
             want = np.sort(np.concatenate(want)) if want else np.zeros(0, np.uint64)
             assert np.array_equal(np.sort(expand(fams, group=grp)), want), (r, grp)
         # sharded: union over 3 shards equals the whole round

@@ -102,6 +102,27 @@ def test_hundred_million_rows_index_sets(oracle, golden):
         _check_call(oracle, rows, call, 100_000_000)
 
 
+@pytest.mark.parametrize("n", [1_000_000, 10_000_000])
+def test_clt_leader_stops_where_the_reference_fast_worker_stopped(oracle, golden, table, n):
+    """Exact parity of the stop point in the race-free regime: with T = 2 the reference has ONE fast thread (golden
+    clt_fast_stop records how many rows it had taken when its own statistics satisfied DB.cpp:936-961).  The restatement's
+    leader judges its own samples at the reference's cadence (every check_interval rows): it must stop on the very same
+    row count — at 1 M rows and at the bench's 10 M — and in the converging regime of the CLI's call (T = 4) the rows
+    collected must lie within what the reference's 30 recorded runs show."""
+    rows = table(n)
+    T = golden["tables"][str(n)]
+    for g in T["clt_fast_stop"]:
+        rc, res, _ = oracle.clt_run(rows, g["pct"], 0.95, g["check_interval"], 2, g["e"])
+        assert rc == 0 and res.converged == 1
+        assert res.fast.n == g["n_fast_at_stop"] and res.rounds == g["n_fast_at_stop"] // g["check_interval"], (g, res.fast.n)
+    runs = T["distributions"]["clt_e1_pct20_T4"]
+    base4 = int(n * 0.2) // 4
+    ref_collected = [r["n"] - base4 for r in runs]
+    rc, res, _ = oracle.clt_run(rows, 20.0, 0.95, 10, 4, 1.0)
+    assert rc == 0 and res.converged == 1 and res.topup == base4
+    assert min(ref_collected) <= res.final.n - res.topup <= max(ref_collected), (res.final.n - res.topup, min(ref_collected), max(ref_collected))
+
+
 def test_clt_fast_worker_stop_points(oracle, golden, table):
     """DB.cpp:936-961 decision function, pinned by where the reference's single fast worker stopped."""
     rows = table(1_000_000)
@@ -127,22 +148,26 @@ def test_clt_round_synchronous_reference_cadence_single_fast(oracle, golden, tab
     the decision scan above for the reference and here check the oracle's own driver is consistent with
     its decision function at R0 = check_interval."""
     rows = table(100_000)
-    rc, res, idx = oracle.clt_run(rows, 20.0, 0.95, 10, 4, 2.0, want_idx=True)
+    rc, res, idx = oracle.clt_run(rows, 20.0, 0.95, 10, 4, 5.0, want_idx=True)
     assert rc == 0 and res.converged == 1
     z = oracle.lib.aqo_clt_zscore(0.95)
-    # replay: after every round of 10 samples per worker, the pooled rule must first fire at res.rounds
+    # replay: after every round of 10 samples per worker, the rule on the LEADER's own samples (fast worker 0, group 0)
+    # must first fire at res.rounds; every worker has contributed the same rounds by then
     rc2, plan = oracle.clt_plan(len(rows), 20.0, 0.95, 10, 4)
-    vals = []
+    vals, lead = [], []
     fired = None
     for r in range(res.rounds):
         for w in range(plan.n_workers):
             wk = plan.w[w]
             for k in range(r * 10, min((r + 1) * 10, wk.count)):
-                vals.append(rows["amount"][wk.first + k * wk.step])
-        v = np.array(vals)
+                x = rows["amount"][wk.first + k * wk.step]
+                vals.append(x)
+                if wk.group == 0:
+                    lead.append(x)
+        v = np.array(lead)
         mean = float(v.sum() / len(v))
-        var = float(((v - mean) ** 2).sum() / (len(v) - 1))
-        if oracle.lib.aqo_clt_fast_rule(len(v), mean, var, z, 2.0):
+        var = float(((v - mean) ** 2).sum() / (len(v) - 1)) if len(v) > 1 else 0.0
+        if len(v) >= 30 and oracle.lib.aqo_clt_fast_rule(len(v), mean, var, z, 5.0):
             fired = r + 1
             break
     assert fired == res.rounds
@@ -170,17 +195,16 @@ def test_clt_distribution_of_reference_runs(oracle, golden, table):
     # sample counts: reference returns collected + base/4 top-up (DB.cpp:1032-1040) => >= base/4
     assert min(r["n"] for r in runs) >= 50_000 and res.final.n >= 50_000
     # Rows COLLECTED before the stop (pre-top-up).  The reference stops when ONE fast thread's own statistics satisfy
-    # the rule (n_fast ~ 12.4 k at e = 1 %, golden clt_fast_stop) while the other threads have collected whatever the
-    # race let them: 395 ... 49 885 rows over its 30 runs (about T x 12.4 k when all four run at full speed).  The
-    # round-synchronous restatement judges the POOLED triple — the "(n, S, Q) all-reduce per convergence step" of the
-    # north star — so it stops once the pool holds ~12.7 k rows: fewer rows than the reference's typical run, inside
-    # the range its runs actually show.  (Either way the returned sample is dominated by the base/4 top-up.)
+    # the rule (n_fast = 12 390 at e = 1 %, golden clt_fast_stop) while the other threads have collected whatever the
+    # race let them: 395 ... 49 885 rows over its 30 runs at 1 M rows — T x 12 390 = 49 560 when all four run at full
+    # speed.  The round-synchronous restatement lets the LEADER (fast worker 0) judge its own samples and gives every
+    # worker the same number of rows per round: it stops with exactly T x n_fast rows, inside the reference's range.
     base4 = 200_000 // 4
     ref_collected = [r["n"] - base4 for r in runs]
     ours = res.final.n - res.topup
     assert res.topup == base4 and min(ref_collected) <= ours <= max(ref_collected), (ours, min(ref_collected), max(ref_collected))
     fast_alone = next(g_["n_fast_at_stop"] for g_ in golden["tables"]["1000000"]["clt_fast_stop"] if g_["e"] == 1.0 and g_["pct"] == 20.0)
-    assert 0.8 * fast_alone <= ours <= 1.25 * fast_alone  # the pool needs what one fast worker needs: the rule is the same test
+    assert ours == 4 * fast_alone and res.fast.n == fast_alone and res.rounds == fast_alone // 10
 
 
 def test_random_device_reducers_are_statistically_consistent(oracle, golden, table):
