@@ -6,6 +6,7 @@ The Engine owns an ``aqe_ctx``; every number it returns was computed by the HIP 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -28,6 +29,7 @@ class Plan:
         self.query = query
         self._h = C.c_void_p()
         nat.check(nat.lib().aqe_plan_create(engine._h, C.byref(query), C.byref(self._h)), engine._h)
+        engine._plans.add(self)
         r, t = C.c_uint32(), C.c_int32()
         nat.check(nat.lib().aqe_plan_rounds(self._h, C.byref(r), C.byref(t)), engine._h)
         self.rounds, self.has_topup = r.value, bool(t.value)
@@ -115,6 +117,7 @@ class Batch:
         arr = (C.c_void_p * len(self.plans))(*[p._h for p in self.plans])
         self._h = C.c_void_p()
         nat.check(nat.lib().aqe_batch_create(arr, len(self.plans), C.byref(self._h)), self.engine._h)
+        self.engine._batches.add(self)
 
     def close(self):
         if self._h:
@@ -173,6 +176,7 @@ class Comm:
         n, r = C.c_int(), C.c_int()
         nat.check(nat.lib().aqe_comm_info(self._h, C.byref(n), C.byref(r)), engine._h)
         self.nranks, self.rank = n.value, r.value
+        engine._comms.add(self)
 
     @staticmethod
     def unique_id() -> bytes:
@@ -225,10 +229,16 @@ class Engine:
         if rc != nat.OK:
             nat.check(rc, None)
         self._keepalive = None  # tensors adopted through attach_device
+        # what was made on this context and is still alive: a context goes only after them (batches before their plans),
+        # whatever order the caller — or a garbage collector after a failed test — lets go of things in
+        self._plans, self._batches, self._comms = weakref.WeakSet(), weakref.WeakSet(), weakref.WeakSet()
 
     # -- lifecycle --
     def close(self):
         if self._h:
+            for group in (self._batches, self._comms, self._plans):
+                for obj in list(group):
+                    obj.close()
             nat.lib().aqe_destroy(self._h)
             self._h = C.c_void_p()
 
