@@ -2,7 +2,7 @@
 //
 // The reference merges its workers inside one process — a mutex-guarded vector, future.get() concatenation, a CAS loop
 // on atomic<double> (custom_bplus_db.cpp:948-951, 966-967, 2031-2036).  Across GPUs the same merge is ONE all-reduce
-// SUM of (n, S - c n, Q) x {fast, slow} per convergence step — or per batch of queries (aqe_batch_run_sharded).
+// SUM of (n, S - c n, Q) x {leader, others} per convergence step — or per batch of queries (aqe_batch_run_sharded).
 // The library has no link-time dependency on RCCL: librccl is opened on first use (the copy already loaded into the
 // process, e.g. PyTorch's, is taken when there is one), so single-GPU users never load it.
 #include <dlfcn.h>

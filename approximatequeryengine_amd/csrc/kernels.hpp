@@ -54,8 +54,8 @@ struct DevFamily {
 // decision, and the should_stop flag later launches test on entry.
 struct QueryState {
     // shifted sums (n, sum(x-c), sum (x-c)^2): additive, so folds are exact re-groupings
-    double n_a, sd_a, qd_a;    // group a: fast pointers (or every sample of a non-CLT query)
-    double n_b, sd_b, qd_b;    // group b: slow pointers
+    double n_a, sd_a, qd_a;    // group a: the CLT leader, fast worker 0 (or every sample of a non-CLT query)
+    double n_b, sd_b, qd_b;    // group b: every other CLT worker
     double n_p, sd_p, qd_p;    // pooled a+b, plus the top-up
     double visited;            // samples drawn (>= n_p when a WHERE filter drops some)
     double topup;              // rows added by the top-up

@@ -10,7 +10,7 @@
 //     round order and sweeper v (of V) owns tiles v, v+V, v+2V, ...  Waves never wait for each other: while
 //     round r is being judged the chip is already sweeping rounds r+1, r+2...
 //   * when the last wave of a workgroup leaves round r it sums the workgroup's waves through LDS and publishes
-//     the workgroup's partial (n, S-c n, Q) x {fast, slow} into its slot of a flat list (round order), drains
+//     the workgroup's partial (n, S-c n, Q) x {leader, others} into its slot of a flat list (round order), drains
 //     the stores, then writes the slot's flag word (= the launch's epoch).  No counters, no atomics.
 //   * the MONITOR is wave 0 of workgroup 0; it sweeps nothing.  It rehearses its fold once (instruction cache)
 //     and then polls the flag words of the flat list from the first unjudged round on (4 loads per lane); the longest

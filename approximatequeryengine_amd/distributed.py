@@ -1,5 +1,5 @@
 """distributed.py — one process per GPU; the table is sharded by contiguous row region and every
-convergence step costs exactly one all-reduce of the moment vector (n, Σ(x-c), Σ(x-c)²)×{fast, slow}.
+convergence step costs exactly one all-reduce of the moment vector (n, Σ(x-c), Σ(x-c)²)×{leader, others}.
 
 The reference merges its workers through a mutex-guarded vector, a CAS loop on atomic<double> and an
 atomic<bool> stop flag (custom_bplus_db.cpp:948-951, 966-967, 2031-2036).  Here each rank sweeps the
