@@ -358,7 +358,7 @@ __device__ __forceinline__ void sweep_family(const SweepCommon& a, const Fam& F,
         TileAcc ta, tb;
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) { accumulate(ta, va[k], oka[k], a); accumulate(tb, vb[k], okb[k], a); }
-        merge_tile(acc, ta, false);  // (only the leader's region is paired: its fast pointer is group a, planner.cpp)
+        merge_tile(acc, ta, F.group != 0);  // (the first pointer is the leader's only in the leader's region)
         merge_tile(acc, tb, true);
         return;
     }

@@ -492,9 +492,7 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
                     const W& w = ws[static_cast<size_t>(t)];
                     u64 lo, hi;
                     window(w, lo, hi);
-                    // (only the leader's region is paired — fast worker 0 into group a, its slow twin into group b; in the other
-                    //  regions both pointers belong to group b and go out as two plain families)
-                    if (pairable && t == 0 && t < F && ws[static_cast<size_t>(F + t)].step == w.step) {
+                    if (pairable && t < F && ws[static_cast<size_t>(F + t)].step == w.step) {
                         const W& v = ws[static_cast<size_t>(F + t)];
                         u64 lo2, hi2;
                         window(v, lo2, hi2);
@@ -506,7 +504,7 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
                         clip_push(rf, f, shard);
                         continue;
                     }
-                    if (pairable && t == F && F > 0 && ws[0].step == w.step) continue;  // emitted with its fast twin (the leader)
+                    if (pairable && t >= F && ws[static_cast<size_t>(t - F)].step == w.step) continue;  // emitted with its fast twin
                     if (hi <= lo) continue;
                     aqe_family f = strided(w.first, w.step, w.count, w.group);
                     f.ord_lo = lo;
