@@ -464,11 +464,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                     // the head form sweeps it along with the rounds, as one more slot, and the monitor adds it when due.
                     // (Measured, bench query at e = 1 %: 230 k aggregates/s and 14 us per launch, against 76-100 k for
                     // one launch per round replayed as a graph, which is what such plans used before.)
-                    // The round of margin is dropped when the predicted rounds already give the leader half as many rows
-                    // again as the rule needs — the rows needed go with cv^2, so that is 22 % of slack in a cv estimated from
-                    // a thousand rows to 2-3 %; a geometric schedule makes the extra round cost as much as all before it.
-                    const bool roomy = leader >= 1.5 * n_stop;
-                    const size_t r_head = std::min(R, r_stop + (roomy ? 0 : 1));
+                    const size_t r_head = std::min(R, r_stop + 1);
                     p->r_head = r_head;
                     // Attempts, in order: rounds + top-up on one tile per wave; the same on half the largest grid when that many
                     // workgroups' partials would not fit the monitor's one window of steps and the top-up is small enough
