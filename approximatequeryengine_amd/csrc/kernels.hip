@@ -481,6 +481,11 @@ inline unsigned grid_for(u64 work_items, u64 per_block) {
 
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     unsigned grid = grid_for(a.ntiles, kWavesPerBlock);
+    // Four workgroups per compute unit, all resident at once (the kernel's registers allow five): 4096 waves hold 32 MB of
+    // loads in flight, several times what the memory system needs.  Twice as many workgroups queue for a second turn, and
+    // a launch only starts them as the first ones end: 10 M rows exact 25.4 -> 20.5 us, 100 M rows stride 20 % 36.0 -> 32.3 us
+    // (A/B on one box, tools/ab_latency.py).
+    if (grid > kRoundGridCap) grid = kRoundGridCap;
     // with events: they take the dispatch's own begin/end timestamps (what rocprofv3 reports as the kernel's duration)
     if (a.sw.nt) {
         if (ev0) hipExtLaunchKernelGGL(k_round<true>, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);

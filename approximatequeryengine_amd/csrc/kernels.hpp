@@ -24,6 +24,7 @@ inline uint64_t tile_ordinals(uint64_t step, uint32_t flags, uint64_t seg_len) {
 // a tile spanning several segments, instead of one mostly idle tile per segment.
 constexpr uint32_t kFamLinear = 1u << 8;
 constexpr int kMaxBlocks = 2048;            // 8 workgroups per CU on 256 CUs
+constexpr unsigned kRoundGridCap = 1024;    // k_round: 4 workgroups per CU (launch_round)
 constexpr int kVec = AQE_MOMENT_VEC;
 // Arrival tickets are sharded: a same-address device atomic costs ~20 ns and serialises, so 2048
 // workgroups on one counter would spend 40 us arriving.  Workgroup b draws from shard b % kShards (each on
