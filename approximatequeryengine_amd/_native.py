@@ -25,7 +25,9 @@ Q_NO_PERSIST = 2
 Q_FORCE_PERSIST = 4
 Q_NO_LAYOUT = 8
 Q_SHARE_GPU = 16
-Q_FORCE_PERSIST = 4
+Q_NO_LEAN = 32
+KERNEL_ROUND, KERNEL_SWEEP_PERSIST, KERNEL_SWEEP_LEAN, KERNEL_SWEEP_MULTI = 0, 1, 2, 3
+KERNEL_NAMES = {0: "k_round", 1: "k_sweep_persist", 2: "k_sweep_lean", 3: "k_sweep_multi"}
 F_TOPUP = 1
 F_PAIR = 2
 STAGE_KEEP_AOS = 1
@@ -176,6 +178,7 @@ def lib() -> C.CDLL:
         "aqe_plan_set_profiling": (C.c_int, [vp, C.c_int]),
         "aqe_plan_launch_ms": (C.c_int, [vp, P(C.c_float), u32, P(u32)]),
         "aqe_plan_launch_samples": (C.c_int, [vp, P(u64), u32, P(u32)]),
+        "aqe_plan_last_kernel": (C.c_int, [vp, P(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -142,6 +142,11 @@ struct SweepForm {
     uint32_t grid = 0;        // workgroups of the launch (a power of two)
     uint32_t more_rounds = 0; // the form ends before the plan's last round (the head form)
     uint32_t topup_slot = 0;  // the last slot is the plan's top-up
+    // the lean variant of the form (lean.hip, k_sweep_lean), when the plan qualifies: its own tile list (runs), its own
+    // unpadded slot list; d_ppart then holds [slots][kVec] partials followed by the run table
+    bool lean = false;
+    aqe::LeanRuns* d_runs = nullptr;
+    uint32_t slot_begin[aqe::kMaxPersistRounds + 1] = {0};
 };
 
 struct aqe_plan {
@@ -175,6 +180,7 @@ struct aqe_plan {
     // slot written out — the multi-GPU form: ONE all-reduce of the slot totals, then k_replay decides.
     bool persist = false;
     SweepForm decide, totals;
+    SweepForm decide_lean, totals_lean, head_lean;  // their lean variants (lean.hip), ok when the plan qualifies
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
     const double* view_rounds = nullptr;  // stride-major view the rounds' families index (nullptr: the column itself)
     const double* view_topup = nullptr;   // ... and the top-up's
@@ -189,6 +195,7 @@ struct aqe_plan {
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals
+    int last_kernel = 0;  // ... and the kernel that swept it (AQE_KERNEL_*)
     uint32_t last_first_unswept = 0;  // ... and the first round that form (the plan's own, or a batch's group form) did NOT sweep
     size_t r_head = 0;          // rounds the head form covers (per_round plans)
     // optional per-launch timing (aqe_plan_set_profiling): one event pair around every sweep launch

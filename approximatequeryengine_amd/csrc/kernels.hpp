@@ -196,6 +196,39 @@ hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream
 // described; its epoch field is ignored), wg_map[b] = q << 32 | group size << 16 | index within the group for workgroup b.
 hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, bool nt,
                               hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
+// ---- lean single-launch sweep of a multi-round query whose whole sweep is in flight at once: lean.hip -------------
+// A RUN is a family in its simplest form: `rows` consecutive rows of the column (or of a stride-major view) that all
+// belong to the sample — what exact scans, blocks of one segment and every strided pointer read through a view come to.
+constexpr int kLeanMaxRuns = 64;                                        // one run per lane of a wave
+constexpr int kLeanMaxSlots = kMaxPersistGrid + kMaxPersistRounds;      // a round boundary splits at most one workgroup
+struct LeanRuns {  // in device memory, structure of arrays: lane i of every wave holds run i in registers
+    uint64_t row0[kLeanMaxRuns];        // first row, relative to LeanLaunch::amount
+    uint32_t tile_begin[kLeanMaxRuns];  // first tile of the run in the launch's tile list; 0xffffffff past the table
+    uint32_t rows[kLeanMaxRuns];
+    uint32_t meta[kLeanMaxRuns];        // round | group << 8
+    uint32_t slot[kLeanMaxRuns];        // of the run's round: first slot | first workgroup of its cyclic run << 16
+};
+struct LeanLaunch {
+    const double* amount;
+    const LeanRuns* runs;
+    uint32_t ntiles, rounds;
+    int32_t has_where, pad0;
+    double wmin, wmax, shift;
+    uint32_t slot_begin[kMaxPersistRounds + 1];  // round r owns the slots [slot_begin[r], slot_begin[r + 1]) of the flat list
+    double* partials;          // [slots][kVec]: doubles 0..6 = a workgroup's partial of one round
+    unsigned* counter;         // arrival tickets (k_round's), zero between launches
+    double* out_totals;        // totals_only: [rounds][kVec]
+    QueryState* state;
+    FoldParams fold;
+    FinalizeParams fin;
+    aqe_result* result;
+    unsigned long long* result_seq;
+    unsigned long long epoch;
+    uint32_t finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only;  // as in PersistLaunch
+};
+hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);
 

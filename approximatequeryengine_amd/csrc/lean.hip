@@ -1,0 +1,329 @@
+// lean.hip — k_sweep_lean: a multi-round (CLT) query in ONE launch when the whole sweep is in flight at once.
+//
+// The reference's monitor (custom_bplus_db.cpp:885-1043) re-evaluates its rules while the pointer threads are still
+// walking, so that they can stop early (DB.cpp:930, 987).  k_sweep_persist (persist.hip) keeps that shape: a monitor
+// wave judges rounds as they complete and raises should_stop.  On a table of 10 M rows there is nothing left to stop:
+// every wave holds its one or two tiles in flight from the first microsecond, the sweep is over after five, and what
+// the query then waits for is the hand-off.  This kernel is for those queries (plans.hip picks it: at most two tiles per
+// wave, every family a plain run of rows) and is built for a short critical path:
+//
+//   * no monitor wave, no polling, no stop word: every wave sweeps; a workgroup publishes ONE 56-byte partial per
+//     round it swept tiles of (sc1 stores, drained) and draws ONE ticket (k_round's sharded counters);
+//   * the workgroup that draws the last ticket reads the flat partial list — at most 288 slots — with all of its
+//     16 waves, sums every round's slots in a fixed order (bit-reproducible), and wave 0 then judges EVERY round at
+//     once, lane q evaluating the rules on the moments through round q (DB.cpp:936-961, 993-1016).  The first round
+//     that satisfies a rule — or the last — is the query's answer: a decision is a pure function of the partials, so
+//     the rounds swept beyond it change nothing (and cost nothing that was not already in flight);
+//   * the tile decode is a dozen instructions: lane i of every wave holds run i of the plan in registers (one batch of
+//     loads in the prologue), the run of a tile is found by one wave-wide comparison and read with v_readlane; tiles
+//     that lie inside their run — all but a run's last — take no masks.  (k_sweep_persist spent ~500 vector
+//     instructions per tile on window arithmetic: with four waves per SIMD the first tile of a 10 M-row query was
+//     folded after 3.3 us and the last after 8.3; here after 0.4 and 3.7 — tools/exp_latency.hip.)
+//
+// Same forms as the persistent sweep (PersistLaunch): decisions in the kernel, the head form (rounds + the top-up as
+// one more slot, `more_rounds`), totals only (multi-GPU: every slot's total for the all-reduce).
+#include <hip/hip_ext.h>
+
+#include "device_common.hpp"
+
+namespace aqe {
+namespace {
+
+#define AQE_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+typedef const AQE_KARG LeanLaunch* LeanKarg;
+
+__device__ __forceinline__ void lean_state_store(QueryState* g, const QueryState& st) {
+    static_assert(sizeof(QueryState) % 8 == 0, "state is moved as 8-byte words");
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&st);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(g);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(QueryState) / 8; ++i) __hip_atomic_store(d + i, s[i], AQE_RLX);
+}
+
+__device__ __forceinline__ u64 read_lane_u64(u64 v, unsigned src_lane) {
+    const unsigned lo = __builtin_amdgcn_readlane(static_cast<unsigned>(v), src_lane);
+    const unsigned hi = __builtin_amdgcn_readlane(static_cast<unsigned>(v >> 32), src_lane);
+    return (static_cast<u64>(hi) << 32) | lo;
+}
+
+__device__ __forceinline__ u64* lean_t0_word(unsigned* counter) { return reinterpret_cast<u64*>(counter + kShards * kShardStride + 8); }
+
+struct __attribute__((packed, aligned(8))) Row2 { double x, y; };
+
+// One tile = up to 1024 consecutive rows from `base` (two rows per lane per 16-byte load, eight loads in flight);
+// `rem` rows of the run are left from `base` on.
+__device__ __forceinline__ void lean_tile(const double* base, unsigned rem, const double* safe, int lane, int has_where, double wmin, double wmax,
+                                          double shift, TileAcc& ta) {
+    Row2 v2[kTileUnroll];
+    if (rem >= static_cast<unsigned>(kDenseTileOrdinals)) {  // inside the run: no masks
+        const Row2* const p = reinterpret_cast<const Row2*>(base) + lane;
+#pragma unroll
+        for (int k = 0; k < kTileUnroll; ++k) v2[k] = p[k * 64];
+        ta.nv = 2u * kTileUnroll;
+        if (has_where) {
+#pragma unroll
+            for (int k = 0; k < kTileUnroll; ++k) {
+                const double x = v2[k].x, y = v2[k].y;
+                const bool px = x >= wmin && x <= wmax, py = y >= wmin && y <= wmax;  // inclusive both ends, DB.cpp:329
+                const double dx = px ? x - shift : 0.0, dy = py ? y - shift : 0.0;
+                ta.n += (px ? 1u : 0u) + (py ? 1u : 0u);
+                ta.s += dx; ta.q += dx * dx;
+                ta.s += dy; ta.q += dy * dy;
+            }
+        } else {
+            ta.n = 2u * kTileUnroll;
+#pragma unroll
+            for (int k = 0; k < kTileUnroll; ++k) {
+                const double dx = v2[k].x - shift, dy = v2[k].y - shift;
+                ta.s += dx; ta.q += dx * dx;
+                ta.s += dy; ta.q += dy * dy;
+            }
+        }
+        return;
+    }
+    // the run's last tile: rows past its end are masked (and never addressed: a lane whose pair leaves the run reads
+    // rows 0..1 of the column instead, then its one valid row by itself)
+    bool ok0[kTileUnroll], ok1[kTileUnroll];
+#pragma unroll
+    for (int k = 0; k < kTileUnroll; ++k) {
+        const unsigned r0 = 2u * static_cast<unsigned>(lane) + 128u * static_cast<unsigned>(k);
+        ok0[k] = r0 < rem;
+        ok1[k] = r0 + 1u < rem;
+        v2[k] = *reinterpret_cast<const Row2*>(ok1[k] ? base + r0 : safe);
+        if (!ok1[k]) {
+            v2[k].x = ok0[k] ? base[r0] : 0.0;
+            v2[k].y = 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kTileUnroll; ++k) {
+        const double x = v2[k].x, y = v2[k].y;
+        const bool px = ok0[k] && (!has_where || (x >= wmin && x <= wmax)), py = ok1[k] && (!has_where || (y >= wmin && y <= wmax));
+        const double dx = px ? x - shift : 0.0, dy = py ? y - shift : 0.0;
+        ta.nv += (ok0[k] ? 1u : 0u) + (ok1[k] ? 1u : 0u);
+        ta.n += (px ? 1u : 0u) + (py ? 1u : 0u);
+        ta.s += dx; ta.q += dx * dx;
+        ta.s += dy; ta.q += dy * dy;
+    }
+}
+
+// Wave 0 of the folding workgroup, lane q holding the moments through round q (or a slot's own total where the form
+// asks for that): the decision and the result.  The rules and what follows them are the monitor's (persist.hip,
+// monitor_fold), evaluated once, for every round at the same time.
+__device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], unsigned lane, unsigned* counter) {
+    const unsigned rounds = K->rounds;
+    const bool tslot = K->topup_slot != 0;  // the last slot is the top-up: summed on its own, never judged
+    const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
+    if (K->totals_only) {  // multi-GPU form: hand the slot totals out; the decision is taken after the all-reduce
+        if (lane < rounds) {
+            double* o = K->out_totals + static_cast<size_t>(lane) * kVec;
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc) o[cc] = tot[cc];
+            o[7] = 0.0;
+        }
+        return;
+    }
+    FoldParams fp;
+    fp.shift = K->fold.shift; fp.z = K->fold.z; fp.e = K->fold.e; fp.base = K->fold.base; fp.is_clt = K->fold.is_clt; fp.is_topup = 0; fp.pad = 0;
+    FinalizeParams fin;
+    fin.n_global = K->fin.n_global; fin.pct = K->fin.pct; fin.shift = K->fin.shift; fin.agg = K->fin.agg;
+    fin.convention = K->fin.convention; fin.is_exact = K->fin.is_exact; fin.is_clt = K->fin.is_clt;
+    const bool with_result = K->finalize_here != 0;
+    QueryState st{};
+    st.n_a = tot[0]; st.sd_a = tot[1]; st.qd_a = tot[2];
+    st.n_b = tot[3]; st.sd_b = tot[4]; st.qd_b = tot[5];
+    st.n_p = tot[0] + tot[3]; st.sd_p = tot[1] + tot[4]; st.qd_p = tot[2] + tot[5];
+    st.visited = tot[6];
+    double tup[7] = {0, 0, 0, 0, 0, 0, 0};  // the top-up slot's own total
+    if (tslot) {
+#pragma unroll
+        for (int cc = 0; cc < 7; ++cc) tup[cc] = read_lane_f64(tot[cc], static_cast<int>(rounds - 1u));
+    }
+    int code = 0;
+    aqe_result res{};
+    // every lane works its round's estimate out beside the rules: the two chains of f64 operations overlap (with a
+    // top-up slot the estimate depends on the decision and follows it)
+    const bool result_now = with_result && !tslot;
+    if (lane < rounds_j) {
+        if (fp.is_clt) code = clt_rules(tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], fp);
+        if (result_now) res = make_result(st, fin);
+    }
+    const unsigned long long stops = __ballot(code != 0);
+    const unsigned last_round = stops ? static_cast<unsigned>(__builtin_ctzll(stops)) : rounds_j - 1u;  // the rule holds after this round / samples exhausted
+    if (lane != last_round) return;
+    st.rounds = static_cast<int32_t>(last_round + 1u);
+    st.converged = code;
+    st.stop = code != 0;
+    // DB.cpp:1032: too few rows collected -> the top-up is due.  Swept with the rounds (head form): it is added here.
+    // Otherwise the result is marked and the host launches it (rarely due).
+    const bool goes_on = code == 0 && K->more_rounds;  // head form: out of rounds, not out of samples
+    bool due = K->topup_gate && st.n_p < static_cast<double>(fp.base / 4);
+    if (tslot && due && !goes_on) {  // the fold of a top-up vector (device_common.hpp, fold)
+        st.n_p += tup[0]; st.sd_p += tup[1]; st.qd_p += tup[2];
+        st.topup += tup[0];
+        st.visited += tup[6];
+        due = false;
+    }
+    if (with_result && !result_now) res = make_result(st, fin);
+    if (K->want_ticks) {
+        st.t0 = __hip_atomic_load(lean_t0_word(counter), AQE_RLX);
+        res.kernel_ms = static_cast<double>(__builtin_amdgcn_s_memrealtime() - st.t0) * 1e-5;
+    }
+    res.rounds = st.rounds;
+    res.converged = code;
+    res.topup_pending = goes_on ? 2 : due ? 1 : 0;  // 2: the host launches the plan's remaining rounds
+    lean_state_store(K->state, st);
+    if (with_result) {
+        *K->result = res;
+        // the host polls the pinned result instead of waiting for the end of the launch: the check word tells it when
+        // every field has landed (kernels.hpp, result_check)
+        __hip_atomic_store(K->result_seq, result_check(res, K->epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
+    __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];  // a wave's sums of a round (zero where it swept none)
+    __shared__ double lds_flat[kLeanMaxSlots * kVec];                     // the folding workgroup's copy of the partial list
+    __shared__ double lds_quarter[kMaxPersistRounds][kVec][4];
+    __shared__ double lds_round[kMaxPersistRounds][kVec];
+    __shared__ unsigned lds_slot[kMaxPersistRounds];
+    __shared__ unsigned lds_touched;
+    __shared__ int s_last;
+    const LeanKarg K = (LeanKarg)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = threadIdx.x >> 6;
+    // the run table: lane i holds run i.  One batch of loads, in flight while LDS is cleared.
+    const u64 my_row0 = a.runs->row0[lane];
+    const unsigned my_tb = a.runs->tile_begin[lane], my_rows = a.runs->rows[lane], my_meta = a.runs->meta[lane], my_slot = a.runs->slot[lane];
+    {
+        double* z = &lds_part[0][0][0];
+        constexpr unsigned kWords = kMaxPersistRounds * kPersistWaves * kVec;
+#pragma unroll
+        for (unsigned i = 0; i < kWords / kPersistThreads; ++i) z[threadIdx.x + i * kPersistThreads] = 0.0;
+        if (threadIdx.x == 0) lds_touched = 0;
+    }
+    if (a.want_ticks && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(lean_t0_word(a.counter), static_cast<u64>(__builtin_amdgcn_s_memrealtime()), AQE_RLX);
+    __syncthreads();
+
+    const unsigned V = gridDim.x * kPersistWaves;
+    const unsigned w = __builtin_amdgcn_readfirstlane(blockIdx.x * kPersistWaves + wave);
+    Acc acc;
+    unsigned cur = ~0u, cur_slot = 0;  // the round this wave is in
+    auto flush = [&]() {
+        const double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb, static_cast<double>(acc.nv)};
+        const double mine = wave_sum7(v, lane);  // lane 8c holds component c
+        if ((lane & 7) == 0 && lane < 56) lds_part[cur][wave][lane >> 3] = mine;
+        if (lane == 0) {
+            lds_slot[cur] = cur_slot;
+            __hip_atomic_fetch_or(&lds_touched, 1u << cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    for (unsigned t = w; t < a.ntiles; t += V) {
+        // the run that owns tile t: the last whose first tile is <= t (ascending; 0xffffffff past the table)
+        const unsigned i = static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb <= t))) - 1u;
+        const unsigned meta = __builtin_amdgcn_readlane(my_meta, i);
+        const unsigned r = meta & 0xffu;
+        if (r != cur) {
+            if (cur != ~0u) { flush(); acc = Acc{}; }
+            cur = r;
+            cur_slot = __builtin_amdgcn_readlane(my_slot, i);
+        }
+        const unsigned first = (t - __builtin_amdgcn_readlane(my_tb, i)) * static_cast<unsigned>(kDenseTileOrdinals);
+        const unsigned rem = __builtin_amdgcn_readlane(my_rows, i) - first;
+        const double* const base = a.amount + (read_lane_u64(my_row0, i) + first);
+        TileAcc ta;
+        lean_tile(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
+        merge_tile(acc, ta, ((meta >> 8) & 1u) != 0);
+    }
+    if (cur != ~0u) flush();
+    __syncthreads();
+
+    // ---- the workgroup's partial of every round it swept tiles of: data, drain, ticket (cdna_hip_programming.md G16) ----
+    if (wave == 0) {
+        unsigned m = __builtin_amdgcn_readfirstlane(lds_touched);
+        while (m) {
+            const unsigned r = static_cast<unsigned>(__builtin_ctz(m));
+            m &= m - 1u;
+            const unsigned info = lds_slot[r];
+            const unsigned first_wg = info >> 16;
+            const unsigned slot = (info & 0xffffu) + (blockIdx.x >= first_wg ? blockIdx.x - first_wg : blockIdx.x + gridDim.x - first_wg);
+            if (lane < 7) {
+                double x[kPersistWaves];
+#pragma unroll
+                for (unsigned j = 0; j < kPersistWaves; ++j) x[j] = lds_part[r][j][lane];  // all reads in flight at once
+                double s = 0.0;
+#pragma unroll
+                for (unsigned j = 0; j < kPersistWaves; ++j) s += x[j];  // wave order
+                __hip_atomic_store(a.partials + static_cast<size_t>(slot) * kVec + lane, s, AQE_RLX);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partials are out before the ticket is drawn
+        if (lane == 0) {
+            int last = 0;
+            const unsigned G = gridDim.x;
+            unsigned* const ct = a.counter + static_cast<size_t>(kShards) * kShardStride;
+            if (G <= static_cast<unsigned>(kShards)) {
+                if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) == G - 1u) { __hip_atomic_store(ct, 0u, AQE_RLX); last = 1; }
+            } else {
+                const unsigned sh = blockIdx.x % static_cast<unsigned>(kShards);
+                const unsigned members = (G - sh + static_cast<unsigned>(kShards) - 1u) / static_cast<unsigned>(kShards);
+                unsigned* const cs = a.counter + static_cast<size_t>(sh) * kShardStride;
+                if (__hip_atomic_fetch_add(cs, 1u, AQE_RLX) == members - 1u) {
+                    __hip_atomic_store(cs, 0u, AQE_RLX);
+                    if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) == static_cast<unsigned>(kShards) - 1u) { __hip_atomic_store(ct, 0u, AQE_RLX); last = 1; }
+                }
+            }
+            s_last = last;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    // ---- the last workgroup to arrive folds the launch: every wave loads, sums in a fixed order ----
+    const unsigned rounds = K->rounds;
+    const unsigned nwords = K->slot_begin[rounds] * static_cast<unsigned>(kVec);
+    for (unsigned i = threadIdx.x; i < nwords; i += kPersistThreads) lds_flat[i] = __hip_atomic_load(a.partials + i, AQE_RLX);
+    __syncthreads();
+    {   // thread (q, c, quarter): every fourth slot of round q, component c
+        const unsigned q = threadIdx.x >> 5, c = (threadIdx.x >> 2) & 7u, part = threadIdx.x & 3u;
+        if (q < rounds && c < 7u) {
+            const unsigned b = K->slot_begin[q], e = K->slot_begin[q + 1u];
+            double s = 0.0;
+            for (unsigned sl = b + part; sl < e; sl += 4u) s += lds_flat[sl * static_cast<unsigned>(kVec) + c];
+            lds_quarter[q][c][part] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxPersistRounds * kVec) {
+        const unsigned q = threadIdx.x >> 3, c = threadIdx.x & 7u;
+        if (q < rounds && c < 7u) lds_round[q][c] = ((lds_quarter[q][c][0] + lds_quarter[q][c][1]) + lds_quarter[q][c][2]) + lds_quarter[q][c][3];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // lane q: the moments through round q (a slot's own total in the totals form, and for the top-up slot)
+    const bool tslot = K->topup_slot != 0;
+    const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
+    const bool own = K->totals_only != 0 || (tslot && static_cast<unsigned>(lane) == rounds - 1u);
+    double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (unsigned r = 0; r < rounds; ++r) {
+        const bool take = own ? r == static_cast<unsigned>(lane) : (r <= static_cast<unsigned>(lane) && r < rounds_j);
+#pragma unroll
+        for (int cc = 0; cc < 7; ++cc) {
+            const double x = lds_round[r][cc];
+            tot[cc] += take ? x : 0.0;
+        }
+    }
+    lean_judge(K, tot, static_cast<unsigned>(lane), a.counter);
+}
+
+}  // namespace
+
+hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) hipExtLaunchKernelGGL(k_sweep_lean, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL(k_sweep_lean, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace aqe

@@ -28,7 +28,7 @@ void destroy_plan(aqe_plan* p) {
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
     if (p->d_fams_small) (void)hipFree(p->d_fams_small);
-    for (SweepForm* f : {&p->decide, &p->totals, &p->head}) {
+    for (SweepForm* f : {&p->decide, &p->totals, &p->head, &p->decide_lean, &p->totals_lean, &p->head_lean}) {
         if (f->d_ppart) (void)hipFree(f->d_ppart);  // (the form's family table lives in the same block)
     }
     if (p->d_state) (void)hipFree(p->d_state);
@@ -181,7 +181,7 @@ hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStr
 
 int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, hipStream_t s, unsigned long long epoch = 0) {
     aqe_ctx* c = p->ctx;
-    if (!topup && index == 0) p->last_exec = 0;
+    if (!topup && index == 0) { p->last_exec = 0; p->last_kernel = AQE_KERNEL_ROUND; }
     if (!epoch) p->poll_epoch = 0;  // this launch writes no check word: whatever it finishes is fetched the ordinary way
     RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec, epoch);
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
@@ -278,6 +278,103 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), init.size() * sizeof(uint64_t)));
     HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     F.d_fams = F.h_fams.empty() ? nullptr : reinterpret_cast<DevFamily*>(reinterpret_cast<uint64_t*>(F.d_ppart) + ppart_words);  // (inside d_ppart's block: never freed on its own)
+    F.ok = true;
+    return AQE_OK;
+}
+
+
+// The lean variant of a form (lean.hip, k_sweep_lean): for a plan whose families are all plain runs of rows and whose
+// whole sweep is in flight at once (at most kLeanTilesPerWave tiles per wave).  Its own tile list — a run is tiled from
+// its first row — and its own slot list, unpadded: round r owns one slot per workgroup that sweeps tiles of it.
+// Leaves F.ok false (and returns AQE_OK) when the plan does not qualify.
+constexpr uint64_t kLeanTilesPerWave = 2;
+
+int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t grid, size_t nrounds) {
+    aqe_ctx* c = p->ctx;
+    static const long max_tiles_per_wave = [] { const char* e = std::getenv("AQE_LEAN_TILES_PER_WAVE"); return e ? std::atol(e) : static_cast<long>(kLeanTilesPerWave); }();
+    if (max_tiles_per_wave <= 0 || !c->dense16 || grid == 0 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;
+    std::vector<const LaunchDesc*> slots;
+    for (size_t r = 0; r < nrounds; ++r) slots.push_back(&p->rounds[r]);
+    const bool tslot = with_topup_slot && p->host.has_topup;
+    if (tslot) slots.push_back(&p->topup);
+    const size_t S = slots.size();
+    if (S == 0 || S > static_cast<size_t>(kMaxPersistRounds)) return AQE_OK;
+    const SweepCommon sw_r = sweep_common(p, nullptr, 0, false), sw_t = sweep_common(p, nullptr, 0, true);
+    const int64_t base_gap = static_cast<int64_t>(reinterpret_cast<uintptr_t>(sw_t.amount) - reinterpret_cast<uintptr_t>(sw_r.amount)) / 8;  // rows (build_sweep_form)
+    LeanRuns runs{};
+    for (int i = 0; i < kLeanMaxRuns; ++i) runs.tile_begin[i] = 0xffffffffu;
+    uint32_t nruns = 0;
+    uint64_t tiles = 0, samples = 0;
+    uint64_t round_begin[kMaxPersistRounds + 1] = {0};
+    for (size_t r = 0; r < S; ++r) {
+        const LaunchDesc& L = *slots[r];
+        const bool is_topup = slots[r] == &p->topup;
+        const SweepCommon& sw = is_topup ? sw_t : sw_r;
+        round_begin[r] = tiles;
+        for (uint32_t i = 0; i < L.nfam; ++i) {
+            const DevFamily& d = p->h_fams[L.fam_offset + i];
+            // a plain run: one pointer, step 1, its window inside one segment
+            if (!is_dense16(d.step, d.flags, d.seg_len) || (d.flags & kFamLinear) || d.tiles_per_seg != 0 || d.ord_hi <= d.ord_lo) return AQE_OK;
+            const uint64_t len = d.ord_hi - d.ord_lo;
+            if (nruns == static_cast<uint32_t>(kLeanMaxRuns) || len >= 0xffffffffull) return AQE_OK;
+            // row of ordinal o: row0 + seg pitch - shard_lo + (o - seg seg_len)   (device_common.hpp, sweep_family; wraps like it)
+            uint64_t row = d.row0 + d.seg_lo * d.pitch - sw.shard_lo + d.ord_lo - d.seg_lo * d.seg_len;
+            if (is_topup) row += static_cast<uint64_t>(base_gap);  // one launch has one column base: the rounds'
+            runs.row0[nruns] = row;
+            runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
+            runs.rows[nruns] = static_cast<uint32_t>(len);
+            runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
+            tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
+            samples += len;
+            ++nruns;
+        }
+        if (tiles == round_begin[r]) return AQE_OK;  // a slot without tiles: the other forms deal with it
+    }
+    round_begin[S] = tiles;
+    const uint64_t G = grid, V = G * kPersistWaves;
+    if (tiles >= 0xffffffffull || tiles > static_cast<uint64_t>(max_tiles_per_wave) * V) return AQE_OK;
+    // wave v owns tiles v, v + V, ...: the workgroups with tiles of a slot form one cyclic run of ids (build_sweep_form)
+    auto wave_has = [&](uint64_t v, uint64_t b0, uint64_t b1) { const uint64_t m0 = b0 % V; return b0 + (v >= m0 ? v - m0 : v + V - m0) < b1; };
+    uint32_t part_first[kMaxPersistRounds] = {0};
+    for (size_t r = 0; r < S; ++r) {
+        std::vector<char> member(G, 0);
+        uint64_t members = 0;
+        for (uint64_t b = 0; b < G; ++b) {
+            for (uint64_t j = 0; j < kPersistWaves && !member[b]; ++j)
+                if (wave_has(b * kPersistWaves + j, round_begin[r], round_begin[r + 1])) member[b] = 1;
+            members += member[b];
+        }
+        uint64_t first = 0;
+        if (members != 0 && members != G) {
+            uint64_t starts = 0;
+            for (uint64_t b = 0; b < G; ++b)
+                if (member[b] && !member[(b + G - 1) % G]) { first = b; ++starts; }
+            if (starts != 1) return fail(c, AQE_ERR_INVALID, "internal: lean-sweep participation is not one cyclic run");
+        }
+        for (uint64_t i = 0; i < members; ++i)
+            if (!member[(first + i) % G]) return fail(c, AQE_ERR_INVALID, "internal: lean-sweep participation is not one cyclic run");
+        part_first[r] = static_cast<uint32_t>(first);
+        F.slot_begin[r + 1] = F.slot_begin[r] + static_cast<uint32_t>(members);
+    }
+    if (F.slot_begin[S] > static_cast<uint32_t>(kLeanMaxSlots)) return AQE_OK;
+    for (uint32_t i = 0; i < nruns; ++i) {
+        const uint32_t r = runs.meta[i] & 0xffu;
+        runs.slot[i] = F.slot_begin[r] | (part_first[r] << 16);
+    }
+    // ONE allocation and ONE copy: [partials, zero][run table]
+    const size_t ppart_words = static_cast<size_t>(kVec) * F.slot_begin[S];
+    std::vector<uint64_t> init(ppart_words + (sizeof(LeanRuns) + 7) / 8, 0);
+    std::memcpy(init.data() + ppart_words, &runs, sizeof(LeanRuns));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), init.size() * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    F.d_runs = reinterpret_cast<LeanRuns*>(reinterpret_cast<uint64_t*>(F.d_ppart) + ppart_words);
+    F.lean = true;
+    F.slots = static_cast<uint32_t>(S);
+    F.ntiles = tiles;
+    F.samples = samples;
+    F.grid = grid;
+    F.more_rounds = nrounds < p->rounds.size() ? 1u : 0u;
+    F.topup_slot = tslot ? 1u : 0u;
     F.ok = true;
     return AQE_OK;
 }
@@ -437,6 +534,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         for (size_t r = 0; r < R; ++r) every_round_has_tiles = every_round_has_tiles && p->rounds[r].ntiles > 0;
         if (multi && whole && every_round_has_tiles && R <= static_cast<size_t>(kMaxPersistRounds) && !(q->flags & AQE_Q_NO_PERSIST)) {
             int rc2 = build_sweep_form(p.get(), false, p->decide, p->grid, R);
+            if (rc2 == AQE_OK) rc2 = build_lean_form(p.get(), false, p->decide_lean, p->grid, R);
             if (rc2 != AQE_OK) return rc2;
             p->persist = true;
             // The single launch sweeps every round speculatively: right when the query runs (almost) to the end, a waste
@@ -489,6 +587,8 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                         // (with the top-up the monitor judges once, from one window of steps)
                         if (rc2 == AQE_OK && !(at.topup && F.step_begin[F.slots] > static_cast<uint32_t>(kDecSteps))) {
                             p->head = std::move(F);
+                            rc2 = build_lean_form(p.get(), at.topup, p->head_lean, g, r_head);
+                            if (rc2 != AQE_OK) return rc2;
                             break;
                         }
                         if (F.d_ppart) (void)hipFree(F.d_ppart);
@@ -499,6 +599,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         }
         if (multi && R <= static_cast<size_t>(kMaxPersistRounds)) {
             int rc2 = build_sweep_form(p.get(), false, p->totals, p->grid, R);
+            if (rc2 == AQE_OK) rc2 = build_lean_form(p.get(), false, p->totals_lean, p->grid, R);
             if (rc2 != AQE_OK) return rc2;
         }
     }
@@ -567,12 +668,56 @@ void fill_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_to
     }
 }
 
+// The descriptor of the lean variant L of a form (what k_sweep_lean takes by value).
+void fill_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_totals, unsigned long long epoch, LeanLaunch& a) {
+    a = LeanLaunch{};
+    const SweepCommon sw = sweep_common(p, nullptr, 0);
+    a.amount = sw.amount;
+    a.runs = L.d_runs;
+    a.ntiles = static_cast<uint32_t>(L.ntiles);
+    a.rounds = L.slots;
+    a.has_where = sw.has_where;
+    a.wmin = sw.wmin; a.wmax = sw.wmax; a.shift = sw.shift;
+    for (uint32_t r = 0; r <= L.slots; ++r) a.slot_begin[r] = L.slot_begin[r];
+    a.partials = L.d_ppart;
+    a.counter = p->counter;
+    a.out_totals = out_totals;
+    a.state = p->d_state;
+    a.fold = fold_params(p, false);
+    a.fin = finalize_params(p);
+    a.result = p->d_result;
+    a.result_seq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p->d_result) + (reinterpret_cast<const volatile char*>(p->h_seq) - reinterpret_cast<const char*>(p->h_result)));
+    a.epoch = epoch;
+    a.finalize_here = 1u;
+    a.topup_gate = p->host.has_topup ? 1u : 0u;
+    a.more_rounds = L.more_rounds;
+    a.topup_slot = totals_only ? 0u : L.topup_slot;
+    a.want_ticks = (p->want_ticks && !totals_only) ? 1u : 0u;
+    a.totals_only = totals_only ? 1u : 0u;
+}
+
 int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_totals, hipStream_t s) {
     aqe_ctx* c = p->ctx;
+    // the lean kernel when the plan qualifies for it (and nobody asked for the persistent sweep's in-kernel timeline)
+    const SweepForm* lean = &F == &p->decide ? &p->decide_lean : &F == &p->head ? &p->head_lean : &F == &p->totals ? &p->totals_lean : nullptr;
+    if (lean && lean->ok && !c->d_stamps && !(p->q.flags & AQE_Q_NO_LEAN)) {
+        LeanLaunch a;
+        fill_lean(p, *lean, totals_only, out_totals, c->epoch++, a);
+        p->poll_epoch = totals_only ? 0 : a.epoch;
+        p->last_exec = totals_only ? 2 : 1;
+        p->last_kernel = AQE_KERNEL_SWEEP_LEAN;
+        p->last_grid = lean->grid;
+        p->last_first_unswept = lean->slots - lean->topup_slot;
+        const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
+        HIPCHK(c, launch_sweep_lean(a, lean->grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
+        if (prof) p->lev_used++;
+        return AQE_OK;
+    }
     PersistLaunch a;
     fill_form(p, F, totals_only, out_totals, c->epoch++, true, a);
     p->poll_epoch = totals_only ? 0 : a.epoch;
     p->last_exec = totals_only ? 2 : 1;
+    p->last_kernel = AQE_KERNEL_SWEEP_PERSIST;
     p->last_grid = F.grid;
     p->last_first_unswept = F.slots - F.topup_slot;
     if (c->d_stamps) {
@@ -996,6 +1141,7 @@ int launch_multi(aqe_batch* b, int kind, hipStream_t s) {
         aqe_plan* p = b->plans[i];
         p->poll_epoch = kind == 0 ? epoch : 0;
         p->last_exec = kind == 0 ? 1 : 2;
+        p->last_kernel = AQE_KERNEL_SWEEP_MULTI;
         p->last_first_unswept = m.forms[i].slots - m.forms[i].topup_slot;
         p->last_grid = m.forms[i].grid;
         p->lev_used = 0;
@@ -1330,6 +1476,12 @@ int aqe_plan_launch_ms(aqe_plan* p, float* ms, uint32_t cap, uint32_t* n_out) {
     return AQE_OK;
 }
 
+int aqe_plan_last_kernel(const aqe_plan* p, int* kernel) {
+    if (!p || !kernel) return AQE_ERR_INVALID;
+    *kernel = p->last_kernel;
+    return AQE_OK;
+}
+
 int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, uint32_t* n_out) {
     if (!p || !n_out) return AQE_ERR_INVALID;
     // reports the launches of the form the plan last executed with (or will: the fused path by default)
@@ -1347,7 +1499,7 @@ int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, 
     *n_out = n;
     if (!samples) return AQE_OK;
     if (cap < n) return AQE_ERR_CAPACITY;
-    if (form == 1) samples[0] = p->decide.samples;
+    if (form == 1) samples[0] = p->last_kernel == AQE_KERNEL_SWEEP_LEAN && p->decide_lean.ok ? p->decide_lean.samples : p->decide.samples;
     else for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
     if (with_topup) samples[sweeps] = p->topup.samples;
     return AQE_OK;

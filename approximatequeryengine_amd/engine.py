@@ -94,6 +94,12 @@ class Plan:
         self._chk(nat.lib().aqe_plan_launch_samples(self._h, buf, n.value, C.byref(n)))
         return list(buf[: n.value])
 
+    def last_kernel(self) -> int:
+        """Which kernel swept the rounds of the most recent execution (nat.KERNEL_*)."""
+        k = C.c_int()
+        self._chk(nat.lib().aqe_plan_last_kernel(self._h, C.byref(k)))
+        return k.value
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._chk(nat.lib().aqe_plan_last_kernel_ms(self._h, C.byref(ms)))

@@ -135,6 +135,10 @@ typedef struct aqe_query {
                               contiguous (same rows, same answer, a fraction of the memory traffic) */
 #define AQE_Q_SHARE_GPU 16u /* this query will run beside others (several plans in flight on different streams): its
                                single-launch sweep takes half the compute units, so that two fit the chip side by side */
+#define AQE_Q_NO_LEAN 32u /* single-launch form: keep the persistent sweep with its monitor wave (k_sweep_persist) where the
+                             plan would qualify for the lean launch that judges every round once, at the end (k_sweep_lean:
+                             small sweeps, every family a plain run of rows).  Same decision rule on the same partial
+                             moments; the sums are taken in another order */
 #define AQE_Q_FORCE_PERSIST 4u /* take the single-launch form whenever the plan has one, also where the query is
                                   predicted to stop early (by default such plans are launched round by round) */
 
@@ -423,6 +427,12 @@ AQE_API int aqe_plan_last_kernel_ms(aqe_plan* plan, float* ms);
  * of each launch of the most recent execution, in launch order. */
 AQE_API int aqe_plan_set_profiling(aqe_plan* plan, int enable);
 AQE_API int aqe_plan_launch_ms(aqe_plan* plan, float* ms, uint32_t cap, uint32_t* n_out);
+/* Which kernel swept the rounds of the plan's most recent execution (diagnostics, roofline reports). */
+#define AQE_KERNEL_ROUND 0         /* one k_round / k_indexed / k_permuted launch per round                        */
+#define AQE_KERNEL_SWEEP_PERSIST 1 /* k_sweep_persist: every round in one launch, a monitor wave judges as rounds complete */
+#define AQE_KERNEL_SWEEP_LEAN 2    /* k_sweep_lean: every round in one launch, judged once by the last workgroup to arrive */
+#define AQE_KERNEL_SWEEP_MULTI 3   /* k_sweep_multi: the plan ran as a group of a batch's one launch                */
+AQE_API int aqe_plan_last_kernel(const aqe_plan* plan, int* kernel);
 /* samples (sampled rows) each sweep launch of this shard folds, in launch order; the top-up entry is
  * its upper bound */
 AQE_API int aqe_plan_launch_samples(const aqe_plan* plan, uint64_t* samples, uint32_t cap, uint32_t* n_out);

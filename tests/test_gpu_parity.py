@@ -231,6 +231,12 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     alt = eng.reduce(q)
     assert (alt.n, alt.visited, alt.converged, alt.rounds, alt.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
     assert rel(alt.sum, multi.sum) <= 1e-14 and rel(alt.sumsq, multi.sumsq) <= 1e-14 and rel(alt.ci_lower, multi.ci_lower) <= 1e-13
+    # ... and both single-launch kernels: the persistent sweep with its monitor wave, and the lean launch that judges every
+    # round once at the end (taken by default where the whole sweep is in flight at once)
+    q.flags = nat.Q_FORCE_PERSIST | nat.Q_NO_LEAN
+    mon = eng.reduce(q)
+    assert (mon.n, mon.visited, mon.converged, mon.rounds, mon.topup) == (multi.n, multi.visited, multi.converged, multi.rounds, multi.topup)
+    assert rel(mon.sum, multi.sum) <= 1e-14 and rel(mon.sumsq, multi.sumsq) <= 1e-14 and rel(mon.ci_lower, multi.ci_lower) <= 1e-13
     q.flags = nat.Q_FORCE_PERSIST
     res = eng.reduce(q)
     # (different summation trees: integers and decisions identical, sums to rounding)
@@ -677,16 +683,55 @@ def test_persistent_sweep_stress_alternating_queries(nat, oracle, table, engines
     qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=e, clt_round0=r0, clt_growth=g, num_threads=T)
           for e, r0, g, T in ((1.0, 4096, 4, 4), (0.0, 4096, 4, 4), (0.3, 16, 2, 8), (5.0, 64, 2, 4), (0.05, 1024, 2, 6),
                               (2.0, 8, 2, 2), (0.0, 100_000, 2, 4))]
-    first = [eng.reduce(q) for q in qs]
-    for rep in range(15):
-        for q, f in zip(qs, first):
-            r = eng.reduce(q)
-            assert r.device_status == 0
-            assert (r.n, r.sum, r.sumsq, r.converged, r.rounds, r.topup, r.value) == \
-                (f.n, f.sum, f.sumsq, f.converged, f.rounds, f.topup, f.value), (rep, q.max_error_percent)
+    for flags in (0, nat.Q_NO_LEAN):  # the lean single launch (default where the sweep is small), and the monitor-wave kernel
+        for q in qs:
+            q.flags = flags
+        first = [eng.reduce(q) for q in qs]
+        for rep in range(15):
+            for q, f in zip(qs, first):
+                r = eng.reduce(q)
+                assert r.device_status == 0
+                assert (r.n, r.sum, r.sumsq, r.converged, r.rounds, r.topup, r.value) == \
+                    (f.n, f.sum, f.sumsq, f.converged, f.rounds, f.topup, f.value), (rep, q.max_error_percent)
     # a non-CLT query in between uses the ordinary launch and must not disturb anything
     assert eng.reduce(make_query(nat.M_BLOCK, 5.0)).n == 50_000
     assert eng.reduce(qs[0]).sum == first[0].sum
+
+
+def test_single_launch_kernel_choice(nat, engines):
+    """Which kernel sweeps a CLT plan's rounds (aqe_plan_last_kernel): the lean launch where the whole sweep is in flight at
+    once and every family is a plain run of rows (the bench query through its stride-major views), the persistent sweep
+    with its monitor wave when asked for (AQE_Q_NO_LEAN), when the column is swept in place (strided pointers: no runs) and
+    when the sweep is long enough for stopping early to matter; one k_round per round under AQE_Q_NO_PERSIST."""
+    import torch
+    from approximatequeryengine_amd.engine import make_query
+    eng = engines(10_000_000)
+    st = torch.cuda.Stream().cuda_stream
+    def kernel_of(flags, **kw):
+        args = dict(max_error_percent=0.01, clt_round0=4096, clt_growth=4)
+        args.update(kw)
+        q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, **args)
+        q.flags = flags
+        p = eng.plan(q)
+        p.enqueue_all(st)
+        r = p.fetch(st)
+        k = p.last_kernel()
+        p.close()
+        return k, r
+    k_lean, r_lean = kernel_of(0)
+    k_mon, r_mon = kernel_of(nat.Q_NO_LEAN)
+    k_place, r_place = kernel_of(nat.Q_NO_LAYOUT)
+    k_rounds, r_rounds = kernel_of(nat.Q_NO_PERSIST)
+    assert (k_lean, k_mon, k_place, k_rounds) == (nat.KERNEL_SWEEP_LEAN, nat.KERNEL_SWEEP_PERSIST, nat.KERNEL_SWEEP_PERSIST, nat.KERNEL_ROUND)
+    for r in (r_mon, r_place, r_rounds):
+        assert (r.n, r.visited, r.converged, r.rounds, r.topup) == (r_lean.n, r_lean.visited, r_lean.converged, r_lean.rounds, r_lean.topup)
+        assert rel(r.sum, r_lean.sum) <= 1e-14 and rel(r.sumsq, r_lean.sumsq) <= 1e-14 and rel(r.ci_lower, r_lean.ci_lower) <= 1e-13
+    # the head form of a query predicted to stop early is lean as well
+    k_head, r_head = kernel_of(0, max_error_percent=1.0)
+    k_head_mon, r_head_mon = kernel_of(nat.Q_NO_LEAN, max_error_percent=1.0)
+    assert (k_head, k_head_mon) == (nat.KERNEL_SWEEP_LEAN, nat.KERNEL_SWEEP_PERSIST)
+    assert (r_head.n, r_head.converged, r_head.rounds, r_head.topup) == (r_head_mon.n, r_head_mon.converged, r_head_mon.rounds, r_head_mon.topup)
+    assert rel(r_head.sum, r_head_mon.sum) <= 1e-14 and rel(r_head.ci_upper, r_head_mon.ci_upper) <= 1e-13
 
 
 def test_concurrent_plans_on_separate_streams(nat, engines):
