@@ -31,6 +31,7 @@ int aqe_device_malloc(aqe_ctx* c, size_t bytes, void** out) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(out, bytes ? bytes : 8));
     HIPCHK(c, hipMemset(*out, 0, bytes ? bytes : 8));
+    HIPCHK(c, hipDeviceSynchronize());  // (the memset may still be in flight, on the null stream: the caller's streams do not wait for it)
     return AQE_OK;
 }
 

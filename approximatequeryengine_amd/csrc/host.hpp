@@ -145,6 +145,7 @@ struct SweepForm {
     // the lean variant of the form (lean.hip, k_sweep_lean), when the plan qualifies: its own tile list (runs), its own
     // unpadded slot list; d_ppart then holds [slots][kVec] partials followed by the run table
     bool lean = false;
+    uint32_t tiles_per_wg = 0;  // workgroup b owns the tiles [b tiles_per_wg, (b + 1) tiles_per_wg)
     aqe::LeanRuns* d_runs = nullptr;
     uint32_t slot_begin[aqe::kMaxPersistRounds + 1] = {0};
 };
@@ -192,6 +193,7 @@ struct aqe_plan {
     volatile unsigned long long* h_seq = nullptr;  // behind h_result: the epoch of the launch whose result is there
     unsigned long long poll_epoch = 0;  // != 0: the last execution ends with a persistent launch of this epoch: fetch() may poll h_seq
     uint32_t last_grid = 0;     // workgroups of the last persistent launch (diagnostics)
+    bool predicted_full = false;  // the rules are predicted not to hold before the plan's last round (or there are none)
     bool per_round = false;     // both forms exist and the query is predicted to stop early: launch round by round
     bool expect_topup = false;  // single-launch form: the last execution needed the top-up -> enqueue its launch up front
     int last_exec = 0;  // which form the most recent execution used: 0 one launch per round, 1 decide, 2 totals

@@ -207,13 +207,14 @@ struct LeanRuns {  // in device memory, structure of arrays: lane i of every wav
     uint32_t tile_begin[kLeanMaxRuns];  // first tile of the run in the launch's tile list; 0xffffffff past the table
     uint32_t rows[kLeanMaxRuns];
     uint32_t meta[kLeanMaxRuns];        // round | group << 8
-    uint32_t slot[kLeanMaxRuns];        // of the run's round: first slot | first workgroup of its cyclic run << 16
+    uint32_t slot[kLeanMaxRuns];        // of the run's round: its first slot | the first workgroup that sweeps tiles of it << 16
 };
 struct LeanLaunch {
     const double* amount;
     const LeanRuns* runs;
     uint32_t ntiles, rounds;
-    int32_t has_where, pad0;
+    int32_t has_where;
+    uint32_t tiles_per_wg;     // workgroup b owns the tiles [b tiles_per_wg, (b + 1) tiles_per_wg)
     double wmin, wmax, shift;
     uint32_t slot_begin[kMaxPersistRounds + 1];  // round r owns the slots [slot_begin[r], slot_begin[r + 1]) of the flat list
     double* partials;          // [slots][kVec]: doubles 0..6 = a workgroup's partial of one round
@@ -227,7 +228,7 @@ struct LeanLaunch {
     unsigned long long epoch;
     uint32_t finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only;  // as in PersistLaunch
 };
-hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, bool nt, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);

@@ -7,8 +7,10 @@
 // the query then waits for is the hand-off.  This kernel is for those queries (plans.hip picks it: at most two tiles per
 // wave, every family a plain run of rows) and is built for a short critical path:
 //
-//   * no monitor wave, no polling, no stop word: every wave sweeps; a workgroup publishes ONE 56-byte partial per
-//     round it swept tiles of (sc1 stores, drained) and draws ONE ticket (k_round's sharded counters);
+//   * no monitor wave, no polling, no stop word: every wave sweeps.  Workgroup b owns the tiles [b K, (b + 1) K) of the
+//     launch's list (K = tiles / workgroups, rounded up; its wave j takes the j-th, (j + 16)-th, ... of them: the 16 waves
+//     stream one window of the column), so it sweeps tiles of one round, or of a few consecutive ones; it publishes ONE
+//     56-byte partial per round it swept tiles of (sc1 stores, drained) and draws ONE ticket (k_round's sharded counters);
 //   * the workgroup that draws the last ticket reads the flat partial list — at most 288 slots — with all of its
 //     16 waves, sums every round's slots in a fixed order (bit-reproducible), and wave 0 then judges EVERY round at
 //     once, lane q evaluating the rules on the moments through round q (DB.cpp:936-961, 993-1016).  The first round
@@ -53,13 +55,21 @@ struct __attribute__((packed, aligned(8))) Row2 { double x, y; };
 
 // One tile = up to 1024 consecutive rows from `base` (two rows per lane per 16-byte load, eight loads in flight);
 // `rem` rows of the run are left from `base` on.
+template <bool kNT>
 __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, const double* safe, int lane, int has_where, double wmin, double wmax,
                                           double shift, TileAcc& ta) {
     Row2 v2[kTileUnroll];
     if (rem >= static_cast<unsigned>(kDenseTileOrdinals)) {  // inside the run: no masks
         const Row2* const p = reinterpret_cast<const Row2*>(base) + lane;
 #pragma unroll
-        for (int k = 0; k < kTileUnroll; ++k) v2[k] = p[k * 64];
+        for (int k = 0; k < kTileUnroll; ++k) {
+            if (kNT) {  // a sweep beyond the Infinity Cache: past the caches (device_common.hpp, sweep_family)
+                v2[k].x = __builtin_nontemporal_load(&p[k * 64].x);
+                v2[k].y = __builtin_nontemporal_load(&p[k * 64].y);
+            } else {
+                v2[k] = p[k * 64];
+            }
+        }
         ta.nv = 2u * kTileUnroll;
         if (has_where) {
 #pragma unroll
@@ -182,6 +192,7 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
     }
 }
 
+template <bool kNT>
 __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
     __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];  // a wave's sums of a round (zero where it swept none)
     __shared__ double lds_flat[kLeanMaxSlots * kVec];                     // the folding workgroup's copy of the partial list
@@ -207,8 +218,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
         __hip_atomic_store(lean_t0_word(a.counter), static_cast<u64>(__builtin_amdgcn_s_memrealtime()), AQE_RLX);
     __syncthreads();
 
-    const unsigned V = gridDim.x * kPersistWaves;
-    const unsigned w = __builtin_amdgcn_readfirstlane(blockIdx.x * kPersistWaves + wave);
+    const unsigned t_lo = blockIdx.x * a.tiles_per_wg, t_end = t_lo + a.tiles_per_wg < a.ntiles ? t_lo + a.tiles_per_wg : a.ntiles;
     Acc acc;
     unsigned cur = ~0u, cur_slot = 0;  // the round this wave is in
     auto flush = [&]() {
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
             __hip_atomic_fetch_or(&lds_touched, 1u << cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    for (unsigned t = w; t < a.ntiles; t += V) {
+    for (unsigned t = __builtin_amdgcn_readfirstlane(t_lo + wave); t < t_end; t += kPersistWaves) {
         // the run that owns tile t: the last whose first tile is <= t (ascending; 0xffffffff past the table)
         const unsigned i = static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb <= t))) - 1u;
         const unsigned meta = __builtin_amdgcn_readlane(my_meta, i);
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
         const unsigned rem = __builtin_amdgcn_readlane(my_rows, i) - first;
         const double* const base = a.amount + (read_lane_u64(my_row0, i) + first);
         TileAcc ta;
-        lean_tile(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
+        lean_tile<kNT>(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
         merge_tile(acc, ta, ((meta >> 8) & 1u) != 0);
     }
     if (cur != ~0u) flush();
@@ -247,8 +257,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
             const unsigned r = static_cast<unsigned>(__builtin_ctz(m));
             m &= m - 1u;
             const unsigned info = lds_slot[r];
-            const unsigned first_wg = info >> 16;
-            const unsigned slot = (info & 0xffffu) + (blockIdx.x >= first_wg ? blockIdx.x - first_wg : blockIdx.x + gridDim.x - first_wg);
+            const unsigned slot = (info & 0xffffu) + blockIdx.x - (info >> 16);  // the round's workgroups are consecutive
             if (lane < 7) {
                 double x[kPersistWaves];
 #pragma unroll
@@ -320,9 +329,14 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
 
 }  // namespace
 
-hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (ev0) hipExtLaunchKernelGGL(k_sweep_lean, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL(k_sweep_lean, dim3(grid), dim3(kPersistThreads), 0, s, a);
+hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, bool nt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (nt) {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_lean<true>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL(k_sweep_lean<true>, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    } else {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_lean<false>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL(k_sweep_lean<false>, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -283,16 +283,15 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
 }
 
 
-// The lean variant of a form (lean.hip, k_sweep_lean): for a plan whose families are all plain runs of rows and whose
-// whole sweep is in flight at once (at most kLeanTilesPerWave tiles per wave).  Its own tile list — a run is tiled from
-// its first row — and its own slot list, unpadded: round r owns one slot per workgroup that sweeps tiles of it.
+// The lean variant of a form (lean.hip, k_sweep_lean): for a plan whose families are all plain runs of rows.  Its own
+// tile list — a run is tiled from its first row — cut into one contiguous share per workgroup, and its own slot list:
+// round r owns one slot per workgroup whose share holds tiles of it (consecutive workgroups; a round boundary splits
+// at most one share, so there are fewer than workgroups + rounds slots whatever the size of the sweep).
 // Leaves F.ok false (and returns AQE_OK) when the plan does not qualify.
-constexpr uint64_t kLeanTilesPerWave = 2;
-
 int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t grid, size_t nrounds) {
     aqe_ctx* c = p->ctx;
-    static const long max_tiles_per_wave = [] { const char* e = std::getenv("AQE_LEAN_TILES_PER_WAVE"); return e ? std::atol(e) : static_cast<long>(kLeanTilesPerWave); }();
-    if (max_tiles_per_wave <= 0 || !c->dense16 || grid == 0 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;
+    static const bool off = [] { const char* e = std::getenv("AQE_LEAN"); return e && e[0] == '0'; }();  // diagnostics: AQE_LEAN=0
+    if (off || !c->dense16 || grid == 0 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;
     std::vector<const LaunchDesc*> slots;
     for (size_t r = 0; r < nrounds; ++r) slots.push_back(&p->rounds[r]);
     const bool tslot = with_topup_slot && p->host.has_topup;
@@ -331,30 +330,14 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
         if (tiles == round_begin[r]) return AQE_OK;  // a slot without tiles: the other forms deal with it
     }
     round_begin[S] = tiles;
-    const uint64_t G = grid, V = G * kPersistWaves;
-    if (tiles >= 0xffffffffull || tiles > static_cast<uint64_t>(max_tiles_per_wave) * V) return AQE_OK;
-    // wave v owns tiles v, v + V, ...: the workgroups with tiles of a slot form one cyclic run of ids (build_sweep_form)
-    auto wave_has = [&](uint64_t v, uint64_t b0, uint64_t b1) { const uint64_t m0 = b0 % V; return b0 + (v >= m0 ? v - m0 : v + V - m0) < b1; };
+    const uint64_t G = grid;
+    if (tiles == 0 || tiles + G >= 0xffffffffull) return AQE_OK;
+    const uint64_t K = (tiles + G - 1) / G;  // workgroup b owns the tiles [b K, (b + 1) K)
     uint32_t part_first[kMaxPersistRounds] = {0};
     for (size_t r = 0; r < S; ++r) {
-        std::vector<char> member(G, 0);
-        uint64_t members = 0;
-        for (uint64_t b = 0; b < G; ++b) {
-            for (uint64_t j = 0; j < kPersistWaves && !member[b]; ++j)
-                if (wave_has(b * kPersistWaves + j, round_begin[r], round_begin[r + 1])) member[b] = 1;
-            members += member[b];
-        }
-        uint64_t first = 0;
-        if (members != 0 && members != G) {
-            uint64_t starts = 0;
-            for (uint64_t b = 0; b < G; ++b)
-                if (member[b] && !member[(b + G - 1) % G]) { first = b; ++starts; }
-            if (starts != 1) return fail(c, AQE_ERR_INVALID, "internal: lean-sweep participation is not one cyclic run");
-        }
-        for (uint64_t i = 0; i < members; ++i)
-            if (!member[(first + i) % G]) return fail(c, AQE_ERR_INVALID, "internal: lean-sweep participation is not one cyclic run");
+        const uint64_t first = round_begin[r] / K, last = (round_begin[r + 1] - 1) / K;
         part_first[r] = static_cast<uint32_t>(first);
-        F.slot_begin[r + 1] = F.slot_begin[r] + static_cast<uint32_t>(members);
+        F.slot_begin[r + 1] = F.slot_begin[r] + static_cast<uint32_t>(last - first + 1);
     }
     if (F.slot_begin[S] > static_cast<uint32_t>(kLeanMaxSlots)) return AQE_OK;
     for (uint32_t i = 0; i < nruns; ++i) {
@@ -369,6 +352,7 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
     HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     F.d_runs = reinterpret_cast<LeanRuns*>(reinterpret_cast<uint64_t*>(F.d_ppart) + ppart_words);
     F.lean = true;
+    F.tiles_per_wg = static_cast<uint32_t>(K);
     F.slots = static_cast<uint32_t>(S);
     F.ntiles = tiles;
     F.samples = samples;
@@ -504,6 +488,9 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
         HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams_small), kPoolFams * sizeof(DevFamily)));
+        // (hipMemset of device memory may return before it has run, and it runs on the null stream, which the plan's
+        // streams — non-blocking ones — do not wait for: the tickets must be zero before the first launch draws one)
+        HIPCHK(c, hipDeviceSynchronize());
     }
     std::memset(p->h_result, 0, kSeqOffset + 64);
     p->h_seq = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(p->h_result) + kSeqOffset);
@@ -529,6 +516,15 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         // aggregates/s with 32 in flight — at the price of a longer launch when it runs alone (19.4 against 16.4 us).
         p->grid = (q->flags & AQE_Q_SHARE_GPU) ? std::max(16u, c->persist_grid / 2) : c->persist_grid;
         const bool multi = !p->host.is_random && !p->host.is_perm && R >= 2 && p->grid > 0;
+        {   // will the query run out of rounds before the error rule can hold (the prediction described below)?
+            p->predicted_full = !p->host.is_clt || q->max_error_percent <= 0.0;
+            if (p->host.is_clt && c->head_cv > 0.0 && q->max_error_percent > 0.0) {
+                const double root = p->host.clt.z * c->head_cv * 100.0 / q->max_error_percent;
+                double leader = 0.0;
+                for (const LaunchDesc& L : p->rounds) leader += static_cast<double>(L.samples) / static_cast<double>(std::max(1, p->host.clt.n_workers));
+                p->predicted_full = leader < std::max(50.0, root * root);
+            }
+        }
         const bool whole = c->shard_lo == 0 && c->n_local == c->n_global;
         bool every_round_has_tiles = true;
         for (size_t r = 0; r < R; ++r) every_round_has_tiles = every_round_has_tiles && p->rounds[r].ntiles > 0;
@@ -675,6 +671,7 @@ void fill_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_to
     a.amount = sw.amount;
     a.runs = L.d_runs;
     a.ntiles = static_cast<uint32_t>(L.ntiles);
+    a.tiles_per_wg = L.tiles_per_wg;
     a.rounds = L.slots;
     a.has_where = sw.has_where;
     a.wmin = sw.wmin; a.wmax = sw.wmax; a.shift = sw.shift;
@@ -700,7 +697,11 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     aqe_ctx* c = p->ctx;
     // the lean kernel when the plan qualifies for it (and nobody asked for the persistent sweep's in-kernel timeline)
     const SweepForm* lean = &F == &p->decide ? &p->decide_lean : &F == &p->head ? &p->head_lean : &F == &p->totals ? &p->totals_lean : nullptr;
-    if (lean && lean->ok && !c->d_stamps && !(p->q.flags & AQE_Q_NO_LEAN)) {
+    // A sweep that is in flight all at once (two tiles per wave: 64 MB) has nothing to gain from a monitor; a longer
+    // one takes the lean launch when the rules are predicted not to hold before the plan runs out of rounds (create_plan)
+    // — should the prediction fail, the answer is the same and the rounds behind the stopping one were swept for nothing.
+    const bool lean_pays = lean && lean->ok && (lean->ntiles <= 2ull * lean->grid * kPersistWaves || p->predicted_full);
+    if (lean_pays && !c->d_stamps && !(p->q.flags & AQE_Q_NO_LEAN)) {
         LeanLaunch a;
         fill_lean(p, *lean, totals_only, out_totals, c->epoch++, a);
         p->poll_epoch = totals_only ? 0 : a.epoch;
@@ -709,7 +710,7 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
         p->last_grid = lean->grid;
         p->last_first_unswept = lean->slots - lean->topup_slot;
         const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
-        HIPCHK(c, launch_sweep_lean(a, lean->grid, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
+        HIPCHK(c, launch_sweep_lean(a, lean->grid, p->nt, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
         if (prof) p->lev_used++;
         return AQE_OK;
     }

@@ -791,7 +791,7 @@ def test_device_side_seeded_sampler(nat, oracle, golden, table, engines):
             want = perm_rows(n, pct, seed)
             q = make_query(nat.M_RANDOM_DEVICE, pct, seed=seed)
             res = eng.reduce(q)
-            assert res.visited == len(want) == res.n
+            assert res.visited == len(want) == res.n, (n, pct, seed, res.visited, res.n, len(want), res.device_status, res.rounds)
             got = eng.gather(q)
             assert np.array_equal((got["id"] - 1).astype(np.uint64), want)  # draw order
             if len(want):
