@@ -199,13 +199,17 @@ hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long lo
 
 // ---- lean single-launch sweep of a multi-round query whose whole sweep is in flight at once: lean.hip -------------
 // A RUN is a family in its simplest form: `rows` consecutive rows of the column (or of a stride-major view) that all
-// belong to the sample — what exact scans, blocks of one segment and every strided pointer read through a view come to.
+// belong to the sample — what exact scans and every strided pointer read through a view come to — or `rows` whole
+// segments of `seg_rows` such rows each, `pitch` rows apart (block samplers).
 constexpr int kLeanMaxRuns = 64;                                        // one run per lane of a wave
 constexpr int kLeanMaxSlots = kMaxPersistGrid + kMaxPersistRounds;      // a round boundary splits at most one workgroup
 struct LeanRuns {  // in device memory, structure of arrays: lane i of every wave holds run i in registers
     uint64_t row0[kLeanMaxRuns];        // first row, relative to LeanLaunch::amount
     uint32_t tile_begin[kLeanMaxRuns];  // first tile of the run in the launch's tile list; 0xffffffff past the table
-    uint32_t rows[kLeanMaxRuns];
+    uint32_t rows[kLeanMaxRuns];        // rows of the run; segments of a segmented run
+    uint32_t seg_tiles[kLeanMaxRuns];   // 0: one stretch of rows; else tiles per segment
+    uint32_t seg_rows[kLeanMaxRuns];    // segmented run: rows per segment
+    uint64_t pitch[kLeanMaxRuns];       // segmented run: rows from one segment's start to the next
     uint32_t meta[kLeanMaxRuns];        // round | group << 8
     uint32_t slot[kLeanMaxRuns];        // of the run's round: its first slot | the first workgroup that sweeps tiles of it << 16
 };

@@ -1,4 +1,5 @@
-// lean.hip — k_sweep_lean: a multi-round (CLT) query in ONE launch when the whole sweep is in flight at once.
+// lean.hip — k_sweep_lean: a query in ONE lean launch — every round of a multi-round (CLT) query, or a single-round
+// sampler — when its families are plain runs of rows.
 //
 // The reference's monitor (custom_bplus_db.cpp:885-1043) re-evaluates its rules while the pointer threads are still
 // walking, so that they can stop early (DB.cpp:930, 987).  k_sweep_persist (persist.hip) keeps that shape: a monitor
@@ -35,6 +36,18 @@ namespace {
 
 typedef const AQE_KARG LeanLaunch* LeanKarg;
 
+// Diagnostics (builds with -DAQE_LEAN_STAMPS only; tools/stamp_lean.py): s_memrealtime marks, 100 MHz.
+// [wave][8]: 0 entry, 1 table in registers, 2 first tile folded, 3 sweep done, 4 sums handed to the workgroup, 5 partial out
+// (wave 0), 6 ticket drawn (wave 0);  then [8] of the folding workgroup: 0 partials in LDS, 1 rounds summed, 2 judged
+#ifdef AQE_LEAN_STAMPS
+__device__ unsigned long long g_lean_stamps[(kMaxPersistGrid * kPersistWaves + 1) * 8];
+#define LEAN_STAMP(slot) do { if (lane == 0) g_lean_stamps[(static_cast<size_t>(blockIdx.x) * kPersistWaves + wave) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define LEAN_STAMP_FOLD(slot) do { if (threadIdx.x == 0) g_lean_stamps[static_cast<size_t>(kMaxPersistGrid) * kPersistWaves * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LEAN_STAMP(slot) do { } while (0)
+#define LEAN_STAMP_FOLD(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ void lean_state_store(QueryState* g, const QueryState& st) {
     static_assert(sizeof(QueryState) % 8 == 0, "state is moved as 8-byte words");
     const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&st);
@@ -58,8 +71,8 @@ struct __attribute__((packed, aligned(8))) Row2 { double x, y; };
 template <bool kNT>
 __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, const double* safe, int lane, int has_where, double wmin, double wmax,
                                           double shift, TileAcc& ta) {
-    Row2 v2[kTileUnroll];
     if (rem >= static_cast<unsigned>(kDenseTileOrdinals)) {  // inside the run: no masks
+        Row2 v2[kTileUnroll];
         const Row2* const p = reinterpret_cast<const Row2*>(base) + lane;
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) {
@@ -92,29 +105,25 @@ __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, cons
         }
         return;
     }
-    // the run's last tile: rows past its end are masked (and never addressed: a lane whose pair leaves the run reads
-    // rows 0..1 of the column instead, then its one valid row by itself)
-    bool ok0[kTileUnroll], ok1[kTileUnroll];
+    // the run's last tile (every tile of a run of short segments): one row per lane per load, sixteen loads in flight, rows
+    // past the end masked — and never addressed: such a lane reads row 0 of the column instead
+    double v[2 * kTileUnroll];
+    bool ok[2 * kTileUnroll];
 #pragma unroll
-    for (int k = 0; k < kTileUnroll; ++k) {
-        const unsigned r0 = 2u * static_cast<unsigned>(lane) + 128u * static_cast<unsigned>(k);
-        ok0[k] = r0 < rem;
-        ok1[k] = r0 + 1u < rem;
-        v2[k] = *reinterpret_cast<const Row2*>(ok1[k] ? base + r0 : safe);
-        if (!ok1[k]) {
-            v2[k].x = ok0[k] ? base[r0] : 0.0;
-            v2[k].y = 0.0;
-        }
+    for (int k = 0; k < 2 * kTileUnroll; ++k) {
+        const unsigned r0 = static_cast<unsigned>(lane) + 64u * static_cast<unsigned>(k);
+        ok[k] = r0 < rem;
+        const double* const p = ok[k] ? base + r0 : safe;
+        v[k] = kNT ? __builtin_nontemporal_load(p) : *p;
     }
 #pragma unroll
-    for (int k = 0; k < kTileUnroll; ++k) {
-        const double x = v2[k].x, y = v2[k].y;
-        const bool px = ok0[k] && (!has_where || (x >= wmin && x <= wmax)), py = ok1[k] && (!has_where || (y >= wmin && y <= wmax));
-        const double dx = px ? x - shift : 0.0, dy = py ? y - shift : 0.0;
-        ta.nv += (ok0[k] ? 1u : 0u) + (ok1[k] ? 1u : 0u);
-        ta.n += (px ? 1u : 0u) + (py ? 1u : 0u);
+    for (int k = 0; k < 2 * kTileUnroll; ++k) {
+        const double x = v[k];
+        const bool px = ok[k] && (!has_where || (x >= wmin && x <= wmax));
+        const double dx = px ? x - shift : 0.0;
+        ta.nv += ok[k] ? 1u : 0u;
+        ta.n += px ? 1u : 0u;
         ta.s += dx; ta.q += dx * dx;
-        ta.s += dy; ta.q += dy * dy;
     }
 }
 
@@ -190,6 +199,9 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
         // every field has landed (kernels.hpp, result_check)
         __hip_atomic_store(K->result_seq, result_check(res, K->epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#ifdef AQE_LEAN_STAMPS
+    g_lean_stamps[static_cast<size_t>(kMaxPersistGrid) * kPersistWaves * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <bool kNT>
@@ -199,36 +211,39 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
     __shared__ double lds_quarter[kMaxPersistRounds][kVec][4];
     __shared__ double lds_round[kMaxPersistRounds][kVec];
     __shared__ unsigned lds_slot[kMaxPersistRounds];
-    __shared__ unsigned lds_touched;
+    __shared__ unsigned lds_mask[kPersistWaves];  // rounds a wave swept tiles of
     __shared__ int s_last;
     const LeanKarg K = (LeanKarg)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const unsigned wave = threadIdx.x >> 6;
+    LEAN_STAMP(0);
     // the run table: lane i holds run i.  One batch of loads, in flight while LDS is cleared.
     const u64 my_row0 = a.runs->row0[lane];
     const unsigned my_tb = a.runs->tile_begin[lane], my_rows = a.runs->rows[lane], my_meta = a.runs->meta[lane], my_slot = a.runs->slot[lane];
-    {
-        double* z = &lds_part[0][0][0];
-        constexpr unsigned kWords = kMaxPersistRounds * kPersistWaves * kVec;
+    const unsigned my_seg_tiles = a.runs->seg_tiles[lane], my_seg_rows = a.runs->seg_rows[lane];
+    const u64 my_pitch = a.runs->pitch[lane];
+    // every wave clears its own rows of lds_part: nothing to wait for before the sweep
 #pragma unroll
-        for (unsigned i = 0; i < kWords / kPersistThreads; ++i) z[threadIdx.x + i * kPersistThreads] = 0.0;
-        if (threadIdx.x == 0) lds_touched = 0;
+    for (unsigned i = 0; i < kMaxPersistRounds * kVec / 64; ++i) {
+        const unsigned x = static_cast<unsigned>(lane) + 64u * i;
+        lds_part[x >> 3][wave][x & 7u] = 0.0;
     }
     if (a.want_ticks && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(lean_t0_word(a.counter), static_cast<u64>(__builtin_amdgcn_s_memrealtime()), AQE_RLX);
-    __syncthreads();
+#ifdef AQE_LEAN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LEAN_STAMP(1);
+#endif
 
     const unsigned t_lo = blockIdx.x * a.tiles_per_wg, t_end = t_lo + a.tiles_per_wg < a.ntiles ? t_lo + a.tiles_per_wg : a.ntiles;
     Acc acc;
-    unsigned cur = ~0u, cur_slot = 0;  // the round this wave is in
+    unsigned cur = ~0u, cur_slot = 0, touched = 0;  // the round this wave is in; the rounds it has been in
     auto flush = [&]() {
         const double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb, static_cast<double>(acc.nv)};
         const double mine = wave_sum7(v, lane);  // lane 8c holds component c
         if ((lane & 7) == 0 && lane < 56) lds_part[cur][wave][lane >> 3] = mine;
-        if (lane == 0) {
-            lds_slot[cur] = cur_slot;
-            __hip_atomic_fetch_or(&lds_touched, 1u << cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (lane == 0) lds_slot[cur] = cur_slot;
+        touched |= 1u << cur;
     };
     for (unsigned t = __builtin_amdgcn_readfirstlane(t_lo + wave); t < t_end; t += kPersistWaves) {
         // the run that owns tile t: the last whose first tile is <= t (ascending; 0xffffffff past the table)
@@ -240,19 +255,39 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
             cur = r;
             cur_slot = __builtin_amdgcn_readlane(my_slot, i);
         }
-        const unsigned first = (t - __builtin_amdgcn_readlane(my_tb, i)) * static_cast<unsigned>(kDenseTileOrdinals);
-        const unsigned rem = __builtin_amdgcn_readlane(my_rows, i) - first;
-        const double* const base = a.amount + (read_lane_u64(my_row0, i) + first);
+        const unsigned k = t - __builtin_amdgcn_readlane(my_tb, i);  // tile of the run
+        const unsigned seg_tiles = __builtin_amdgcn_readlane(my_seg_tiles, i);
+        unsigned first, rem;
+        u64 row = read_lane_u64(my_row0, i);
+        if (seg_tiles == 0) {
+            first = k * static_cast<unsigned>(kDenseTileOrdinals);
+            rem = __builtin_amdgcn_readlane(my_rows, i) - first;
+        } else {  // segmented run (blocks): tile k is tile j of segment k / seg_tiles
+            const unsigned seg = seg_tiles == 1u ? k : k / seg_tiles;
+            first = (k - seg * seg_tiles) * static_cast<unsigned>(kDenseTileOrdinals);
+            rem = __builtin_amdgcn_readlane(my_seg_rows, i) - first;
+            row += static_cast<u64>(seg) * read_lane_u64(my_pitch, i);
+        }
+        const double* const base = a.amount + (row + first);
         TileAcc ta;
         lean_tile<kNT>(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
         merge_tile(acc, ta, ((meta >> 8) & 1u) != 0);
+#ifdef AQE_LEAN_STAMPS
+        if (t == t_lo + wave) LEAN_STAMP(2);
+#endif
     }
+    LEAN_STAMP(3);
     if (cur != ~0u) flush();
+    if (lane == 0) lds_mask[wave] = touched;
+    LEAN_STAMP(4);
     __syncthreads();
 
     // ---- the workgroup's partial of every round it swept tiles of: data, drain, ticket (cdna_hip_programming.md G16) ----
     if (wave == 0) {
-        unsigned m = __builtin_amdgcn_readfirstlane(lds_touched);
+        unsigned m = 0;
+#pragma unroll
+        for (unsigned j = 0; j < kPersistWaves; ++j) m |= lds_mask[j];
+        m = __builtin_amdgcn_readfirstlane(m);
         while (m) {
             const unsigned r = static_cast<unsigned>(__builtin_ctz(m));
             m &= m - 1u;
@@ -269,23 +304,27 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partials are out before the ticket is drawn
+        LEAN_STAMP(5);
         if (lane == 0) {
             int last = 0;
             const unsigned G = gridDim.x;
             unsigned* const ct = a.counter + static_cast<size_t>(kShards) * kShardStride;
-            if (G <= static_cast<unsigned>(kShards)) {
+            // at most 256 arrivals: 16 shards of 16 (a same-address atomic serialises at ~16 ns), then the top counter
+            constexpr unsigned kLeanShards = 16;
+            if (G <= kLeanShards) {
                 if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) == G - 1u) { __hip_atomic_store(ct, 0u, AQE_RLX); last = 1; }
             } else {
-                const unsigned sh = blockIdx.x % static_cast<unsigned>(kShards);
-                const unsigned members = (G - sh + static_cast<unsigned>(kShards) - 1u) / static_cast<unsigned>(kShards);
+                const unsigned sh = blockIdx.x % kLeanShards;
+                const unsigned members = (G - sh + kLeanShards - 1u) / kLeanShards;
                 unsigned* const cs = a.counter + static_cast<size_t>(sh) * kShardStride;
                 if (__hip_atomic_fetch_add(cs, 1u, AQE_RLX) == members - 1u) {
                     __hip_atomic_store(cs, 0u, AQE_RLX);
-                    if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) == static_cast<unsigned>(kShards) - 1u) { __hip_atomic_store(ct, 0u, AQE_RLX); last = 1; }
+                    if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) == kLeanShards - 1u) { __hip_atomic_store(ct, 0u, AQE_RLX); last = 1; }
                 }
             }
             s_last = last;
         }
+        LEAN_STAMP(6);
     }
     __syncthreads();
     if (!s_last) return;
@@ -295,6 +334,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
     const unsigned nwords = K->slot_begin[rounds] * static_cast<unsigned>(kVec);
     for (unsigned i = threadIdx.x; i < nwords; i += kPersistThreads) lds_flat[i] = __hip_atomic_load(a.partials + i, AQE_RLX);
     __syncthreads();
+    LEAN_STAMP_FOLD(0);
     {   // thread (q, c, quarter): every fourth slot of round q, component c
         const unsigned q = threadIdx.x >> 5, c = (threadIdx.x >> 2) & 7u, part = threadIdx.x & 3u;
         if (q < rounds && c < 7u) {
@@ -310,6 +350,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
         if (q < rounds && c < 7u) lds_round[q][c] = ((lds_quarter[q][c][0] + lds_quarter[q][c][1]) + lds_quarter[q][c][2]) + lds_quarter[q][c][3];
     }
     __syncthreads();
+    LEAN_STAMP_FOLD(1);
     if (wave != 0) return;
     // lane q: the moments through round q (a slot's own total in the totals form, and for the top-up slot)
     const bool tslot = K->topup_slot != 0;
@@ -339,5 +380,12 @@ hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, bool nt, hipStr
     }
     return hipGetLastError();
 }
+
+#ifdef AQE_LEAN_STAMPS
+extern "C" __attribute__((visibility("default"))) int aqe_debug_lean_stamps(unsigned long long* out, size_t words) {
+    const size_t all = (kMaxPersistGrid * kPersistWaves + 1) * 8;
+    return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lean_stamps), 8 * (words < all ? words : all), 0, hipMemcpyDeviceToHost));
+}
+#endif
 
 }  // namespace aqe

@@ -28,7 +28,7 @@ void destroy_plan(aqe_plan* p) {
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
     if (p->d_fams_small) (void)hipFree(p->d_fams_small);
-    for (SweepForm* f : {&p->decide, &p->totals, &p->head, &p->decide_lean, &p->totals_lean, &p->head_lean}) {
+    for (SweepForm* f : {&p->decide, &p->totals, &p->head, &p->decide_lean, &p->totals_lean, &p->head_lean, &p->single_lean}) {
         if (f->d_ppart) (void)hipFree(f->d_ppart);  // (the form's family table lives in the same block)
     }
     if (p->d_state) (void)hipFree(p->d_state);
@@ -291,7 +291,7 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
 int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t grid, size_t nrounds) {
     aqe_ctx* c = p->ctx;
     static const bool off = [] { const char* e = std::getenv("AQE_LEAN"); return e && e[0] == '0'; }();  // diagnostics: AQE_LEAN=0
-    if (off || !c->dense16 || grid == 0 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;
+    if (off || !c->dense16 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;  // (grid 0: one workgroup per 16 tiles, at most the context's)
     std::vector<const LaunchDesc*> slots;
     for (size_t r = 0; r < nrounds; ++r) slots.push_back(&p->rounds[r]);
     const bool tslot = with_topup_slot && p->host.has_topup;
@@ -312,26 +312,55 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
         round_begin[r] = tiles;
         for (uint32_t i = 0; i < L.nfam; ++i) {
             const DevFamily& d = p->h_fams[L.fam_offset + i];
-            // a plain run: one pointer, step 1, its window inside one segment
-            if (!is_dense16(d.step, d.flags, d.seg_len) || (d.flags & kFamLinear) || d.tiles_per_seg != 0 || d.ord_hi <= d.ord_lo) return AQE_OK;
-            const uint64_t len = d.ord_hi - d.ord_lo;
-            if (nruns == static_cast<uint32_t>(kLeanMaxRuns) || len >= 0xffffffffull) return AQE_OK;
+            // one pointer, step 1: its window is a stretch of one segment, or (blocks) the end of a first segment, a
+            // number of whole segments and the start of a last one — up to three runs
+            if (!is_dense16(d.step, d.flags, d.seg_len) || (d.flags & kFamLinear) || d.ord_hi <= d.ord_lo) return AQE_OK;
+            const uint64_t rebase = is_topup ? static_cast<uint64_t>(base_gap) : 0;  // one launch has one column base: the rounds'
             // row of ordinal o: row0 + seg pitch - shard_lo + (o - seg seg_len)   (device_common.hpp, sweep_family; wraps like it)
-            uint64_t row = d.row0 + d.seg_lo * d.pitch - sw.shard_lo + d.ord_lo - d.seg_lo * d.seg_len;
-            if (is_topup) row += static_cast<uint64_t>(base_gap);  // one launch has one column base: the rounds'
-            runs.row0[nruns] = row;
-            runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
-            runs.rows[nruns] = static_cast<uint32_t>(len);
-            runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
-            tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
-            samples += len;
-            ++nruns;
+            auto row_of = [&](uint64_t o) { const uint64_t seg = o / d.seg_len; return d.row0 + seg * d.pitch - sw.shard_lo + (o - seg * d.seg_len) + rebase; };
+            auto add_run = [&](uint64_t o_lo, uint64_t o_hi) {  // a stretch inside one segment
+                const uint64_t len = o_hi - o_lo;
+                if (nruns == static_cast<uint32_t>(kLeanMaxRuns) || len >= 0xffffffffull) return false;
+                runs.row0[nruns] = row_of(o_lo);
+                runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
+                runs.rows[nruns] = static_cast<uint32_t>(len);
+                runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
+                tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
+                samples += len;
+                ++nruns;
+                return true;
+            };
+            const uint64_t s_lo = d.ord_lo / d.seg_len, s_hi = (d.ord_hi - 1) / d.seg_len;
+            if (s_lo == s_hi) {
+                if (!add_run(d.ord_lo, d.ord_hi)) return AQE_OK;
+                continue;
+            }
+            uint64_t whole_lo = s_lo, whole_hi = s_hi + 1;  // segments swept whole
+            if (d.ord_lo % d.seg_len) { if (!add_run(d.ord_lo, (s_lo + 1) * d.seg_len)) return AQE_OK; whole_lo = s_lo + 1; }
+            const bool tail = d.ord_hi % d.seg_len != 0;
+            if (tail) whole_hi = s_hi;
+            if (whole_hi > whole_lo) {
+                const uint64_t nseg = whole_hi - whole_lo, seg_tiles = (d.seg_len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
+                if (nruns == static_cast<uint32_t>(kLeanMaxRuns) || nseg >= 0xffffffffull || d.seg_len >= 0xffffffffull || tiles + nseg * seg_tiles >= 0xffffffffull) return AQE_OK;
+                runs.row0[nruns] = row_of(whole_lo * d.seg_len);
+                runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
+                runs.rows[nruns] = static_cast<uint32_t>(nseg);
+                runs.seg_tiles[nruns] = static_cast<uint32_t>(seg_tiles);
+                runs.seg_rows[nruns] = static_cast<uint32_t>(d.seg_len);
+                runs.pitch[nruns] = d.pitch;
+                runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
+                tiles += nseg * seg_tiles;
+                samples += nseg * d.seg_len;
+                ++nruns;
+            }
+            if (tail && !add_run(s_hi * d.seg_len, d.ord_hi)) return AQE_OK;
         }
         if (tiles == round_begin[r]) return AQE_OK;  // a slot without tiles: the other forms deal with it
     }
     round_begin[S] = tiles;
+    if (grid == 0) grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(c->persist_grid, 1u), (tiles + kPersistWaves - 1) / kPersistWaves));
     const uint64_t G = grid;
-    if (tiles == 0 || tiles + G >= 0xffffffffull) return AQE_OK;
+    if (tiles == 0 || G == 0 || tiles + G >= 0xffffffffull) return AQE_OK;
     const uint64_t K = (tiles + G - 1) / G;  // workgroup b owns the tiles [b K, (b + 1) K)
     uint32_t part_first[kMaxPersistRounds] = {0};
     for (size_t r = 0; r < S; ++r) {
@@ -593,6 +622,12 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                 }
             }
         }
+        // (below ~12 MB a sweep is a handful of tiles per compute unit and k_round's small workgroups spread it wider)
+        static const uint64_t single_min_tiles = [] { const char* e = std::getenv("AQE_LEAN_SINGLE_MIN_TILES"); return e ? static_cast<uint64_t>(std::atoll(e)) : 1536ull; }();
+        if (!multi && R == 1 && !p->host.is_random && !p->host.is_perm && !p->host.has_topup && p->rounds[0].ntiles >= single_min_tiles) {
+            int rc2 = build_lean_form(p.get(), false, p->single_lean, (q->flags & AQE_Q_SHARE_GPU) ? p->grid : 0u, 1);
+            if (rc2 != AQE_OK) return rc2;
+        }
         if (multi && R <= static_cast<size_t>(kMaxPersistRounds)) {
             int rc2 = build_sweep_form(p.get(), false, p->totals, p->grid, R);
             if (rc2 == AQE_OK) rc2 = build_lean_form(p.get(), false, p->totals_lean, p->grid, R);
@@ -693,6 +728,22 @@ void fill_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_to
     a.totals_only = totals_only ? 1u : 0u;
 }
 
+int launch_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_totals, hipStream_t s) {
+    aqe_ctx* c = p->ctx;
+    LeanLaunch a;
+    fill_lean(p, L, totals_only, out_totals, c->epoch++, a);
+    p->poll_epoch = totals_only ? 0 : a.epoch;
+    p->last_exec = totals_only ? 2 : 1;
+    p->last_kernel = AQE_KERNEL_SWEEP_LEAN;
+    p->last_samples = L.samples;
+    p->last_grid = L.grid;
+    p->last_first_unswept = L.slots - L.topup_slot;
+    const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
+    HIPCHK(c, launch_sweep_lean(a, L.grid, p->nt, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
+    if (prof) p->lev_used++;
+    return AQE_OK;
+}
+
 int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_totals, hipStream_t s) {
     aqe_ctx* c = p->ctx;
     // the lean kernel when the plan qualifies for it (and nobody asked for the persistent sweep's in-kernel timeline)
@@ -701,24 +752,13 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     // one takes the lean launch when the rules are predicted not to hold before the plan runs out of rounds (create_plan)
     // — should the prediction fail, the answer is the same and the rounds behind the stopping one were swept for nothing.
     const bool lean_pays = lean && lean->ok && (lean->ntiles <= 2ull * lean->grid * kPersistWaves || p->predicted_full);
-    if (lean_pays && !c->d_stamps && !(p->q.flags & AQE_Q_NO_LEAN)) {
-        LeanLaunch a;
-        fill_lean(p, *lean, totals_only, out_totals, c->epoch++, a);
-        p->poll_epoch = totals_only ? 0 : a.epoch;
-        p->last_exec = totals_only ? 2 : 1;
-        p->last_kernel = AQE_KERNEL_SWEEP_LEAN;
-        p->last_grid = lean->grid;
-        p->last_first_unswept = lean->slots - lean->topup_slot;
-        const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
-        HIPCHK(c, launch_sweep_lean(a, lean->grid, p->nt, s, prof ? p->lev[2 * p->lev_used] : nullptr, prof ? p->lev[2 * p->lev_used + 1] : nullptr));
-        if (prof) p->lev_used++;
-        return AQE_OK;
-    }
+    if (lean_pays && !c->d_stamps && !(p->q.flags & AQE_Q_NO_LEAN)) return launch_lean(p, *lean, totals_only, out_totals, s);
     PersistLaunch a;
     fill_form(p, F, totals_only, out_totals, c->epoch++, true, a);
     p->poll_epoch = totals_only ? 0 : a.epoch;
     p->last_exec = totals_only ? 2 : 1;
     p->last_kernel = AQE_KERNEL_SWEEP_PERSIST;
+    p->last_samples = F.samples;
     p->last_grid = F.grid;
     p->last_first_unswept = F.slots - F.topup_slot;
     if (c->d_stamps) {
@@ -780,6 +820,12 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             }
             p->last_exec = 0;
             HIPCHK(c, hipGraphLaunch(p->round_graph, s));
+            topup_done = true;
+        } else if (p->single_lean.ok && !(p->q.flags & (AQE_Q_NO_LEAN | AQE_Q_NO_PERSIST))) {
+            // a single-round sampler whose families are plain runs of rows (exact scans, strided pointers through a view,
+            // whole blocks): the lean launch, one round
+            int rc = launch_lean(p, p->single_lean, false, nullptr, s);
+            if (rc != AQE_OK) return rc;
             topup_done = true;
         } else {
             plain_epoch = c->epoch++;  // launch by launch: the one that finishes the query writes the check word
@@ -1500,7 +1546,7 @@ int aqe_plan_launch_samples(const aqe_plan* p, uint64_t* samples, uint32_t cap, 
     *n_out = n;
     if (!samples) return AQE_OK;
     if (cap < n) return AQE_ERR_CAPACITY;
-    if (form == 1) samples[0] = p->last_kernel == AQE_KERNEL_SWEEP_LEAN && p->decide_lean.ok ? p->decide_lean.samples : p->decide.samples;
+    if (form == 1) samples[0] = p->last_exec == 1 ? p->last_samples : p->decide.samples;
     else for (size_t i = 0; i < p->rounds.size(); ++i) samples[i] = p->rounds[i].samples;
     if (with_topup) samples[sweeps] = p->topup.samples;
     return AQE_OK;
