@@ -26,8 +26,8 @@ Q_FORCE_PERSIST = 4
 Q_NO_LAYOUT = 8
 Q_SHARE_GPU = 16
 Q_NO_LEAN = 32
-KERNEL_ROUND, KERNEL_SWEEP_PERSIST, KERNEL_SWEEP_LEAN, KERNEL_SWEEP_MULTI = 0, 1, 2, 3
-KERNEL_NAMES = {0: "k_round", 1: "k_sweep_persist", 2: "k_sweep_lean", 3: "k_sweep_multi"}
+KERNEL_ROUND, KERNEL_SWEEP_PERSIST, KERNEL_SWEEP_LEAN, KERNEL_SWEEP_MULTI, KERNEL_SWEEP_LEAN_MULTI = 0, 1, 2, 3, 4
+KERNEL_NAMES = {0: "k_round", 1: "k_sweep_persist", 2: "k_sweep_lean", 3: "k_sweep_multi", 4: "k_sweep_lean_multi"}
 F_TOPUP = 1
 F_PAIR = 2
 STAGE_KEEP_AOS = 1

@@ -182,7 +182,6 @@ struct aqe_plan {
     bool persist = false;
     SweepForm decide, totals;
     SweepForm decide_lean, totals_lean, head_lean;  // their lean variants (lean.hip), ok when the plan qualifies
-    SweepForm single_lean;                          // a single-round sampler as a lean launch (not persist)
     uint64_t last_samples = 0;                      // samples the most recent single launch swept
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
     const double* view_rounds = nullptr;  // stride-major view the rounds' families index (nullptr: the column itself)

@@ -199,17 +199,13 @@ hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long lo
 
 // ---- lean single-launch sweep of a multi-round query whose whole sweep is in flight at once: lean.hip -------------
 // A RUN is a family in its simplest form: `rows` consecutive rows of the column (or of a stride-major view) that all
-// belong to the sample — what exact scans and every strided pointer read through a view come to — or `rows` whole
-// segments of `seg_rows` such rows each, `pitch` rows apart (block samplers).
+// belong to the sample — what every strided pointer read through a view comes to.
 constexpr int kLeanMaxRuns = 64;                                        // one run per lane of a wave
 constexpr int kLeanMaxSlots = kMaxPersistGrid + kMaxPersistRounds;      // a round boundary splits at most one workgroup
 struct LeanRuns {  // in device memory, structure of arrays: lane i of every wave holds run i in registers
     uint64_t row0[kLeanMaxRuns];        // first row, relative to LeanLaunch::amount
     uint32_t tile_begin[kLeanMaxRuns];  // first tile of the run in the launch's tile list; 0xffffffff past the table
-    uint32_t rows[kLeanMaxRuns];        // rows of the run; segments of a segmented run
-    uint32_t seg_tiles[kLeanMaxRuns];   // 0: one stretch of rows; else tiles per segment
-    uint32_t seg_rows[kLeanMaxRuns];    // segmented run: rows per segment
-    uint64_t pitch[kLeanMaxRuns];       // segmented run: rows from one segment's start to the next
+    uint32_t rows[kLeanMaxRuns];
     uint32_t meta[kLeanMaxRuns];        // round | group << 8
     uint32_t slot[kLeanMaxRuns];        // of the run's round: its first slot | the first workgroup that sweeps tiles of it << 16
 };
@@ -233,6 +229,9 @@ struct LeanLaunch {
     uint32_t finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only;  // as in PersistLaunch
 };
 hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, bool nt, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// a batch of queries in one launch: table[q] describes query q (its epoch field is ignored), wg_map as for launch_sweep_multi
+hipError_t launch_sweep_lean_multi(const LeanLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, bool nt,
+                                   hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 hipError_t launch_replay(const double* totals, uint32_t rounds, uint32_t has_topup, const FoldParams& fp,
                          const FinalizeParams& fin, QueryState* state, aqe_result* result, hipStream_t s);

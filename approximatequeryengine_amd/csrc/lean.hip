@@ -1,5 +1,4 @@
-// lean.hip — k_sweep_lean: a query in ONE lean launch — every round of a multi-round (CLT) query, or a single-round
-// sampler — when its families are plain runs of rows.
+// lean.hip — k_sweep_lean: every round of a multi-round (CLT) query in ONE lean launch, judged once at the end.
 //
 // The reference's monitor (custom_bplus_db.cpp:885-1043) re-evaluates its rules while the pointer threads are still
 // walking, so that they can stop early (DB.cpp:930, 987).  k_sweep_persist (persist.hip) keeps that shape: a monitor
@@ -130,7 +129,7 @@ __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, cons
 // Wave 0 of the folding workgroup, lane q holding the moments through round q (or a slot's own total where the form
 // asks for that): the decision and the result.  The rules and what follows them are the monitor's (persist.hip,
 // monitor_fold), evaluated once, for every round at the same time.
-__device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], unsigned lane, unsigned* counter) {
+__device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], unsigned lane, unsigned* counter, unsigned long long epoch) {
     const unsigned rounds = K->rounds;
     const bool tslot = K->topup_slot != 0;  // the last slot is the top-up: summed on its own, never judged
     const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
@@ -197,15 +196,18 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
         *K->result = res;
         // the host polls the pinned result instead of waiting for the end of the launch: the check word tells it when
         // every field has landed (kernels.hpp, result_check)
-        __hip_atomic_store(K->result_seq, result_check(res, K->epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(K->result_seq, result_check(res, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef AQE_LEAN_STAMPS
     g_lean_stamps[static_cast<size_t>(kMaxPersistGrid) * kPersistWaves * 8 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
+// One query on the workgroups bid = 0 .. G-1 (a launch of its own, or one group of a batch's launch).  `a`: the fields
+// the sweep needs, in registers; K: the descriptor the folding workgroup reads the rest from (the kernel arguments of
+// a single launch, the batch's table in device memory otherwise).
 template <bool kNT>
-__global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
+__device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K, const unsigned bid, const unsigned G, const unsigned long long epoch) {
     __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];  // a wave's sums of a round (zero where it swept none)
     __shared__ double lds_flat[kLeanMaxSlots * kVec];                     // the folding workgroup's copy of the partial list
     __shared__ double lds_quarter[kMaxPersistRounds][kVec][4];
@@ -213,29 +215,26 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
     __shared__ unsigned lds_slot[kMaxPersistRounds];
     __shared__ unsigned lds_mask[kPersistWaves];  // rounds a wave swept tiles of
     __shared__ int s_last;
-    const LeanKarg K = (LeanKarg)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const unsigned wave = threadIdx.x >> 6;
     LEAN_STAMP(0);
     // the run table: lane i holds run i.  One batch of loads, in flight while LDS is cleared.
     const u64 my_row0 = a.runs->row0[lane];
     const unsigned my_tb = a.runs->tile_begin[lane], my_rows = a.runs->rows[lane], my_meta = a.runs->meta[lane], my_slot = a.runs->slot[lane];
-    const unsigned my_seg_tiles = a.runs->seg_tiles[lane], my_seg_rows = a.runs->seg_rows[lane];
-    const u64 my_pitch = a.runs->pitch[lane];
     // every wave clears its own rows of lds_part: nothing to wait for before the sweep
 #pragma unroll
     for (unsigned i = 0; i < kMaxPersistRounds * kVec / 64; ++i) {
         const unsigned x = static_cast<unsigned>(lane) + 64u * i;
         lds_part[x >> 3][wave][x & 7u] = 0.0;
     }
-    if (a.want_ticks && blockIdx.x == 0 && threadIdx.x == 0)
+    if (a.want_ticks && bid == 0 && threadIdx.x == 0)
         __hip_atomic_store(lean_t0_word(a.counter), static_cast<u64>(__builtin_amdgcn_s_memrealtime()), AQE_RLX);
 #ifdef AQE_LEAN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LEAN_STAMP(1);
 #endif
 
-    const unsigned t_lo = blockIdx.x * a.tiles_per_wg, t_end = t_lo + a.tiles_per_wg < a.ntiles ? t_lo + a.tiles_per_wg : a.ntiles;
+    const unsigned t_lo = bid * a.tiles_per_wg, t_end = t_lo + a.tiles_per_wg < a.ntiles ? t_lo + a.tiles_per_wg : a.ntiles;
     Acc acc;
     unsigned cur = ~0u, cur_slot = 0, touched = 0;  // the round this wave is in; the rounds it has been in
     auto flush = [&]() {
@@ -255,20 +254,9 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
             cur = r;
             cur_slot = __builtin_amdgcn_readlane(my_slot, i);
         }
-        const unsigned k = t - __builtin_amdgcn_readlane(my_tb, i);  // tile of the run
-        const unsigned seg_tiles = __builtin_amdgcn_readlane(my_seg_tiles, i);
-        unsigned first, rem;
-        u64 row = read_lane_u64(my_row0, i);
-        if (seg_tiles == 0) {
-            first = k * static_cast<unsigned>(kDenseTileOrdinals);
-            rem = __builtin_amdgcn_readlane(my_rows, i) - first;
-        } else {  // segmented run (blocks): tile k is tile j of segment k / seg_tiles
-            const unsigned seg = seg_tiles == 1u ? k : k / seg_tiles;
-            first = (k - seg * seg_tiles) * static_cast<unsigned>(kDenseTileOrdinals);
-            rem = __builtin_amdgcn_readlane(my_seg_rows, i) - first;
-            row += static_cast<u64>(seg) * read_lane_u64(my_pitch, i);
-        }
-        const double* const base = a.amount + (row + first);
+        const unsigned first = (t - __builtin_amdgcn_readlane(my_tb, i)) * static_cast<unsigned>(kDenseTileOrdinals);
+        const unsigned rem = __builtin_amdgcn_readlane(my_rows, i) - first;
+        const double* const base = a.amount + (read_lane_u64(my_row0, i) + first);
         TileAcc ta;
         lean_tile<kNT>(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
         merge_tile(acc, ta, ((meta >> 8) & 1u) != 0);
@@ -292,7 +280,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
             const unsigned r = static_cast<unsigned>(__builtin_ctz(m));
             m &= m - 1u;
             const unsigned info = lds_slot[r];
-            const unsigned slot = (info & 0xffffu) + blockIdx.x - (info >> 16);  // the round's workgroups are consecutive
+            const unsigned slot = (info & 0xffffu) + bid - (info >> 16);  // the round's workgroups are consecutive
             if (lane < 7) {
                 double x[kPersistWaves];
 #pragma unroll
@@ -307,14 +295,13 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
         LEAN_STAMP(5);
         if (lane == 0) {
             int last = 0;
-            const unsigned G = gridDim.x;
             unsigned* const ct = a.counter + static_cast<size_t>(kShards) * kShardStride;
             // at most 256 arrivals: 16 shards of 16 (a same-address atomic serialises at ~16 ns), then the top counter
             constexpr unsigned kLeanShards = 16;
             if (G <= kLeanShards) {
                 if (__hip_atomic_fetch_add(ct, 1u, AQE_RLX) == G - 1u) { __hip_atomic_store(ct, 0u, AQE_RLX); last = 1; }
             } else {
-                const unsigned sh = blockIdx.x % kLeanShards;
+                const unsigned sh = bid % kLeanShards;
                 const unsigned members = (G - sh + kLeanShards - 1u) / kLeanShards;
                 unsigned* const cs = a.counter + static_cast<size_t>(sh) * kShardStride;
                 if (__hip_atomic_fetch_add(cs, 1u, AQE_RLX) == members - 1u) {
@@ -365,10 +352,42 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
             tot[cc] += take ? x : 0.0;
         }
     }
-    lean_judge(K, tot, static_cast<unsigned>(lane), a.counter);
+    lean_judge(K, tot, static_cast<unsigned>(lane), a.counter, epoch);
+}
+
+template <bool kNT>
+__global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
+    lean_query<kNT>(a, (LeanKarg)__builtin_amdgcn_kernarg_segment_ptr(), blockIdx.x, gridDim.x, a.epoch);
+}
+
+// A BATCH of queries in one launch (as k_sweep_multi, persist.hip): the grid is cut into one group of workgroups per
+// query, wg_map[blockIdx.x] = query << 32 | group size << 16 | index in the group, group q runs table[q] exactly as a
+// launch of its own would on that many workgroups.  Nothing here waits for anything — the last workgroup of a group to
+// arrive finishes its query — so groups may be dispatched in any order and there may be more of them than compute units.
+template <bool kNT>
+__global__ __launch_bounds__(kPersistThreads) void k_sweep_lean_multi(const LeanLaunch* table, const unsigned long long* wg_map, unsigned long long epoch) {
+    const u64 me = uniform64(wg_map[blockIdx.x]);
+    const LeanKarg K = (LeanKarg)(table + (me >> 32));
+    LeanLaunch a;  // what the sweep reads, out of the table once
+    a.amount = K->amount; a.runs = K->runs; a.ntiles = K->ntiles; a.tiles_per_wg = K->tiles_per_wg;
+    a.has_where = K->has_where; a.wmin = K->wmin; a.wmax = K->wmax; a.shift = K->shift;
+    a.partials = K->partials; a.counter = K->counter; a.want_ticks = 0;
+    lean_query<kNT>(a, K, static_cast<unsigned>(me) & 0xffffu, static_cast<unsigned>(me >> 16) & 0xffffu, epoch);
 }
 
 }  // namespace
+
+hipError_t launch_sweep_lean_multi(const LeanLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, bool nt,
+                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (nt) {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_lean_multi<true>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, table, wg_map, epoch);
+        else hipLaunchKernelGGL(k_sweep_lean_multi<true>, dim3(grid), dim3(kPersistThreads), 0, s, table, wg_map, epoch);
+    } else {
+        if (ev0) hipExtLaunchKernelGGL(k_sweep_lean_multi<false>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, table, wg_map, epoch);
+        else hipLaunchKernelGGL(k_sweep_lean_multi<false>, dim3(grid), dim3(kPersistThreads), 0, s, table, wg_map, epoch);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, bool nt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (nt) {

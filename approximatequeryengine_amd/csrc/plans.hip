@@ -28,7 +28,7 @@ void destroy_plan(aqe_plan* p) {
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
     if (p->d_fams_small) (void)hipFree(p->d_fams_small);
-    for (SweepForm* f : {&p->decide, &p->totals, &p->head, &p->decide_lean, &p->totals_lean, &p->head_lean, &p->single_lean}) {
+    for (SweepForm* f : {&p->decide, &p->totals, &p->head, &p->decide_lean, &p->totals_lean, &p->head_lean}) {
         if (f->d_ppart) (void)hipFree(f->d_ppart);  // (the form's family table lives in the same block)
     }
     if (p->d_state) (void)hipFree(p->d_state);
@@ -291,7 +291,7 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
 int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t grid, size_t nrounds) {
     aqe_ctx* c = p->ctx;
     static const bool off = [] { const char* e = std::getenv("AQE_LEAN"); return e && e[0] == '0'; }();  // diagnostics: AQE_LEAN=0
-    if (off || !c->dense16 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;  // (grid 0: one workgroup per 16 tiles, at most the context's)
+    if (off || !c->dense16 || grid == 0 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;
     std::vector<const LaunchDesc*> slots;
     for (size_t r = 0; r < nrounds; ++r) slots.push_back(&p->rounds[r]);
     const bool tslot = with_topup_slot && p->host.has_topup;
@@ -312,55 +312,26 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
         round_begin[r] = tiles;
         for (uint32_t i = 0; i < L.nfam; ++i) {
             const DevFamily& d = p->h_fams[L.fam_offset + i];
-            // one pointer, step 1: its window is a stretch of one segment, or (blocks) the end of a first segment, a
-            // number of whole segments and the start of a last one — up to three runs
+            // a plain run: one pointer, step 1, its window inside one segment
             if (!is_dense16(d.step, d.flags, d.seg_len) || (d.flags & kFamLinear) || d.ord_hi <= d.ord_lo) return AQE_OK;
-            const uint64_t rebase = is_topup ? static_cast<uint64_t>(base_gap) : 0;  // one launch has one column base: the rounds'
+            const uint64_t seg = d.ord_lo / d.seg_len, len = d.ord_hi - d.ord_lo;
+            if ((d.ord_hi - 1) / d.seg_len != seg || nruns == static_cast<uint32_t>(kLeanMaxRuns) || len >= 0xffffffffull) return AQE_OK;
             // row of ordinal o: row0 + seg pitch - shard_lo + (o - seg seg_len)   (device_common.hpp, sweep_family; wraps like it)
-            auto row_of = [&](uint64_t o) { const uint64_t seg = o / d.seg_len; return d.row0 + seg * d.pitch - sw.shard_lo + (o - seg * d.seg_len) + rebase; };
-            auto add_run = [&](uint64_t o_lo, uint64_t o_hi) {  // a stretch inside one segment
-                const uint64_t len = o_hi - o_lo;
-                if (nruns == static_cast<uint32_t>(kLeanMaxRuns) || len >= 0xffffffffull) return false;
-                runs.row0[nruns] = row_of(o_lo);
-                runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
-                runs.rows[nruns] = static_cast<uint32_t>(len);
-                runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
-                tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
-                samples += len;
-                ++nruns;
-                return true;
-            };
-            const uint64_t s_lo = d.ord_lo / d.seg_len, s_hi = (d.ord_hi - 1) / d.seg_len;
-            if (s_lo == s_hi) {
-                if (!add_run(d.ord_lo, d.ord_hi)) return AQE_OK;
-                continue;
-            }
-            uint64_t whole_lo = s_lo, whole_hi = s_hi + 1;  // segments swept whole
-            if (d.ord_lo % d.seg_len) { if (!add_run(d.ord_lo, (s_lo + 1) * d.seg_len)) return AQE_OK; whole_lo = s_lo + 1; }
-            const bool tail = d.ord_hi % d.seg_len != 0;
-            if (tail) whole_hi = s_hi;
-            if (whole_hi > whole_lo) {
-                const uint64_t nseg = whole_hi - whole_lo, seg_tiles = (d.seg_len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
-                if (nruns == static_cast<uint32_t>(kLeanMaxRuns) || nseg >= 0xffffffffull || d.seg_len >= 0xffffffffull || tiles + nseg * seg_tiles >= 0xffffffffull) return AQE_OK;
-                runs.row0[nruns] = row_of(whole_lo * d.seg_len);
-                runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
-                runs.rows[nruns] = static_cast<uint32_t>(nseg);
-                runs.seg_tiles[nruns] = static_cast<uint32_t>(seg_tiles);
-                runs.seg_rows[nruns] = static_cast<uint32_t>(d.seg_len);
-                runs.pitch[nruns] = d.pitch;
-                runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
-                tiles += nseg * seg_tiles;
-                samples += nseg * d.seg_len;
-                ++nruns;
-            }
-            if (tail && !add_run(s_hi * d.seg_len, d.ord_hi)) return AQE_OK;
+            uint64_t row = d.row0 + seg * d.pitch - sw.shard_lo + d.ord_lo - seg * d.seg_len;
+            if (is_topup) row += static_cast<uint64_t>(base_gap);  // one launch has one column base: the rounds'
+            runs.row0[nruns] = row;
+            runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
+            runs.rows[nruns] = static_cast<uint32_t>(len);
+            runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
+            tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
+            samples += len;
+            ++nruns;
         }
         if (tiles == round_begin[r]) return AQE_OK;  // a slot without tiles: the other forms deal with it
     }
     round_begin[S] = tiles;
-    if (grid == 0) grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(c->persist_grid, 1u), (tiles + kPersistWaves - 1) / kPersistWaves));
     const uint64_t G = grid;
-    if (tiles == 0 || G == 0 || tiles + G >= 0xffffffffull) return AQE_OK;
+    if (tiles == 0 || tiles + G >= 0xffffffffull) return AQE_OK;
     const uint64_t K = (tiles + G - 1) / G;  // workgroup b owns the tiles [b K, (b + 1) K)
     uint32_t part_first[kMaxPersistRounds] = {0};
     for (size_t r = 0; r < S; ++r) {
@@ -622,12 +593,6 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                 }
             }
         }
-        // (below ~12 MB a sweep is a handful of tiles per compute unit and k_round's small workgroups spread it wider)
-        static const uint64_t single_min_tiles = [] { const char* e = std::getenv("AQE_LEAN_SINGLE_MIN_TILES"); return e ? static_cast<uint64_t>(std::atoll(e)) : 1536ull; }();
-        if (!multi && R == 1 && !p->host.is_random && !p->host.is_perm && !p->host.has_topup && p->rounds[0].ntiles >= single_min_tiles) {
-            int rc2 = build_lean_form(p.get(), false, p->single_lean, (q->flags & AQE_Q_SHARE_GPU) ? p->grid : 0u, 1);
-            if (rc2 != AQE_OK) return rc2;
-        }
         if (multi && R <= static_cast<size_t>(kMaxPersistRounds)) {
             int rc2 = build_sweep_form(p.get(), false, p->totals, p->grid, R);
             if (rc2 == AQE_OK) rc2 = build_lean_form(p.get(), false, p->totals_lean, p->grid, R);
@@ -821,12 +786,6 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             p->last_exec = 0;
             HIPCHK(c, hipGraphLaunch(p->round_graph, s));
             topup_done = true;
-        } else if (p->single_lean.ok && !(p->q.flags & (AQE_Q_NO_LEAN | AQE_Q_NO_PERSIST))) {
-            // a single-round sampler whose families are plain runs of rows (exact scans, strided pointers through a view,
-            // whole blocks): the lean launch, one round
-            int rc = launch_lean(p, p->single_lean, false, nullptr, s);
-            if (rc != AQE_OK) return rc;
-            topup_done = true;
         } else {
             plain_epoch = c->epoch++;  // launch by launch: the one that finishes the query writes the check word
             for (uint32_t i = 0; i < p->rounds.size(); ++i) {
@@ -999,6 +958,8 @@ struct BatchMulti {
     bool built = false;
     std::vector<SweepForm> forms;          // group form of plan i
     PersistLaunch* d_table = nullptr;      // [plans] descriptors, written once
+    bool lean = false;                     // every plan qualifies for the lean launch: groups of k_sweep_lean_multi
+    LeanLaunch* d_ltable = nullptr;        // ... and their descriptors
     unsigned long long* d_wgmap = nullptr; // [grid] workgroup -> (plan, group size, index in the group)
     unsigned grid = 0;
     uint64_t samples = 0;                  // rows one launch sweeps (all plans)
@@ -1029,7 +990,10 @@ void free_multi(BatchMulti& m) {
         if (f.d_ppart) (void)hipFree(f.d_ppart);
     m.forms.clear();
     if (m.d_table) (void)hipFree(m.d_table);
+    if (m.d_ltable) (void)hipFree(m.d_ltable);
     if (m.d_wgmap) (void)hipFree(m.d_wgmap);
+    m.d_ltable = nullptr;
+    m.lean = false;
     m.d_table = nullptr;
     m.d_wgmap = nullptr;
     m.built = false;
@@ -1097,11 +1061,37 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
     }
     m.forms.resize(n);
     std::vector<PersistLaunch> table(n);
+    std::vector<LeanLaunch> ltable;
     std::vector<unsigned long long> wgmap, monitors;
     const char* layout_env = std::getenv("AQE_MULTI_LAYOUT");
     const bool packed_layout = layout_env && std::strcmp(layout_env, "packed") == 0;
     m.samples = 0;
-    for (size_t i = 0; i < n; ++i) {
+    {   // Lean groups (lean.hip, k_sweep_lean_multi) when every plan of the batch qualifies: no monitor waves, the last
+        // workgroup of a group to arrive finishes its query.  (AQE_MULTI_LEAN=0: the groups of k_sweep_multi.)
+        static const bool lean_off = [] { const char* e = std::getenv("AQE_MULTI_LEAN"); return e && e[0] == '0'; }();
+        bool all = !lean_off;
+        std::vector<SweepForm> lf(n);
+        for (size_t i = 0; i < n && all; ++i) {
+            aqe_plan* p = b->plans[i];
+            if (p->q.flags & AQE_Q_NO_LEAN) { all = false; break; }
+            int rc = build_lean_form(p, head[i] != 0, lf[i], gs[i], head[i] ? p->r_head : p->rounds.size());
+            if (rc != AQE_OK) { for (SweepForm& f : lf) if (f.d_ppart) (void)hipFree(f.d_ppart); return rc; }
+            all = lf[i].ok;
+        }
+        if (all) {
+            m.lean = true;
+            ltable.resize(n);
+            for (size_t i = 0; i < n; ++i) {
+                fill_lean(b->plans[i], lf[i], kind == 1, kind == 1 ? dev_totals + i * row_stride : nullptr, 0, ltable[i]);
+                ltable[i].want_ticks = 0;
+                m.samples += lf[i].samples;
+            }
+            m.forms = std::move(lf);
+        } else {
+            for (SweepForm& f : lf) if (f.d_ppart) (void)hipFree(f.d_ppart);
+        }
+    }
+    for (size_t i = 0; i < n && !m.lean; ++i) {
         aqe_plan* p = b->plans[i];
         const size_t R = p->rounds.size();
         const uint32_t g = gs[i];
@@ -1148,8 +1138,13 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
     }
     wgmap.insert(wgmap.end(), monitors.begin(), monitors.end());
     m.grid = static_cast<unsigned>(wgmap.size());
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_table), n * sizeof(PersistLaunch)));
-    HIPCHK(c, hipMemcpy(m.d_table, table.data(), n * sizeof(PersistLaunch), hipMemcpyHostToDevice));
+    if (m.lean) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_ltable), n * sizeof(LeanLaunch)));
+        HIPCHK(c, hipMemcpy(m.d_ltable, ltable.data(), n * sizeof(LeanLaunch), hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_table), n * sizeof(PersistLaunch)));
+        HIPCHK(c, hipMemcpy(m.d_table, table.data(), n * sizeof(PersistLaunch), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m.d_wgmap), wgmap.size() * sizeof(unsigned long long)));
     HIPCHK(c, hipMemcpy(m.d_wgmap, wgmap.data(), wgmap.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     {   // Load policy of the launch.  The groups of a batch that sweep the same rows find each other's lines in the caches
@@ -1188,7 +1183,7 @@ int launch_multi(aqe_batch* b, int kind, hipStream_t s) {
         aqe_plan* p = b->plans[i];
         p->poll_epoch = kind == 0 ? epoch : 0;
         p->last_exec = kind == 0 ? 1 : 2;
-        p->last_kernel = AQE_KERNEL_SWEEP_MULTI;
+        p->last_kernel = m.lean ? AQE_KERNEL_SWEEP_LEAN_MULTI : AQE_KERNEL_SWEEP_MULTI;
         p->last_first_unswept = m.forms[i].slots - m.forms[i].topup_slot;
         p->last_grid = m.forms[i].grid;
         p->lev_used = 0;
@@ -1196,7 +1191,8 @@ int launch_multi(aqe_batch* b, int kind, hipStream_t s) {
         p->tick_timed = false;
     }
     b->profiled = b->profile;
-    HIPCHK(c, launch_sweep_multi(m.d_table, m.d_wgmap, epoch, m.grid, m.nt, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
+    if (m.lean) HIPCHK(c, launch_sweep_lean_multi(m.d_ltable, m.d_wgmap, epoch, m.grid, m.nt, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
+    else HIPCHK(c, launch_sweep_multi(m.d_table, m.d_wgmap, epoch, m.grid, m.nt, s, b->profile ? b->pev0 : nullptr, b->profile ? b->pev1 : nullptr));
     b->last_stream = s;
     b->last_kind = kind;
     return AQE_OK;

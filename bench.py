@@ -224,6 +224,7 @@ def cpu_baseline(rows_per_gpu: int, e: float, sample_rows: int) -> dict:
 # ---------------------------------------------------------------------------------------------------------------
 def measure_config(eng, st, name, q, reps=20, note=None):
     import statistics
+    from approximatequeryengine_amd import _native as nat
     plan = eng.plan(q)
     try:
         for _ in range(3):
@@ -244,7 +245,7 @@ def measure_config(eng, st, name, q, reps=20, note=None):
         tot = sorted(sum(x) for x in per_query)
         us = 1e3 * statistics.median(tot)
         nbytes = 8.0 * r.visited
-        out = {"config": name, "samples": int(r.visited), "n": int(r.n), "value": r.value, "ci": [r.ci_lower, r.ci_upper],
+        out = {"config": name, "kernel": nat.KERNEL_NAMES.get(plan.last_kernel(), "?"), "samples": int(r.visited), "n": int(r.n), "value": r.value, "ci": [r.ci_lower, r.ci_upper],
                "converged": int(r.converged), "rounds": int(r.rounds), "topup_rows": int(r.topup),
                "launches_per_query": len(per_query[-1]), "kernel_us": us, "kernel_us_min": 1e3 * tot[0],
                "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / (us * 1e-6) / 1e9 if us > 0 else None,
@@ -548,7 +549,7 @@ def main():
             finally:
                 del os.environ["AQE_MULTI_LAYOUT"]
 
-        # ---- a single query on the whole chip (k_sweep_persist), one in flight: launch time and closed loop ----
+        # ---- a single query on the whole chip (k_sweep_lean), one in flight: launch time and closed loop ----
         single = None
         if not use_dist:
             plan_one.set_profiling(True)
@@ -567,7 +568,7 @@ def main():
             lat.sort()
             acc.sort()
             s_us = 1e3 * sum(acc) / len(acc)
-            single = {"kernel": "k_sweep_persist", "avg_launch_us": s_us, "min_launch_us": 1e3 * acc[0], "samples": int(r_one.visited),
+            single = {"kernel": nat.KERNEL_NAMES.get(plan_one.last_kernel(), "?"), "avg_launch_us": s_us, "min_launch_us": 1e3 * acc[0], "samples": int(r_one.visited),
                       "achieved_GBps": 8.0 * r_one.visited / (s_us * 1e-6) / 1e9, "frac": 8.0 * r_one.visited / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                       "closed_loop_latency_us": {"p50": 1e6 * lat[len(lat) // 2], "min": 1e6 * lat[0]},
                       "aggregates_per_sec_one_in_flight": 1.0 / lat[len(lat) // 2]}

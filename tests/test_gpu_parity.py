@@ -106,8 +106,8 @@ def test_golden_calls_reduce_and_gather(nat, oracle, golden, table, engines, n):
         if g["n"]:
             assert rel(res.sum, call["fsum"]) <= SUM_TOL, call
             assert rel(res.sumsq, call["fsumsq"]) <= SUM_TOL, call
-        # the same call through the other kernel (where the lean launch is the default: one launch per round, and
-        # the monitor-wave kernel for a multi-round plan): same counts, sums to rounding
+        # the same call through the other kernels (a multi-round plan takes the lean launch by default: the monitor-wave
+        # kernel, and one launch per round): same counts, sums to rounding
         for other in (nat.Q_NO_LEAN, nat.Q_NO_PERSIST):
             q.flags = other
             alt = eng.reduce(q)
@@ -734,28 +734,6 @@ def test_single_launch_kernel_choice(nat, engines):
     for r in (r_mon, r_place, r_rounds):
         assert (r.n, r.visited, r.converged, r.rounds, r.topup) == (r_lean.n, r_lean.visited, r_lean.converged, r_lean.rounds, r_lean.topup)
         assert rel(r.sum, r_lean.sum) <= 1e-14 and rel(r.sumsq, r_lean.sumsq) <= 1e-14 and rel(r.ci_lower, r_lean.ci_lower) <= 1e-13
-    # single-round samplers: plain runs of rows (an exact scan, a strided pointer through its view, whole blocks) take the
-    # lean launch from ~12 MB of samples on; pages of 128 rows (short segments, tiled across) and an explicit AQE_Q_NO_LEAN take k_round
-    def single(method, pct, flags=0, **kw):
-        q = make_query(method, pct, **kw)
-        q.flags = flags
-        p = eng.plan(q)
-        p.enqueue_all(st)
-        r = p.fetch(st)
-        k = p.last_kernel()
-        p.close()
-        return k, r
-    for method, pct, kw, want in ((nat.M_EXACT, 100.0, {}, nat.KERNEL_SWEEP_LEAN), (nat.M_MEMORY_STRIDE, 20.0, {}, nat.KERNEL_SWEEP_LEAN),
-                                  (nat.M_BLOCK, 20.0, {"block_size": 1000}, nat.KERNEL_SWEEP_LEAN), (nat.M_BLOCK, 20.0, {"block_size": 2500}, nat.KERNEL_SWEEP_LEAN),
-                                  (nat.M_BLOCK, 1.0, {"block_size": 1000}, nat.KERNEL_ROUND),  # 100 tiles: a sweep this small stays with k_round
-                                  (nat.M_PAGE, 20.0, {"block_size": 128}, nat.KERNEL_ROUND)):
-        k, r = single(method, pct, **kw)
-        k2, r2 = single(method, pct, flags=nat.Q_NO_LEAN, **kw)
-        assert (k, k2) == (want, nat.KERNEL_ROUND), (method, pct)
-        assert (r.n, r.visited) == (r2.n, r2.visited) and rel(r.sum, r2.sum) <= 1e-13 and rel(r.sumsq, r2.sumsq) <= 1e-13 and rel(r.ci_upper, r2.ci_upper) <= 1e-12
-        k3, r3 = single(method, pct, where=(250.0, 750.0), **kw)
-        k4, r4 = single(method, pct, flags=nat.Q_NO_LEAN, where=(250.0, 750.0), **kw)
-        assert k3 == want and (r3.n, r3.visited) == (r4.n, r4.visited) and r3.n < r3.visited and rel(r3.sum, r4.sum) <= 1e-13
     # the head form of a query predicted to stop early is lean as well
     k_head, r_head = kernel_of(0, max_error_percent=1.0)
     k_head_mon, r_head_mon = kernel_of(nat.Q_NO_LEAN, max_error_percent=1.0)
