@@ -1,29 +1,34 @@
-// lean.hip — k_sweep_lean: every round of a multi-round (CLT) query in ONE lean launch, judged once at the end.
+// lean.hip — k_sweep_lean / k_sweep_lean_multi: every round of a multi-round (CLT) query in ONE lean launch, judged once
+// at the end — and a batch of such queries in one launch, a group of workgroups each.
 //
 // The reference's monitor (custom_bplus_db.cpp:885-1043) re-evaluates its rules while the pointer threads are still
 // walking, so that they can stop early (DB.cpp:930, 987).  k_sweep_persist (persist.hip) keeps that shape: a monitor
 // wave judges rounds as they complete and raises should_stop.  On a table of 10 M rows there is nothing left to stop:
-// every wave holds its one or two tiles in flight from the first microsecond, the sweep is over after five, and what
-// the query then waits for is the hand-off.  This kernel is for those queries (plans.hip picks it: at most two tiles per
-// wave, every family a plain run of rows) and is built for a short critical path:
+// every wave holds its tile in flight from the first microsecond, the sweep is over after five, and what the query then
+// waits for is the hand-off.  This kernel is for those queries — and for longer sweeps that are predicted not to stop
+// early (plans.hip, launch_form) — provided every family of the plan is a plain run of rows, which is what strided
+// pointers read through their stride-major views are.  It is built for a short critical path:
 //
 //   * no monitor wave, no polling, no stop word: every wave sweeps.  Workgroup b owns the tiles [b K, (b + 1) K) of the
 //     launch's list (K = tiles / workgroups, rounded up; its wave j takes the j-th, (j + 16)-th, ... of them: the 16 waves
 //     stream one window of the column), so it sweeps tiles of one round, or of a few consecutive ones; it publishes ONE
-//     56-byte partial per round it swept tiles of (sc1 stores, drained) and draws ONE ticket (k_round's sharded counters);
-//   * the workgroup that draws the last ticket reads the flat partial list — at most 288 slots — with all of its
-//     16 waves, sums every round's slots in a fixed order (bit-reproducible), and wave 0 then judges EVERY round at
-//     once, lane q evaluating the rules on the moments through round q (DB.cpp:936-961, 993-1016).  The first round
-//     that satisfies a rule — or the last — is the query's answer: a decision is a pure function of the partials, so
-//     the rounds swept beyond it change nothing (and cost nothing that was not already in flight);
+//     56-byte partial per round it swept tiles of (sc1 stores, drained) and draws ONE ticket (sharded counters, as k_round);
+//   * the workgroup that draws the last ticket sums every round's slots of the flat partial list — fewer than
+//     workgroups + rounds of them, whatever the size of the sweep — in a fixed order (bit-reproducible), 64 threads per
+//     round, and wave 0 then judges EVERY round at once, lane q evaluating the rules on the moments through round q
+//     (DB.cpp:936-961, 993-1016).  The first round that satisfies a rule — or the last — is the query's answer: a
+//     decision is a pure function of the partials, so the rounds swept beyond it change nothing;
 //   * the tile decode is a dozen instructions: lane i of every wave holds run i of the plan in registers (one batch of
 //     loads in the prologue), the run of a tile is found by one wave-wide comparison and read with v_readlane; tiles
-//     that lie inside their run — all but a run's last — take no masks.  (k_sweep_persist spent ~500 vector
-//     instructions per tile on window arithmetic: with four waves per SIMD the first tile of a 10 M-row query was
-//     folded after 3.3 us and the last after 8.3; here after 0.4 and 3.7 — tools/exp_latency.hip.)
+//     that lie inside their run — all but a run's last — take no masks.  With four waves per SIMD every instruction of
+//     a wave costs ~8 ns of wall time while all waves do the same thing, which they do at the start and at the end of a
+//     short query: k_sweep_persist's general tile path (~500 vector instructions of window arithmetic per tile) had the
+//     first tile of a 10 M-row query folded after 3.3 us and the last after 8.3, where a lean loop needs 0.4 and 3.7
+//     (tools/exp_latency.hip) — 17.7 us per launch against 10.
 //
 // Same forms as the persistent sweep (PersistLaunch): decisions in the kernel, the head form (rounds + the top-up as
-// one more slot, `more_rounds`), totals only (multi-GPU: every slot's total for the all-reduce).
+// one more slot, `more_rounds`), totals only (multi-GPU: every slot's total for the all-reduce).  Nothing in it waits
+// for another workgroup, so the groups of a batch (k_sweep_lean_multi) may outnumber the compute units.
 #include <hip/hip_ext.h>
 
 #include "device_common.hpp"
@@ -37,7 +42,7 @@ typedef const AQE_KARG LeanLaunch* LeanKarg;
 
 // Diagnostics (builds with -DAQE_LEAN_STAMPS only; tools/stamp_lean.py): s_memrealtime marks, 100 MHz.
 // [wave][8]: 0 entry, 1 table in registers, 2 first tile folded, 3 sweep done, 4 sums handed to the workgroup, 5 partial out
-// (wave 0), 6 ticket drawn (wave 0);  then [8] of the folding workgroup: 0 partials in LDS, 1 rounds summed, 2 judged
+// (wave 0), 6 ticket drawn (wave 0);  then [8] of the folding workgroup: 1 rounds summed, 2 judged
 #ifdef AQE_LEAN_STAMPS
 __device__ unsigned long long g_lean_stamps[(kMaxPersistGrid * kPersistWaves + 1) * 8];
 #define LEAN_STAMP(slot) do { if (lane == 0) g_lean_stamps[(static_cast<size_t>(blockIdx.x) * kPersistWaves + wave) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -129,7 +134,7 @@ __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, cons
 // Wave 0 of the folding workgroup, lane q holding the moments through round q (or a slot's own total where the form
 // asks for that): the decision and the result.  The rules and what follows them are the monitor's (persist.hip,
 // monitor_fold), evaluated once, for every round at the same time.
-__device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], unsigned lane, unsigned* counter, unsigned long long epoch) {
+__device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], unsigned lane, unsigned long long t0, unsigned long long epoch) {
     const unsigned rounds = K->rounds;
     const bool tslot = K->topup_slot != 0;  // the last slot is the top-up: summed on its own, never judged
     const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
@@ -185,7 +190,7 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
     }
     if (with_result && !result_now) res = make_result(st, fin);
     if (K->want_ticks) {
-        st.t0 = __hip_atomic_load(lean_t0_word(counter), AQE_RLX);
+        st.t0 = t0;
         res.kernel_ms = static_cast<double>(__builtin_amdgcn_s_memrealtime() - st.t0) * 1e-5;
     }
     res.rounds = st.rounds;
@@ -209,8 +214,6 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
 template <bool kNT>
 __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K, const unsigned bid, const unsigned G, const unsigned long long epoch) {
     __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];  // a wave's sums of a round (zero where it swept none)
-    __shared__ double lds_flat[kLeanMaxSlots * kVec];                     // the folding workgroup's copy of the partial list
-    __shared__ double lds_quarter[kMaxPersistRounds][kVec][4];
     __shared__ double lds_round[kMaxPersistRounds][kVec];
     __shared__ unsigned lds_slot[kMaxPersistRounds];
     __shared__ unsigned lds_mask[kPersistWaves];  // rounds a wave swept tiles of
@@ -316,25 +319,31 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K
     __syncthreads();
     if (!s_last) return;
 
-    // ---- the last workgroup to arrive folds the launch: every wave loads, sums in a fixed order ----
+    // ---- the last workgroup to arrive folds the launch.  Thread (q, c, part) — 64 threads per round, 16 rounds per
+    //      pass — sums component c of every eighth slot of round q straight out of the partial list (its loads in flight
+    //      together), eight neighbouring lanes combine their parts in a fixed order: bit-reproducible ----
     const unsigned rounds = K->rounds;
-    const unsigned nwords = K->slot_begin[rounds] * static_cast<unsigned>(kVec);
-    for (unsigned i = threadIdx.x; i < nwords; i += kPersistThreads) lds_flat[i] = __hip_atomic_load(a.partials + i, AQE_RLX);
-    __syncthreads();
-    LEAN_STAMP_FOLD(0);
-    {   // thread (q, c, quarter): every fourth slot of round q, component c
-        const unsigned q = threadIdx.x >> 5, c = (threadIdx.x >> 2) & 7u, part = threadIdx.x & 3u;
-        if (q < rounds && c < 7u) {
-            const unsigned b = K->slot_begin[q], e = K->slot_begin[q + 1u];
-            double s = 0.0;
-            for (unsigned sl = b + part; sl < e; sl += 4u) s += lds_flat[sl * static_cast<unsigned>(kVec) + c];
-            lds_quarter[q][c][part] = s;
+    const unsigned long long t0 = a.want_ticks ? __hip_atomic_load(lean_t0_word(a.counter), AQE_RLX) : 0ull;  // (in flight beside the partials)
+    for (unsigned q0 = 0; q0 < rounds; q0 += kPersistWaves) {
+        const unsigned q = q0 + wave, c = (static_cast<unsigned>(lane) >> 3) & 7u, part = static_cast<unsigned>(lane) & 7u;
+        const bool mine = q < rounds && c < 7u;
+        const unsigned b = mine ? K->slot_begin[q] : 0u, e = mine ? K->slot_begin[q + 1u] : 0u;
+        double s = 0.0;
+        constexpr unsigned kInFlight = 10;  // covers a round of 80 slots in one turn (a 10 M-row query's rounds: ~65)
+        for (unsigned sl0 = b + part; __ballot(sl0 < e) != 0; sl0 += 8u * kInFlight) {
+            double x[kInFlight];
+#pragma unroll
+            for (unsigned i = 0; i < kInFlight; ++i) {
+                const unsigned sl = sl0 + 8u * i;
+                x[i] = sl < e ? __hip_atomic_load(a.partials + static_cast<size_t>(sl) * kVec + c, AQE_RLX) : 0.0;
+            }
+#pragma unroll
+            for (unsigned i = 0; i < kInFlight; ++i) s += x[i];
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < kMaxPersistRounds * kVec) {
-        const unsigned q = threadIdx.x >> 3, c = threadIdx.x & 7u;
-        if (q < rounds && c < 7u) lds_round[q][c] = ((lds_quarter[q][c][0] + lds_quarter[q][c][1]) + lds_quarter[q][c][2]) + lds_quarter[q][c][3];
+        s += dpp_f64<0xB1>(s);   // lane ^ 1
+        s += dpp_f64<0x4E>(s);   // lane ^ 2
+        s += dpp_f64<0x141>(s);  // the other quad of the eight
+        if (mine && part == 0u) lds_round[q][c] = s;
     }
     __syncthreads();
     LEAN_STAMP_FOLD(1);
@@ -352,7 +361,7 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K
             tot[cc] += take ? x : 0.0;
         }
     }
-    lean_judge(K, tot, static_cast<unsigned>(lane), a.counter, epoch);
+    lean_judge(K, tot, static_cast<unsigned>(lane), t0, epoch);
 }
 
 template <bool kNT>

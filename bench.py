@@ -503,7 +503,7 @@ def main():
         firsts = drain()
         fence()
 
-        # ---- roofline of the dominant kernel (k_sweep_multi): ONE batch in flight, the launch's own begin/end
+        # ---- roofline of the dominant kernel (k_sweep_lean_multi): ONE batch in flight, the launch's own begin/end
         #      timestamps (event pair attached to the dispatch), before the throughput loop ----
         prof_steps = max(10, min(100, args.steps))
         natives[0].set_profiling(True)
@@ -519,6 +519,7 @@ def main():
             ms_min = min(ms_min, ms)
         natives[0].set_profiling(False)
         avg_launch_ms = ms_sum / prof_steps
+        batch_kernel = nat.KERNEL_NAMES.get(plan_sets[0][0].last_kernel(), "?")  # k_sweep_lean_multi when every plan of the batch qualifies
         bytes_per_launch = 8.0 * swept
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
 
@@ -674,8 +675,8 @@ def main():
         if not use_dist and rows == ROWS_PER_GPU and e == 0.01:
             doc = json.loads(PMC_FILE.read_text())
             if doc.get("source_hash") == source_hash() and doc.get("batch") == B:
-                traffic = doc["k_sweep_multi_traffic_bytes_per_launch"]
-                packed_traffic = doc.get("k_sweep_multi_packed_traffic_bytes_per_launch")
+                traffic = doc["batch_traffic_bytes_per_launch"]
+                packed_traffic = doc.get("batch_packed_traffic_bytes_per_launch")
                 traffic_src = f"{PMC_FILE.relative_to(ROOT)} (rocprofv3 --pmc, bytes per launch of {B} queries, sources {doc['source_hash']})"
             else:
                 traffic_src = f"{PMC_FILE.relative_to(ROOT)} was measured on other sources / another batch size: not reported"
@@ -706,7 +707,7 @@ def main():
             "result": {"value": last.value, "ci": [last.ci_lower, last.ci_upper], "n": int(last.n), "converged": int(last.converged),
                        "rounds": int(last.rounds), "same_as_first_execution": bool(agree)},
             "roofline": {
-                "bound": "hbm", "kernel": "k_sweep_multi", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": batch_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
                 "algorithmic_over_traffic": (bytes_per_launch / traffic) if traffic else None,

@@ -3,7 +3,7 @@ microseconds from the window's first dispatch.  usage: python tools/multi_timeli
 import csv, re, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: (re.search(r"(k_\w+|__amd_\w+)", r["Kernel_Name"]) or [r["Kernel_Name"][:30]])[0]
-multi = [i for i, r in enumerate(rows) if "k_sweep_multi" in r["Kernel_Name"]]
+multi = [i for i, r in enumerate(rows) if "k_sweep_multi" in r["Kernel_Name"] or "k_sweep_lean_multi" in r["Kernel_Name"]]
 lo = multi[len(multi) - 60]
 t0 = int(rows[lo]["Start_Timestamp"])
 print("# rocprofv3 --kernel-trace of `python3 bench.py --headline-only --steps 200` (tools/gpu_f.sh): a window of the timed loop,")

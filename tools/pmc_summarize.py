@@ -48,17 +48,19 @@ def traffic(prefix):
 def multi_halves(d):
     vals = []
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(path)) if "k_sweep_multi" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
+        rows = [r for r in csv.DictReader(open(path)) if re.search(r"k_sweep_(lean_)?multi", r["Kernel_Name"]) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         vals = [float(r["Counter_Value"]) for r in rows]
     h = len(vals) // 2
     return (statistics.median(vals[:h]), statistics.median(vals[h:])) if h else (None, None)
 fa, fp = multi_halves(fetch_dir)
 wa, wp = multi_halves(write_dir)
-doc["k_sweep_multi_traffic_bytes_per_launch"] = fa * 1024.0 * corr + (wa or 0.0) * 1024.0 if fa else None
-doc["k_sweep_multi_packed_traffic_bytes_per_launch"] = fp * 1024.0 * corr + (wp or 0.0) * 1024.0 if fp else None
-doc["k_sweep_multi_raw_KB"] = {"xcd_aligned (default)": {"FETCH_SIZE": fa, "WRITE_SIZE": wa}, "packed": {"FETCH_SIZE": fp, "WRITE_SIZE": wp}}
-doc["k_sweep_persist_traffic_bytes_per_launch"] = traffic("k_sweep_persist")
+# (the batch's one launch: k_sweep_lean_multi when every plan qualifies for the lean form, else k_sweep_multi)
+doc["batch_kernel"] = next((re.split(r"[<\s]", k, maxsplit=1)[0] for k in F if re.match(r"k_sweep_(lean_)?multi", k)), None)
+doc["batch_traffic_bytes_per_launch"] = fa * 1024.0 * corr + (wa or 0.0) * 1024.0 if fa else None
+doc["batch_packed_traffic_bytes_per_launch"] = fp * 1024.0 * corr + (wp or 0.0) * 1024.0 if fp else None
+doc["batch_raw_KB"] = {"xcd_aligned (default)": {"FETCH_SIZE": fa, "WRITE_SIZE": wa}, "packed": {"FETCH_SIZE": fp, "WRITE_SIZE": wp}}
+doc["single_query_traffic_bytes_per_launch"] = traffic("k_sweep_lean") or traffic("k_sweep_persist")
 doc["k_indexed_traffic_bytes_per_launch"] = traffic("k_indexed")
 # grouped sweeps (tools/pmc_probe.py runs, per key column, the reference's 10 % rowid sample — 1 M sampled rows, 12 B each: amount + key —
 # and the exact scan — 10 M rows): per template instance, the smaller median is the sample, the larger the scan
@@ -68,8 +70,8 @@ for inst in ("k_grouped<true>", "k_grouped<false>"):
         doc.setdefault("k_grouped_traffic_bytes_per_launch", {})[k] = F[k]["median_KB"] * 1024.0 * corr + W.get(k, {"median_KB": 0.0})["median_KB"] * 1024.0
 if len(sys.argv) > 5:  # a third pass: the batch of 32 exact scans over disjoint key ranges of a 320 M-row table (tools/pmc_probe_disjoint.py)
     D = medians(sys.argv[5])["FETCH_SIZE"]
-    k = max((k for k in D if named(k, "k_sweep_multi")), key=lambda k: D[k]["median_KB"])
-    doc["k_sweep_multi_disjoint_320M"] = {"kernel": k, "launches": D[k]["launches"], "fetch_raw_KB": D[k]["median_KB"],
+    k = max((k for k in D if named(k, "k_sweep_multi") or named(k, "k_sweep_lean_multi")), key=lambda k: D[k]["median_KB"])
+    doc["batch_disjoint_320M"] = {"kernel": k, "launches": D[k]["launches"], "fetch_raw_KB": D[k]["median_KB"],
                                           "traffic_bytes_per_launch": D[k]["median_KB"] * 1024.0 * corr, "algorithmic_bytes_per_launch": 8.0 * 320_000_000}
 json.dump(doc, open(dst, "w"), indent=1)
 print(json.dumps({k: v for k, v in doc.items() if not isinstance(v, dict) or k == "calibration"}, indent=1))
