@@ -159,7 +159,7 @@ typedef struct aqe_result {
                           against the leader's (DB.cpp:1009) */
     int32_t rounds;    /* CLT: rounds folded before the stop                                 */
     double kernel_ms;  /* aqe_reduce / timed executions: device time of the query by the device's own 100 MHz clock,
-                          from its first launch starting (the monitor wave, for a persistent launch) to the result
+                          from its first launch starting (its first workgroup, for a single-launch form) to the result
                           being written; a replayed graph of launches is timed by two events around it instead */
     uint64_t bytes_algorithmic; /* 8 B per visited sample (SoA amount column)                 */
     int32_t device_status; /* 0 ok; nonzero: the device-side round protocol reported an error   */
@@ -362,12 +362,13 @@ AQE_API int aqe_batch_enqueue_replays(aqe_batch* batch, const double* dev_totals
 AQE_API int aqe_batch_fetch(aqe_batch* batch, aqe_result* out_n);
 /* Single-GPU form of a batch: Q independent queries in ONE launch, decisions taken in the kernel.  The grid is cut
  * into one group of workgroups per plan (sizes in proportion to the plans' rows); group i runs plan i exactly as
- * aqe_plan_enqueue_all would on a launch of its own — its own monitor wave, its own should_stop word — so the
- * start of the launch and the decision tails of all Q queries are paid once instead of Q times.  This is what
+ * aqe_plan_enqueue_all would on a launch of its own — the last workgroup of the group to finish judges the query
+ * (lean groups, when every plan's families are plain runs of rows), or the group has its own monitor wave and
+ * should_stop word — so the start of the launch and the decision tails of all Q queries are paid once instead of Q times.  This is what
  * replaces the reference's thread creation per call (std::async workers per query, DB.cpp:918-1029) when queries
  * arrive in batches.  A plan predicted to stop early takes its head form (first rounds + the top-up) as its group.
  * Any plan with a family sampler and 1..32 rounds qualifies (not RANDOM_POINTER / RANDOM_DEVICE); the context must
- * hold the whole table.  Results: aqe_batch_fetch (each plan's result is picked up as soon as its monitor has written
+ * hold the whole table.  Results: aqe_batch_fetch (each plan's result is picked up as soon as its group has written
  * it).  A plan has ONE state and ONE result block: it may be part of several batches, but only one execution of it —
  * through a batch or on its own — may be in flight at a time (fetch before enqueueing it again elsewhere).
  * aqe_batch_enqueue_sweeps is the same launch with the decisions left to the replay after the all-reduce. */
