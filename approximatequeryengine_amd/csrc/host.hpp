@@ -183,6 +183,7 @@ struct aqe_plan {
     SweepForm decide, totals;
     SweepForm decide_lean, totals_lean, head_lean;  // their lean variants (lean.hip), ok when the plan qualifies
     uint64_t last_samples = 0;                      // samples the most recent single launch swept
+    bool last_topup_swept = false;                  // ... and whether it swept the top-up along (as one more slot)
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once
     const double* view_rounds = nullptr;  // stride-major view the rounds' families index (nullptr: the column itself)
     const double* view_topup = nullptr;   // ... and the top-up's

@@ -583,7 +583,10 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
                         // (with the top-up the monitor judges once, from one window of steps)
                         if (rc2 == AQE_OK && !(at.topup && F.step_begin[F.slots] > static_cast<uint32_t>(kDecSteps))) {
                             p->head = std::move(F);
-                            rc2 = build_lean_form(p.get(), at.topup, p->head_lean, g, r_head);
+                            // the lean variant has no window of steps to fit: it takes the top-up along whenever the plan has
+                            // one, on the whole grid when the top-up is what it mostly sweeps
+                            if (p->host.has_topup && !at.topup) rc2 = build_lean_form(p.get(), true, p->head_lean, p->grid, r_head);
+                            if (rc2 == AQE_OK && !p->head_lean.ok) rc2 = build_lean_form(p.get(), at.topup, p->head_lean, g, r_head);
                             if (rc2 != AQE_OK) return rc2;
                             break;
                         }
@@ -701,6 +704,7 @@ int launch_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_t
     p->last_exec = totals_only ? 2 : 1;
     p->last_kernel = AQE_KERNEL_SWEEP_LEAN;
     p->last_samples = L.samples;
+    p->last_topup_swept = L.topup_slot != 0 && !totals_only;
     p->last_grid = L.grid;
     p->last_first_unswept = L.slots - L.topup_slot;
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();
@@ -716,7 +720,8 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     // A sweep that is in flight all at once (two tiles per wave: 64 MB) has nothing to gain from a monitor; a longer
     // one takes the lean launch when the rules are predicted not to hold before the plan runs out of rounds (create_plan)
     // — should the prediction fail, the answer is the same and the rounds behind the stopping one were swept for nothing.
-    const bool lean_pays = lean && lean->ok && (lean->ntiles <= 2ull * lean->grid * kPersistWaves || p->predicted_full);
+    // (The head form is judged once, at the end, by either kernel.)
+    const bool lean_pays = lean && lean->ok && (lean->ntiles <= 2ull * lean->grid * kPersistWaves || p->predicted_full || &F == &p->head);
     if (lean_pays && !c->d_stamps && !(p->q.flags & AQE_Q_NO_LEAN)) return launch_lean(p, *lean, totals_only, out_totals, s);
     PersistLaunch a;
     fill_form(p, F, totals_only, out_totals, c->epoch++, true, a);
@@ -724,6 +729,7 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     p->last_exec = totals_only ? 2 : 1;
     p->last_kernel = AQE_KERNEL_SWEEP_PERSIST;
     p->last_samples = F.samples;
+    p->last_topup_swept = F.topup_slot != 0 && !totals_only;
     p->last_grid = F.grid;
     p->last_first_unswept = F.slots - F.topup_slot;
     if (c->d_stamps) {
@@ -766,7 +772,7 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             // The monitor has written the result.  The top-up (DB.cpp:1031-1040) is rarely due — only when the query
             // stops with fewer than base/4 rows — so its launch is enqueued only for plans whose last execution
             // needed it; otherwise the result carries topup_pending if it was due after all, and fetch() runs it.
-            topup_done = F.topup_slot || !p->expect_topup;
+            topup_done = p->last_topup_swept || !p->expect_topup;
         } else if (p->rounds.size() >= kGraphMinRounds && p->rounds.size() <= kGraphMaxRounds && !p->profile && !std::getenv("AQE_NO_GRAPH")) {
             // One launch per round is a launch-bound loop (every launch after the stop is a device-side no-op): it is
             // captured ONCE per plan into a HIP graph — the launches' arguments never change — and replayed.

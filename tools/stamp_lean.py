@@ -31,6 +31,6 @@ for it in range(8):
     t0 = w[live, 0].min()
     us = lambda x: (x - t0) / 100.0
     col = lambda k: w[live & (w[:, k] > 0), k]
-    print("%s %dM: starts ..%.2f | table %.2f..%.2f | first tile %.2f..%.2f | sweep done %.2f..%.2f | handed ..%.2f | partial out %.2f..%.2f | ticket %.2f..%.2f | fold: loaded %.2f summed %.2f judged %.2f" % (
+    print("%s %dM: starts ..%.2f | table %.2f..%.2f | first tile %.2f..%.2f | sweep done %.2f..%.2f | handed ..%.2f | partial out %.2f..%.2f | ticket %.2f..%.2f | fold: rounds summed %.2f judged %.2f" % (
         what, rows // 1000000, us(col(0).max()), us(col(1).min()), us(col(1).max()), us(col(2).min()), us(col(2).max()), us(col(3).min()), us(col(3).max()), us(col(4).max()),
-        us(col(5).min()), us(col(5).max()), us(col(6).min()), us(col(6).max()), us(f[0]), us(f[1]), us(f[2])))
+        us(col(5).min()), us(col(5).max()), us(col(6).min()), us(col(6).max()), us(f[1]), us(f[2])))
