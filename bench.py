@@ -259,8 +259,10 @@ def measure_config(eng, st, name, q, reps=20, note=None):
 
 
 def measure_batch(eng, Batch, st, name, queries, reps=20):
-    """A batch of queries in ONE launch (k_sweep_multi): launch time from the dispatch's events, every result fetched."""
+    """A batch of queries in ONE launch (k_sweep_lean_multi, or k_sweep_multi when a plan of the batch has families that are
+    not plain runs of rows): launch time from the dispatch's events, every result fetched."""
     import statistics
+    from approximatequeryengine_amd import _native as nat
     plans = [eng.plan(q) for q in queries]
     b = Batch(plans)
     try:
@@ -280,7 +282,8 @@ def measure_batch(eng, Batch, st, name, queries, reps=20):
         us = 1e3 * statistics.median(ms)
         nbytes = 8.0 * sum(r.visited for r in rs)
         wall = statistics.median(lat)
-        return {"config": name, "queries_per_launch": len(queries), "samples": int(sum(r.visited for r in rs)), "kernel_us": us,
+        return {"config": name, "kernel": nat.KERNEL_NAMES.get(plans[0].last_kernel(), "?"), "queries_per_launch": len(queries),
+                "samples": int(sum(r.visited for r in rs)), "kernel_us": us,
                 "kernel_us_min": 1e3 * min(ms), "workgroups": int(wgs), "algorithmic_bytes": nbytes,
                 "achieved_GBps": nbytes / (us * 1e-6) / 1e9, "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                 "closed_loop_us_p50": 1e6 * wall, "aggregates_per_sec_one_batch_in_flight": len(queries) / wall,
@@ -713,17 +716,24 @@ def main():
                 "algorithmic_over_traffic": (bytes_per_launch / traffic) if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms, "min_launch_us": 1e3 * ms_min,
                 "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps, "packed_layout": packed,
-                "note": "8 B per sampled row (SoA f64 amount column) x the rows all queries of the batch sweep / mean duration of the ONE "
-                        "launch that serves the batch; the duration is the dispatch's own begin/end timestamps (HIP events attached to "
-                        "the launch, hipExtLaunchKernelGGL, on the launch stream) - the clock rocprofv3 reports "
-                        "(profiles/round2_bench_kernel_stats.csv).  READ WITH `traffic`: every query executes all of its own loads, but "
-                        "the launch is XCD-aware - workgroup k of every group sits on compute die k mod 8 - and the queries of a batch "
-                        "sample the same rows (the reference's samplers are deterministic in (N, pct)), so they read them out of that "
-                        "die's L2 together and the fabric moves a fraction of the algorithmic bytes (PMC); `packed_layout` is the same "
-                        "batch without the alignment (traffic ~ algorithmic).  Either way a 10 M-row column with its stride-major views "
-                        "(80 MB each) stays in the 256 MiB Infinity Cache: cache-assisted bandwidth priced against the HBM peak.  HBM "
-                        "proper: `configs` has the same kernel on a batch whose queries share no byte (32 disjoint 10 M-row key ranges "
-                        "of a 320 M-row table: traffic = algorithmic) and the 100 M / 1 B-row lines",
+                "served_from": "L2 of the compute dies (the batch's queries sample the same rows; the launch is XCD-aware), backed by the "
+                               "Infinity Cache: NOT HBM-bound - see `traffic` and `l2_rate`",
+                "l2_rate": {"achieved_GBps": achieved, "guide_measured_GBps": [16800, 18800],
+                            "frac_of_guide_max": achieved / 18800.0,
+                            "source": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': rows shared by every workgroup, served by the XCDs' L2s, "
+                                      "read at 16.8-18.8 TB/s chip-wide"},
+                "note": "`achieved` is what the contract defines: 8 B per sampled row (SoA f64 amount column) x the rows all queries of the "
+                        "batch sweep / mean duration of the ONE launch that serves the batch (the dispatch's own begin/end timestamps: HIP "
+                        "events attached to the launch, hipExtLaunchKernelGGL, on the launch stream - the clock rocprofv3 reports, "
+                        "profiles/round2_bench_kernel_stats.csv).  A `frac` ABOVE 1 says that these bytes do not come out of HBM: every "
+                        "query executes all of its own loads, but the launch is XCD-aware - workgroup k of every group sits on compute "
+                        "die k mod 8 and sweeps the k-th share of its query's tiles - and the queries of a batch sample the same rows (the "
+                        "reference's samplers are deterministic in (N, pct)), so they read them out of that die's L2 together: the fabric "
+                        "moves a fifth of the algorithmic bytes (`traffic`, PMC) and the launch runs at the rate the guide measures for "
+                        "L2-served reads (`l2_rate`).  `packed_layout` is the same batch without the alignment: traffic ~ algorithmic, "
+                        "Infinity-Cache bandwidth (a 10 M-row column with its stride-major views, 80 MB each, stays in the 256 MiB cache). "
+                        " HBM proper: `configs` has the same kernel on a batch whose queries share no byte (32 disjoint 10 M-row key "
+                        "ranges of a 320 M-row table: traffic = algorithmic) and the 100 M / 1 B-row lines",
             },
             "single_query": single,
             "open_loop_by_batch_size": open_loop,
