@@ -204,7 +204,7 @@ hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long lo
 // ---- lean single-launch sweep of a multi-round query whose whole sweep is in flight at once: lean.hip -------------
 // A RUN is a family in its simplest form: `rows` consecutive rows of the column (or of a stride-major view) that all
 // belong to the sample — what every strided pointer read through a view comes to.
-constexpr int kLeanMaxRuns = 64;                                        // one run per lane of a wave
+constexpr int kLeanMaxRuns = 128;                                       // two runs per lane of a wave: lane i holds runs i and i + 64
 constexpr int kLeanMaxSlots = kMaxPersistGrid + kMaxPersistRounds;      // a round boundary splits at most one workgroup
 struct LeanRuns {  // in device memory, structure of arrays: lane i of every wave holds run i in registers
     uint64_t row0[kLeanMaxRuns];        // first row, relative to LeanLaunch::amount

@@ -18,7 +18,7 @@
 //     round, and wave 0 then judges EVERY round at once, lane q evaluating the rules on the moments through round q
 //     (DB.cpp:936-961, 993-1016).  The first round that satisfies a rule — or the last — is the query's answer: a
 //     decision is a pure function of the partials, so the rounds swept beyond it change nothing;
-//   * the tile decode is a dozen instructions: lane i of every wave holds run i of the plan in registers (one batch of
+//   * the tile decode is a dozen instructions: lane i of every wave holds runs i and i + 64 of the plan in registers (one batch of
 //     loads in the prologue), the run of a tile is found by one wave-wide comparison and read with v_readlane; tiles
 //     that lie inside their run — all but a run's last — take no masks.  With four waves per SIMD every instruction of
 //     a wave costs ~8 ns of wall time while all waves do the same thing, which they do at the start and at the end of a
@@ -221,9 +221,10 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K
     const int lane = threadIdx.x & 63;
     const unsigned wave = threadIdx.x >> 6;
     LEAN_STAMP(0);
-    // the run table: lane i holds run i.  One batch of loads, in flight while LDS is cleared.
-    const u64 my_row0 = a.runs->row0[lane];
+    // the run table: lane i holds runs i and i + 64.  One batch of loads, in flight while LDS is cleared.
+    const u64 my_row0 = a.runs->row0[lane], my_row0_hi = a.runs->row0[lane + 64];
     const unsigned my_tb = a.runs->tile_begin[lane], my_rows = a.runs->rows[lane], my_meta = a.runs->meta[lane], my_slot = a.runs->slot[lane];
+    const unsigned my_tb_hi = a.runs->tile_begin[lane + 64], my_rows_hi = a.runs->rows[lane + 64], my_meta_hi = a.runs->meta[lane + 64], my_slot_hi = a.runs->slot[lane + 64];
     // every wave clears its own rows of lds_part: nothing to wait for before the sweep
 #pragma unroll
     for (unsigned i = 0; i < kMaxPersistRounds * kVec / 64; ++i) {
@@ -249,17 +250,19 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K
     };
     for (unsigned t = __builtin_amdgcn_readfirstlane(t_lo + wave); t < t_end; t += kPersistWaves) {
         // the run that owns tile t: the last whose first tile is <= t (ascending; 0xffffffff past the table)
-        const unsigned i = static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb <= t))) - 1u;
-        const unsigned meta = __builtin_amdgcn_readlane(my_meta, i);
+        const unsigned below = static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb <= t))) + static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb_hi <= t)));
+        const bool hi = below > 64u;           // wave-uniform: the run sits in the lanes' second set
+        const unsigned i = (below - 1u) & 63u;
+        const unsigned meta = hi ? __builtin_amdgcn_readlane(my_meta_hi, i) : __builtin_amdgcn_readlane(my_meta, i);
         const unsigned r = meta & 0xffu;
         if (r != cur) {
             if (cur != ~0u) { flush(); acc = Acc{}; }
             cur = r;
-            cur_slot = __builtin_amdgcn_readlane(my_slot, i);
+            cur_slot = hi ? __builtin_amdgcn_readlane(my_slot_hi, i) : __builtin_amdgcn_readlane(my_slot, i);
         }
-        const unsigned first = (t - __builtin_amdgcn_readlane(my_tb, i)) * static_cast<unsigned>(kDenseTileOrdinals);
-        const unsigned rem = __builtin_amdgcn_readlane(my_rows, i) - first;
-        const double* const base = a.amount + (read_lane_u64(my_row0, i) + first);
+        const unsigned first = (t - (hi ? __builtin_amdgcn_readlane(my_tb_hi, i) : __builtin_amdgcn_readlane(my_tb, i))) * static_cast<unsigned>(kDenseTileOrdinals);
+        const unsigned rem = (hi ? __builtin_amdgcn_readlane(my_rows_hi, i) : __builtin_amdgcn_readlane(my_rows, i)) - first;
+        const double* const base = a.amount + ((hi ? read_lane_u64(my_row0_hi, i) : read_lane_u64(my_row0, i)) + first);
         TileAcc ta;
         lean_tile<kNT>(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
         merge_tile(acc, ta, ((meta >> 8) & 1u) != 0);

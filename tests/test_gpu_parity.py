@@ -734,6 +734,12 @@ def test_single_launch_kernel_choice(nat, engines):
     for r in (r_mon, r_place, r_rounds):
         assert (r.n, r.visited, r.converged, r.rounds, r.topup) == (r_lean.n, r_lean.visited, r_lean.converged, r_lean.rounds, r_lean.topup)
         assert rel(r.sum, r_lean.sum) <= 1e-14 and rel(r.sumsq, r_lean.sumsq) <= 1e-14 and rel(r.ci_lower, r_lean.ci_lower) <= 1e-13
+    # 32 pointers: 96 runs, two per lane of the run table
+    k_wide, r_wide = kernel_of(0, num_threads=32)
+    k_wide_mon, r_wide_mon = kernel_of(nat.Q_NO_LEAN, num_threads=32)
+    assert (k_wide, k_wide_mon) == (nat.KERNEL_SWEEP_LEAN, nat.KERNEL_SWEEP_PERSIST)
+    assert (r_wide.n, r_wide.visited, r_wide.converged, r_wide.rounds) == (r_wide_mon.n, r_wide_mon.visited, r_wide_mon.converged, r_wide_mon.rounds)
+    assert rel(r_wide.sum, r_wide_mon.sum) <= 1e-14 and rel(r_wide.sumsq, r_wide_mon.sumsq) <= 1e-14 and rel(r_wide.ci_lower, r_wide_mon.ci_lower) <= 1e-13
     # the head form of a query predicted to stop early is lean as well
     k_head, r_head = kernel_of(0, max_error_percent=1.0)
     k_head_mon, r_head_mon = kernel_of(nat.Q_NO_LEAN, max_error_percent=1.0)
