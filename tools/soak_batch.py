@@ -1,4 +1,4 @@
-"""Dev helper: soak the one-launch batch (k_sweep_multi) — three batches of mixed queries (CLT never converging / stopping
+"""Dev helper: soak the one-launch batch (mixed kinds: k_sweep_multi; `clt` as second argument: CLT plans only, k_sweep_lean_multi) — three batches of mixed queries (CLT never converging / stopping
 early with the top-up / stopping in the middle, strided, block + WHERE, exact, pages) alternate on two streams, a
 single-plan launch runs in between on a third, every result of every step is fetched and compared BITWISE with the
 first execution of its plan.  A protocol failure shows up as AqeError (device_status) or a changed answer."""
@@ -15,6 +15,8 @@ def clt(e, r0, g, t, agg=nat.AVG):
 kinds = [clt(0.01, 4096, 4, 4), clt(1.0, 4096, 4, 6, nat.SUM), clt(0.05, 512, 2, 8), clt(0.0, 64, 3, 6, nat.COUNT), clt(0.03, 1024, 4, 10),
          make_query(nat.M_MEMORY_STRIDE, 1.0), make_query(nat.M_MEMORY_STRIDE, 20.0, agg=nat.AVG), make_query(nat.M_BLOCK, 1.0, where=(250.0, 750.0), convention=nat.EST_CPP),
          make_query(nat.M_EXACT, 100.0), make_query(nat.M_PAGE, 5.0, block_size=4096)]
+if len(sys.argv) > 2 and sys.argv[2] == "clt":  # only plans that qualify for the lean groups (k_sweep_lean_multi)
+    kinds = kinds[:5] + [clt(0.5, 256, 2, 12), clt(2.0, 4096, 4, 16, nat.SUM)]
 sizes = (32, 7, 64)
 batches, plans = [], []
 for n in sizes:
