@@ -367,7 +367,10 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
 
 namespace {
 
-constexpr uint64_t kViewMinSamples = 1u << 16;  // smaller sweeps are launch-bound: not worth a copy of the column
+// Sweeps below 65 536 samples are launch-bound and gain no bandwidth from a copy of the column: they stay in place — unless
+// the copy is cheap (a shard of at most 16 M rows: 128 MB, built in well under a millisecond) and the sweep is at least a
+// few tiles: a plan over views is a plan of plain runs, and those take the lean launch (10 us instead of 17 for a CLT query).
+constexpr uint64_t kViewMinSamples = 1u << 16, kViewMinSamplesSmallTable = 1u << 12, kViewSmallTableRows = 1u << 24;
 constexpr uint64_t kViewMaxStep = 1024;
 
 // Rewrites a list of single-segment strided families of one common step into dense families over that step's
@@ -380,7 +383,7 @@ int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, co
             step = f.step;
             total += family_size(f);
         }
-    if (!step || total < kViewMinSamples) return AQE_OK;
+    if (!step || total < (c->n_local <= kViewSmallTableRows ? kViewMinSamplesSmallTable : kViewMinSamples)) return AQE_OK;
     uint64_t M = 0, q0 = 0;
     int rc = ensure_stride_view(c, step, view, &M, &q0);
     if (rc != AQE_OK) return rc;
