@@ -519,13 +519,16 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         // aggregates/s with 32 in flight — at the price of a longer launch when it runs alone (19.4 against 16.4 us).
         p->grid = (q->flags & AQE_Q_SHARE_GPU) ? std::max(16u, c->persist_grid / 2) : c->persist_grid;
         const bool multi = !p->host.is_random && !p->host.is_perm && R >= 2 && p->grid > 0;
-        {   // will the query run out of rounds before the error rule can hold (the prediction described below)?
+        {   // Will the query need (nearly) all of its rounds — the rule predicted to hold in the last round, within the one
+            // round of margin of it, or not at all (the prediction described below)?  Then nothing is gained by judging early.
             p->predicted_full = !p->host.is_clt || q->max_error_percent <= 0.0;
             if (p->host.is_clt && c->head_cv > 0.0 && q->max_error_percent > 0.0) {
                 const double root = p->host.clt.z * c->head_cv * 100.0 / q->max_error_percent;
+                const double n_stop = std::max(50.0, root * root), workers = static_cast<double>(std::max(1, p->host.clt.n_workers));
                 double leader = 0.0;
-                for (const LaunchDesc& L : p->rounds) leader += static_cast<double>(L.samples) / static_cast<double>(std::max(1, p->host.clt.n_workers));
-                p->predicted_full = leader < std::max(50.0, root * root);
+                size_t r_pred = 0;
+                for (; r_pred < R && leader < n_stop; ++r_pred) leader += static_cast<double>(p->rounds[r_pred].samples) / workers;
+                p->predicted_full = r_pred + 1 >= R;
             }
         }
         const bool whole = c->shard_lo == 0 && c->n_local == c->n_global;
