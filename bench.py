@@ -341,8 +341,8 @@ def run_configs(eng, nat, make_query, st, max_rows, Batch=None):
                                       make_query(nat.M_BLOCK, 1.0, where=(250.0, 750.0), convention=nat.EST_CPP)))
             out.append(measure_config(eng, st, f"{tag} CLT AVG e=0.01% (never converges)", clt(0.01)))
             if Batch is not None:  # the batch form on an HBM-resident table
-                out.append(measure_batch(eng, Batch, st, f"{tag}: batch of 8 different CLT e=0.01% queries in ONE launch (a table 10x the Infinity Cache: over a "
-                                         "0.5 ms sweep the groups drift further apart than an L2 holds - HBM proper, the fixed costs paid once)", headline_queries(nat, make_query, 8, 1, 0.01), reps=10))
+                out.append(measure_batch(eng, Batch, st, f"{tag}: batch of 8 different CLT e=0.01% queries in ONE launch (a table 10x the Infinity Cache: what the "
+                                         "groups share in the caches depends on how far they drift apart over the sweep - 0.71 to 0.95 from run to run)", headline_queries(nat, make_query, 8, 1, 0.01), reps=10))
         else:
             out.append(measure_config(eng, st, f"config3-local {tag} CLT AVG e=0.005% (never converges: full 20% dual-pointer sweep)", clt(0.005), reps=10))
             out.append(measure_config(eng, st, f"config3-local {tag} CLT AVG e=0.5% (stops early + top-up)", clt(0.5), reps=10))
