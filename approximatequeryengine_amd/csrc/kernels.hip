@@ -21,6 +21,18 @@
 namespace aqe {
 namespace {
 
+// Diagnostics (builds with -DAQE_ROUND_STAMPS only; tools/stamp_round.py): s_memrealtime marks of k_round, 100 MHz.
+// [wave][8]: 0 entry, 1 family table staged, 2 first tile folded, 3 sweep done, 4 workgroup summed, 5 partial out, 6 ticket drawn;
+// then [8] of the folding workgroup: 0 partials read, 1 folded and published
+#ifdef AQE_ROUND_STAMPS
+__device__ unsigned long long g_round_stamps[(kMaxBlocks * kWavesPerBlock + 1) * 8];
+#define ROUND_STAMP(slot) do { if ((threadIdx.x & 63) == 0) g_round_stamps[(static_cast<size_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ROUND_STAMP_FOLD(slot) do { if (threadIdx.x == 0) g_round_stamps[static_cast<size_t>(kMaxBlocks) * kWavesPerBlock * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ROUND_STAMP(slot) do { } while (0)
+#define ROUND_STAMP_FOLD(slot) do { } while (0)
+#endif
+
 // Sum 7 per-thread values over the workgroup in a fixed order: wave64 butterfly (wave_sum7), then the
 // four wave results through LDS.  The totals are valid in thread 0.  `red` must be quiescent on entry.
 __device__ __forceinline__ void block_sum7(double (&v)[7], double (*red)[kVec]) {
@@ -95,6 +107,7 @@ __device__ __forceinline__ void finish_block(const Acc& acc, const RoundLaunch& 
     double v[7] = {static_cast<double>(acc.na), acc.sa, acc.qa, static_cast<double>(acc.nb), acc.sb, acc.qb,
                    static_cast<double>(acc.nv)};
     block_sum7(v, red);
+    ROUND_STAMP(4);
     if (gridDim.x == 1) {  // a launch small enough for one workgroup needs no hand-off
         if (threadIdx.x == 0) fold_and_finish(v, a);
         return;
@@ -104,6 +117,7 @@ __device__ __forceinline__ void finish_block(const Acc& acc, const RoundLaunch& 
 #pragma unroll
         for (int k = 0; k < 7; ++k) __hip_atomic_store(mine + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial is out before the ticket is drawn
+        ROUND_STAMP(5);
         // two-level ticket: shard (blockIdx % kShards), then the top counter
         const unsigned shards = gridDim.x < static_cast<unsigned>(kShards) ? gridDim.x : static_cast<unsigned>(kShards);
         const unsigned sh = blockIdx.x % shards;
@@ -124,18 +138,45 @@ __device__ __forceinline__ void finish_block(const Acc& acc, const RoundLaunch& 
             }
         }
         s_last = last;
+        ROUND_STAMP(6);
     }
     __syncthreads();
     if (!s_last) return;
-    double t[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += kBlockThreads) {
-        const double* p = a.partials + static_cast<size_t>(b) * kVec;
+    // Thread t sums the words t, t + 256, ... of the flat partial list — component t & 7 of every 32nd workgroup — with
+    // coalesced loads (a wave instruction covers eight whole partials; one lane per workgroup, seven loads each, asked the
+    // memory system for every 64-byte partial seven times: 3.3 us for 1024 workgroups, tools/stamp_round.py), sixteen in
+    // flight; lanes of equal component then add up over the wave and the waves through LDS, in a fixed order.
+    double fs = 0.0;
+    const unsigned nwords = gridDim.x * static_cast<unsigned>(kVec);
+    for (unsigned w0 = threadIdx.x; w0 < nwords; w0 += 16u * kBlockThreads) {
+        double x[16];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) t[k] += __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned i = 0; i < 16u; ++i) {
+            const unsigned w = w0 + i * kBlockThreads;
+            x[i] = w < nwords ? __hip_atomic_load(a.partials + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (unsigned i = 0; i < 16u; ++i) fs += x[i];
     }
+    fs += dpp_f64<0x128>(fs);     // lane ^ 8
+    fs = swap_add16(fs, fs);     // lane ^ 16
+    fs = swap_add32(fs, fs);     // lane ^ 32: lanes 0..7 (and every lane of their class) hold the wave's sum of component lane & 7
     __syncthreads();  // `red` is reused
-    block_sum7(t, red);
-    if (threadIdx.x == 0) fold_and_finish(t, a);
+    ROUND_STAMP_FOLD(0);
+    if ((threadIdx.x & 63) < 8) red[threadIdx.x >> 6][threadIdx.x & 7] = fs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            double sum = red[0][k];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) sum += red[w][k];
+            t[k] = sum;
+        }
+        fold_and_finish(t, a);
+    }
+    ROUND_STAMP_FOLD(1);
 }
 
 // Early-outs every launch of a query shares: should_stop (DB.cpp:930/987) and the top-up gate.
@@ -169,10 +210,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_round(RoundLaunch a) {
     const u64 wave_id = uniform64(static_cast<u64>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
     const u64 wave_stride = static_cast<u64>(gridDim.x) * kWavesPerBlock;
     Acc acc;
+    ROUND_STAMP(0);
     // (the table is staged through LDS also when it has a single entry: passing it in the kernel arguments, as the
     // persistent sweep does, measured 0.5 us SLOWER here — a cold scalar load per wave against one staged copy)
     const DevFamily* fams = stage_families(a.sw, lds_fams);
+    ROUND_STAMP(1);
+#ifdef AQE_ROUND_STAMPS
+    for (u64 t = wave_id; t < a.ntiles; t += wave_stride) { sweep_tile<kNT>(a.sw, fams, t, lane, ord_limit, acc); if (t == wave_id) ROUND_STAMP(2); }
+#else
     for (u64 t = wave_id; t < a.ntiles; t += wave_stride) sweep_tile<kNT>(a.sw, fams, t, lane, ord_limit, acc);
+#endif
+    ROUND_STAMP(3);
     finish_block(acc, a);
 }
 
@@ -478,6 +526,13 @@ inline unsigned grid_for(u64 work_items, u64 per_block) {
 }
 
 }  // namespace
+
+#ifdef AQE_ROUND_STAMPS
+extern "C" __attribute__((visibility("default"))) int aqe_debug_round_stamps(unsigned long long* out, size_t words) {
+    const size_t all = (kMaxBlocks * kWavesPerBlock + 1) * 8;
+    return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_stamps), 8 * (words < all ? words : all), 0, hipMemcpyDeviceToHost));
+}
+#endif
 
 hipError_t launch_round(const RoundLaunch& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     unsigned grid = grid_for(a.ntiles, kWavesPerBlock);
