@@ -134,6 +134,8 @@ struct SweepForm {
     std::vector<aqe::DevFamily> h_fams;
     aqe::DevFamily* d_fams = nullptr;
     double* d_ppart = nullptr;  // flat workgroup partials: [step_begin[slots] + kDecSteps][8][aqe::kVec]
+    std::vector<uint64_t> h_init;  // what d_ppart's block starts out as, until the form is first launched (plans.hip, materialize_form)
+    size_t ppart_words = 0;
     uint32_t step_begin[aqe::kMaxPersistRounds + 1] = {0};
     uint64_t round_begin[aqe::kMaxPersistRounds + 1] = {0};
     uint32_t round_mod[aqe::kMaxPersistRounds + 1] = {0};

@@ -275,10 +275,20 @@ int build_sweep_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t g
         for (size_t slot = 8 * static_cast<size_t>(F.step_begin[r]) + F.part_count[r]; slot < 8 * static_cast<size_t>(F.step_begin[r + 1]); ++slot)
             init[slot * kVec + 7] = kSlotAlways;
     if (!F.h_fams.empty()) std::memcpy(init.data() + ppart_words, F.h_fams.data(), F.h_fams.size() * sizeof(DevFamily));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), init.size() * sizeof(uint64_t)));
-    HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    F.d_fams = F.h_fams.empty() ? nullptr : reinterpret_cast<DevFamily*>(reinterpret_cast<uint64_t*>(F.d_ppart) + ppart_words);  // (inside d_ppart's block: never freed on its own)
+    // The block reaches the device when the form is first launched (materialize_form): most plans run as lean launches and
+    // never use their monitor-wave forms, and three allocations + copies were half of what creating a CLT plan cost.
+    F.h_init = std::move(init);
+    F.ppart_words = ppart_words;
     F.ok = true;
+    return AQE_OK;
+}
+
+int materialize_form(aqe_ctx* c, SweepForm& F) {
+    if (F.d_ppart || F.h_init.empty()) return AQE_OK;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), F.h_init.size() * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpy(F.d_ppart, F.h_init.data(), F.h_init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    F.d_fams = F.h_fams.empty() ? nullptr : reinterpret_cast<DevFamily*>(reinterpret_cast<uint64_t*>(F.d_ppart) + F.ppart_words);  // (inside d_ppart's block: never freed on its own)
+    std::vector<uint64_t>().swap(F.h_init);
     return AQE_OK;
 }
 
@@ -729,6 +739,10 @@ int launch_form(aqe_plan* p, const SweepForm& F, bool totals_only, double* out_t
     // (The head form is judged once, at the end, by either kernel.)
     const bool lean_pays = lean && lean->ok && (lean->ntiles <= 2ull * lean->grid * kPersistWaves || p->predicted_full || &F == &p->head);
     if (lean_pays && !c->d_stamps && !(p->q.flags & AQE_Q_NO_LEAN)) return launch_lean(p, *lean, totals_only, out_totals, s);
+    {
+        int rc = materialize_form(c, const_cast<SweepForm&>(F));  // (the plan's own form: first use)
+        if (rc != AQE_OK) return rc;
+    }
     PersistLaunch a;
     fill_form(p, F, totals_only, out_totals, c->epoch++, true, a);
     p->poll_epoch = totals_only ? 0 : a.epoch;
@@ -1122,6 +1136,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
         } else {
             rc = build_sweep_form(p, false, F, g, R);
         }
+        if (rc == AQE_OK) rc = materialize_form(c, F);
         if (rc != AQE_OK) return rc;
         fill_form(p, F, kind == 1, kind == 1 ? dev_totals + i * row_stride : nullptr, 0, false, table[i]);
         table[i].stamps = nullptr;  // (the stamp layout is per launch grid: single launches only)
