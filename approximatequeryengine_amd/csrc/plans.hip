@@ -378,14 +378,15 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
 namespace {
 
 // Sweeps below 65 536 samples are launch-bound and gain no bandwidth from a copy of the column: they stay in place — unless
-// the copy is cheap (a shard of at most 16 M rows: 128 MB, built in well under a millisecond) and the sweep is at least a
-// few tiles: a plan over views is a plan of plain runs, and those take the lean launch (10 us instead of 17 for a CLT query).
+// the plan has several rounds, the copy is cheap (a shard of at most 16 M rows: 128 MB, built in well under a millisecond)
+// and the sweep is at least a few tiles: a multi-round plan over views is a plan of plain runs, and those take the lean
+// launch (10 us instead of 17 for a CLT query).
 constexpr uint64_t kViewMinSamples = 1u << 16, kViewMinSamplesSmallTable = 1u << 12, kViewSmallTableRows = 1u << 24;
 constexpr uint64_t kViewMaxStep = 1024;
 
 // Rewrites a list of single-segment strided families of one common step into dense families over that step's
 // stride-major view (a PAIR family becomes two: its pointers have different residues, i.e. two streams).
-int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, const double** view, uint64_t* view_step) {
+int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, const double** view, uint64_t* view_step, bool multi_round) {
     uint64_t step = 0, total = 0;
     for (auto* L : lists)
         for (const aqe_family& f : *L) {
@@ -393,7 +394,7 @@ int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, co
             step = f.step;
             total += family_size(f);
         }
-    if (!step || total < (c->n_local <= kViewSmallTableRows ? kViewMinSamplesSmallTable : kViewMinSamples)) return AQE_OK;
+    if (!step || total < (multi_round && c->n_local <= kViewSmallTableRows ? kViewMinSamplesSmallTable : kViewMinSamples)) return AQE_OK;
     uint64_t M = 0, q0 = 0;
     int rc = ensure_stride_view(c, step, view, &M, &q0);
     if (rc != AQE_OK) return rc;
@@ -453,8 +454,9 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         // stride-major views of the column: dense streams
         std::vector<std::vector<aqe_family>*> rounds;
         for (auto& rf : p->host.round_fams) rounds.push_back(&rf);
-        rc = families_to_view(c, rounds, &p->view_rounds, &p->view_step_rounds);
-        if (rc == AQE_OK && p->host.has_topup) rc = families_to_view(c, {&p->host.topup_fams}, &p->view_topup, &p->view_step_topup);
+        const bool multi_round = p->host.round_fams.size() >= 2;
+        rc = families_to_view(c, rounds, &p->view_rounds, &p->view_step_rounds, multi_round);
+        if (rc == AQE_OK && p->host.has_topup) rc = families_to_view(c, {&p->host.topup_fams}, &p->view_topup, &p->view_step_topup, multi_round);
         if (rc != AQE_OK) return rc;
     }
     uint64_t out_pos = 0;
