@@ -145,10 +145,10 @@ struct SweepForm {
     uint32_t more_rounds = 0; // the form ends before the plan's last round (the head form)
     uint32_t topup_slot = 0;  // the last slot is the plan's top-up
     // the lean variant of the form (lean.hip, k_sweep_lean), when the plan qualifies: its own tile list (runs), its own
-    // unpadded slot list; d_ppart then holds [slots][kVec] partials followed by the run table
+    // unpadded slot list; d_ppart then holds [slots][kVec] partials
     bool lean = false;
     uint32_t tiles_per_wg = 0;  // workgroup b owns the tiles [b tiles_per_wg, (b + 1) tiles_per_wg)
-    aqe::LeanRuns* d_runs = nullptr;
+    aqe::LeanRuns h_runs{};     // the run table, copied into every launch descriptor
     uint32_t slot_begin[aqe::kMaxPersistRounds + 1] = {0};
 };
 

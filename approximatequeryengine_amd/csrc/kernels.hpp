@@ -206,7 +206,7 @@ hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long lo
 // belong to the sample — what every strided pointer read through a view comes to.
 constexpr int kLeanMaxRuns = 128;                                       // two runs per lane of a wave: lane i holds runs i and i + 64
 constexpr int kLeanMaxSlots = kMaxPersistGrid + kMaxPersistRounds;      // a round boundary splits at most one workgroup
-struct LeanRuns {  // in device memory, structure of arrays: lane i of every wave holds run i in registers
+struct LeanRuns {  // part of the launch descriptor, structure of arrays: lane i of every wave holds runs i and i + 64 in registers
     uint64_t row0[kLeanMaxRuns];        // first row, relative to LeanLaunch::amount
     uint32_t tile_begin[kLeanMaxRuns];  // first tile of the run in the launch's tile list; 0xffffffff past the table
     uint32_t rows[kLeanMaxRuns];
@@ -215,7 +215,6 @@ struct LeanRuns {  // in device memory, structure of arrays: lane i of every wav
 };
 struct LeanLaunch {
     const double* amount;
-    const LeanRuns* runs;
     uint32_t ntiles, rounds;
     int32_t has_where;
     uint32_t tiles_per_wg;     // workgroup b owns the tiles [b tiles_per_wg, (b + 1) tiles_per_wg)
@@ -231,7 +230,11 @@ struct LeanLaunch {
     unsigned long long* result_seq;
     unsigned long long epoch;
     uint32_t finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only;  // as in PersistLaunch
+    // The run table travels IN the descriptor — the kernel arguments of a single launch, the batch's table otherwise — so a
+    // wave's very first loads (its lane's two runs) depend on nothing but the descriptor's address.
+    LeanRuns runs;
 };
+static_assert(sizeof(LeanLaunch) <= 4096, "kernel arguments are limited to 4 KB");
 hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, bool nt, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // a batch of queries in one launch: table[q] describes query q (its epoch field is ignored), wg_map as for launch_sweep_multi
 hipError_t launch_sweep_lean_multi(const LeanLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, bool nt,

@@ -212,7 +212,7 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
 // the sweep needs, in registers; K: the descriptor the folding workgroup reads the rest from (the kernel arguments of
 // a single launch, the batch's table in device memory otherwise).
 template <bool kNT>
-__device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K, const unsigned bid, const unsigned G, const unsigned long long epoch) {
+__device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* const runs, const LeanKarg K, const unsigned bid, const unsigned G, const unsigned long long epoch) {
     __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];  // a wave's sums of a round (zero where it swept none)
     __shared__ double lds_round[kMaxPersistRounds][kVec];
     __shared__ unsigned lds_slot[kMaxPersistRounds];
@@ -222,9 +222,9 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K
     const unsigned wave = threadIdx.x >> 6;
     LEAN_STAMP(0);
     // the run table: lane i holds runs i and i + 64.  One batch of loads, in flight while LDS is cleared.
-    const u64 my_row0 = a.runs->row0[lane], my_row0_hi = a.runs->row0[lane + 64];
-    const unsigned my_tb = a.runs->tile_begin[lane], my_rows = a.runs->rows[lane], my_meta = a.runs->meta[lane], my_slot = a.runs->slot[lane];
-    const unsigned my_tb_hi = a.runs->tile_begin[lane + 64], my_rows_hi = a.runs->rows[lane + 64], my_meta_hi = a.runs->meta[lane + 64], my_slot_hi = a.runs->slot[lane + 64];
+    const u64 my_row0 = runs->row0[lane], my_row0_hi = runs->row0[lane + 64];
+    const unsigned my_tb = runs->tile_begin[lane], my_rows = runs->rows[lane], my_meta = runs->meta[lane], my_slot = runs->slot[lane];
+    const unsigned my_tb_hi = runs->tile_begin[lane + 64], my_rows_hi = runs->rows[lane + 64], my_meta_hi = runs->meta[lane + 64], my_slot_hi = runs->slot[lane + 64];
     // every wave clears its own rows of lds_part: nothing to wait for before the sweep
 #pragma unroll
     for (unsigned i = 0; i < kMaxPersistRounds * kVec / 64; ++i) {
@@ -369,7 +369,9 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanKarg K
 
 template <bool kNT>
 __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
-    lean_query<kNT>(a, (LeanKarg)__builtin_amdgcn_kernarg_segment_ptr(), blockIdx.x, gridDim.x, a.epoch);
+    const LeanKarg K = (LeanKarg)__builtin_amdgcn_kernarg_segment_ptr();
+    // (the run table is read out of the kernel-argument segment itself, per lane: ordinary global memory)
+    lean_query<kNT>(a, &((const LeanLaunch*)K)->runs, K, blockIdx.x, gridDim.x, a.epoch);
 }
 
 // A BATCH of queries in one launch (as k_sweep_multi, persist.hip): the grid is cut into one group of workgroups per
@@ -381,10 +383,10 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean_multi(const Lean
     const u64 me = uniform64(wg_map[blockIdx.x]);
     const LeanKarg K = (LeanKarg)(table + (me >> 32));
     LeanLaunch a;  // what the sweep reads, out of the table once
-    a.amount = K->amount; a.runs = K->runs; a.ntiles = K->ntiles; a.tiles_per_wg = K->tiles_per_wg;
+    a.amount = K->amount; a.ntiles = K->ntiles; a.tiles_per_wg = K->tiles_per_wg;
     a.has_where = K->has_where; a.wmin = K->wmin; a.wmax = K->wmax; a.shift = K->shift;
     a.partials = K->partials; a.counter = K->counter; a.want_ticks = 0;
-    lean_query<kNT>(a, K, static_cast<unsigned>(me) & 0xffffu, static_cast<unsigned>(me >> 16) & 0xffffu, epoch);
+    lean_query<kNT>(a, &(table + (me >> 32))->runs, K, static_cast<unsigned>(me) & 0xffffu, static_cast<unsigned>(me >> 16) & 0xffffu, epoch);
 }
 
 }  // namespace

@@ -354,13 +354,10 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
         const uint32_t r = runs.meta[i] & 0xffu;
         runs.slot[i] = F.slot_begin[r] | (part_first[r] << 16);
     }
-    // ONE allocation and ONE copy: [partials, zero][run table]
-    const size_t ppart_words = static_cast<size_t>(kVec) * F.slot_begin[S];
-    std::vector<uint64_t> init(ppart_words + (sizeof(LeanRuns) + 7) / 8, 0);
-    std::memcpy(init.data() + ppart_words, &runs, sizeof(LeanRuns));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), init.size() * sizeof(uint64_t)));
-    HIPCHK(c, hipMemcpy(F.d_ppart, init.data(), init.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    F.d_runs = reinterpret_cast<LeanRuns*>(reinterpret_cast<uint64_t*>(F.d_ppart) + ppart_words);
+    // the partial list: every slot is written by its workgroup in every launch, nothing to initialise (the run table
+    // travels in the launch descriptor)
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), sizeof(double) * kVec * F.slot_begin[S]));
+    F.h_runs = runs;
     F.lean = true;
     F.tiles_per_wg = static_cast<uint32_t>(K);
     F.slots = static_cast<uint32_t>(S);
@@ -690,7 +687,7 @@ void fill_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_to
     a = LeanLaunch{};
     const SweepCommon sw = sweep_common(p, nullptr, 0);
     a.amount = sw.amount;
-    a.runs = L.d_runs;
+    a.runs = L.h_runs;
     a.ntiles = static_cast<uint32_t>(L.ntiles);
     a.tiles_per_wg = L.tiles_per_wg;
     a.rounds = L.slots;
