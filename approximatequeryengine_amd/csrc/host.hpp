@@ -149,6 +149,9 @@ struct SweepForm {
     bool lean = false;
     uint32_t tiles_per_wg = 0;  // workgroup b owns the tiles [b tiles_per_wg, (b + 1) tiles_per_wg)
     aqe::LeanRuns h_runs{};     // the run table, copied into every launch descriptor
+    bool wide = false;          // more runs than that: the table in device memory (behind the partials), aqe::LeanWideRuns
+    aqe::LeanWideRuns* d_wide = nullptr;
+    uint32_t nruns = 0;
     uint32_t slot_begin[aqe::kMaxPersistRounds + 1] = {0};
 };
 

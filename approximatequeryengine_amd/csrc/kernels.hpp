@@ -213,6 +213,13 @@ struct LeanRuns {  // part of the launch descriptor, structure of arrays: lane i
     uint32_t meta[kLeanMaxRuns];        // round | group << 8
     uint32_t slot[kLeanMaxRuns];        // of the run's round: its first slot | the first workgroup that sweeps tiles of it << 16
 };
+// Plans of more runs than the lanes hold (many pointers: T >= 64 on 10 M rows) bring their table in device memory; every
+// workgroup copies it to LDS and finds a tile's run by bisection (k_sweep_lean<.., wide>).
+constexpr int kLeanWideRuns = 512;
+struct LeanWideRuns {
+    uint64_t row0[kLeanWideRuns];
+    uint32_t tile_begin[kLeanWideRuns], rows[kLeanWideRuns], meta[kLeanWideRuns], slot[kLeanWideRuns];
+};
 struct LeanLaunch {
     const double* amount;
     uint32_t ntiles, rounds;
@@ -230,6 +237,8 @@ struct LeanLaunch {
     unsigned long long* result_seq;
     unsigned long long epoch;
     uint32_t finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only;  // as in PersistLaunch
+    const LeanWideRuns* wide;  // null: the run table below; else the plan's table of `nruns` > kLeanMaxRuns runs
+    uint32_t nruns, pad1;
     // The run table travels IN the descriptor — the kernel arguments of a single launch, the batch's table otherwise — so a
     // wave's very first loads (its lane's two runs) depend on nothing but the descriptor's address.
     LeanRuns runs;

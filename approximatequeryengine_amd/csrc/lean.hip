@@ -211,7 +211,7 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
 // One query on the workgroups bid = 0 .. G-1 (a launch of its own, or one group of a batch's launch).  `a`: the fields
 // the sweep needs, in registers; K: the descriptor the folding workgroup reads the rest from (the kernel arguments of
 // a single launch, the batch's table in device memory otherwise).
-template <bool kNT>
+template <bool kNT, bool kWide>
 __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* const runs, const LeanKarg K, const unsigned bid, const unsigned G, const unsigned long long epoch) {
     __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];  // a wave's sums of a round (zero where it swept none)
     __shared__ double lds_round[kMaxPersistRounds][kVec];
@@ -222,9 +222,22 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     const unsigned wave = threadIdx.x >> 6;
     LEAN_STAMP(0);
     // the run table: lane i holds runs i and i + 64.  One batch of loads, in flight while LDS is cleared.
-    const u64 my_row0 = runs->row0[lane], my_row0_hi = runs->row0[lane + 64];
-    const unsigned my_tb = runs->tile_begin[lane], my_rows = runs->rows[lane], my_meta = runs->meta[lane], my_slot = runs->slot[lane];
-    const unsigned my_tb_hi = runs->tile_begin[lane + 64], my_rows_hi = runs->rows[lane + 64], my_meta_hi = runs->meta[lane + 64], my_slot_hi = runs->slot[lane + 64];
+    // (wide plans: the table goes to LDS instead, one copy per workgroup, and a tile's run is found by bisection)
+    __shared__ u64 lds_row0[kWide ? kLeanWideRuns : 1];
+    __shared__ unsigned lds_tb[kWide ? kLeanWideRuns : 1], lds_rows[kWide ? kLeanWideRuns : 1], lds_meta[kWide ? kLeanWideRuns : 1], lds_rslot[kWide ? kLeanWideRuns : 1];
+    u64 my_row0 = 0, my_row0_hi = 0;
+    unsigned my_tb = 0, my_rows = 0, my_meta = 0, my_slot = 0, my_tb_hi = 0, my_rows_hi = 0, my_meta_hi = 0, my_slot_hi = 0;
+    if (kWide) {
+        for (unsigned i = threadIdx.x; i < a.nruns; i += kPersistThreads) {
+            lds_row0[i] = a.wide->row0[i]; lds_tb[i] = a.wide->tile_begin[i]; lds_rows[i] = a.wide->rows[i];
+            lds_meta[i] = a.wide->meta[i]; lds_rslot[i] = a.wide->slot[i];
+        }
+        __syncthreads();
+    } else {
+        my_row0 = runs->row0[lane]; my_row0_hi = runs->row0[lane + 64];
+        my_tb = runs->tile_begin[lane]; my_rows = runs->rows[lane]; my_meta = runs->meta[lane]; my_slot = runs->slot[lane];
+        my_tb_hi = runs->tile_begin[lane + 64]; my_rows_hi = runs->rows[lane + 64]; my_meta_hi = runs->meta[lane + 64]; my_slot_hi = runs->slot[lane + 64];
+    }
     // every wave clears its own rows of lds_part: nothing to wait for before the sweep
 #pragma unroll
     for (unsigned i = 0; i < kMaxPersistRounds * kVec / 64; ++i) {
@@ -250,19 +263,36 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     };
     for (unsigned t = __builtin_amdgcn_readfirstlane(t_lo + wave); t < t_end; t += kPersistWaves) {
         // the run that owns tile t: the last whose first tile is <= t (ascending; 0xffffffff past the table)
-        const unsigned below = static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb <= t))) + static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb_hi <= t)));
-        const bool hi = below > 64u;           // wave-uniform: the run sits in the lanes' second set
-        const unsigned i = (below - 1u) & 63u;
-        const unsigned meta = hi ? __builtin_amdgcn_readlane(my_meta_hi, i) : __builtin_amdgcn_readlane(my_meta, i);
+        unsigned meta, run_slot, run_tb, run_rows;
+        u64 run_row0;
+        if (kWide) {
+            unsigned lo = 0, hi = a.nruns;
+            while (hi - lo > 1u) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(lds_tb[mid])) <= t) lo = mid; else hi = mid;
+            }
+            meta = __builtin_amdgcn_readfirstlane(lds_meta[lo]); run_slot = __builtin_amdgcn_readfirstlane(lds_rslot[lo]);
+            run_tb = __builtin_amdgcn_readfirstlane(lds_tb[lo]); run_rows = __builtin_amdgcn_readfirstlane(lds_rows[lo]);
+            run_row0 = uniform64(lds_row0[lo]);
+        } else {
+            const unsigned below = static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb <= t))) + static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb_hi <= t)));
+            const bool hi = below > 64u;           // wave-uniform: the run sits in the lanes' second set
+            const unsigned i = (below - 1u) & 63u;
+            meta = hi ? __builtin_amdgcn_readlane(my_meta_hi, i) : __builtin_amdgcn_readlane(my_meta, i);
+            run_slot = hi ? __builtin_amdgcn_readlane(my_slot_hi, i) : __builtin_amdgcn_readlane(my_slot, i);
+            run_tb = hi ? __builtin_amdgcn_readlane(my_tb_hi, i) : __builtin_amdgcn_readlane(my_tb, i);
+            run_rows = hi ? __builtin_amdgcn_readlane(my_rows_hi, i) : __builtin_amdgcn_readlane(my_rows, i);
+            run_row0 = hi ? read_lane_u64(my_row0_hi, i) : read_lane_u64(my_row0, i);
+        }
         const unsigned r = meta & 0xffu;
         if (r != cur) {
             if (cur != ~0u) { flush(); acc = Acc{}; }
             cur = r;
-            cur_slot = hi ? __builtin_amdgcn_readlane(my_slot_hi, i) : __builtin_amdgcn_readlane(my_slot, i);
+            cur_slot = run_slot;
         }
-        const unsigned first = (t - (hi ? __builtin_amdgcn_readlane(my_tb_hi, i) : __builtin_amdgcn_readlane(my_tb, i))) * static_cast<unsigned>(kDenseTileOrdinals);
-        const unsigned rem = (hi ? __builtin_amdgcn_readlane(my_rows_hi, i) : __builtin_amdgcn_readlane(my_rows, i)) - first;
-        const double* const base = a.amount + ((hi ? read_lane_u64(my_row0_hi, i) : read_lane_u64(my_row0, i)) + first);
+        const unsigned first = (t - run_tb) * static_cast<unsigned>(kDenseTileOrdinals);
+        const unsigned rem = run_rows - first;
+        const double* const base = a.amount + (run_row0 + first);
         TileAcc ta;
         lean_tile<kNT>(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
         merge_tile(acc, ta, ((meta >> 8) & 1u) != 0);
@@ -367,11 +397,11 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     lean_judge(K, tot, static_cast<unsigned>(lane), t0, epoch);
 }
 
-template <bool kNT>
+template <bool kNT, bool kWide>
 __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean(LeanLaunch a) {
     const LeanKarg K = (LeanKarg)__builtin_amdgcn_kernarg_segment_ptr();
     // (the run table is read out of the kernel-argument segment itself, per lane: ordinary global memory)
-    lean_query<kNT>(a, &((const LeanLaunch*)K)->runs, K, blockIdx.x, gridDim.x, a.epoch);
+    lean_query<kNT, kWide>(a, &((const LeanLaunch*)K)->runs, K, blockIdx.x, gridDim.x, a.epoch);
 }
 
 // A BATCH of queries in one launch (as k_sweep_multi, persist.hip): the grid is cut into one group of workgroups per
@@ -385,8 +415,8 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean_multi(const Lean
     LeanLaunch a;  // what the sweep reads, out of the table once
     a.amount = K->amount; a.ntiles = K->ntiles; a.tiles_per_wg = K->tiles_per_wg;
     a.has_where = K->has_where; a.wmin = K->wmin; a.wmax = K->wmax; a.shift = K->shift;
-    a.partials = K->partials; a.counter = K->counter; a.want_ticks = 0;
-    lean_query<kNT>(a, &(table + (me >> 32))->runs, K, static_cast<unsigned>(me) & 0xffffu, static_cast<unsigned>(me >> 16) & 0xffffu, epoch);
+    a.partials = K->partials; a.counter = K->counter; a.want_ticks = 0; a.wide = nullptr; a.nruns = 0;
+    lean_query<kNT, false>(a, &(table + (me >> 32))->runs, K, static_cast<unsigned>(me) & 0xffffu, static_cast<unsigned>(me >> 16) & 0xffffu, epoch);
 }
 
 }  // namespace
@@ -404,13 +434,12 @@ hipError_t launch_sweep_lean_multi(const LeanLaunch* table, const unsigned long 
 }
 
 hipError_t launch_sweep_lean(const LeanLaunch& a, unsigned grid, bool nt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (nt) {
-        if (ev0) hipExtLaunchKernelGGL(k_sweep_lean<true>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
-        else hipLaunchKernelGGL(k_sweep_lean<true>, dim3(grid), dim3(kPersistThreads), 0, s, a);
-    } else {
-        if (ev0) hipExtLaunchKernelGGL(k_sweep_lean<false>, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
-        else hipLaunchKernelGGL(k_sweep_lean<false>, dim3(grid), dim3(kPersistThreads), 0, s, a);
-    }
+    auto go = [&](auto kernel) {
+        if (ev0) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kPersistThreads), 0, s, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kPersistThreads), 0, s, a);
+    };
+    if (a.wide) { if (nt) go(k_sweep_lean<true, true>); else go(k_sweep_lean<false, true>); }
+    else { if (nt) go(k_sweep_lean<true, false>); else go(k_sweep_lean<false, false>); }
     return hipGetLastError();
 }
 

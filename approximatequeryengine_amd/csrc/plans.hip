@@ -310,9 +310,10 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
     if (S == 0 || S > static_cast<size_t>(kMaxPersistRounds)) return AQE_OK;
     const SweepCommon sw_r = sweep_common(p, nullptr, 0, false), sw_t = sweep_common(p, nullptr, 0, true);
     const int64_t base_gap = static_cast<int64_t>(reinterpret_cast<uintptr_t>(sw_t.amount) - reinterpret_cast<uintptr_t>(sw_r.amount)) / 8;  // rows (build_sweep_form)
-    LeanRuns runs{};
-    for (int i = 0; i < kLeanMaxRuns; ++i) runs.tile_begin[i] = 0xffffffffu;
-    uint32_t nruns = 0;
+    // up to kLeanMaxRuns runs travel in the launch descriptor (two per lane of a wave); up to kLeanWideRuns in a table of
+    // their own in device memory (copied to LDS by every workgroup, searched by bisection)
+    struct Run { uint64_t row0; uint32_t tile_begin, rows, meta; };
+    std::vector<Run> runs;
     uint64_t tiles = 0, samples = 0;
     uint64_t round_begin[kMaxPersistRounds + 1] = {0};
     for (size_t r = 0; r < S; ++r) {
@@ -325,17 +326,13 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
             // a plain run: one pointer, step 1, its window inside one segment
             if (!is_dense16(d.step, d.flags, d.seg_len) || (d.flags & kFamLinear) || d.ord_hi <= d.ord_lo) return AQE_OK;
             const uint64_t seg = d.ord_lo / d.seg_len, len = d.ord_hi - d.ord_lo;
-            if ((d.ord_hi - 1) / d.seg_len != seg || nruns == static_cast<uint32_t>(kLeanMaxRuns) || len >= 0xffffffffull) return AQE_OK;
+            if ((d.ord_hi - 1) / d.seg_len != seg || runs.size() == static_cast<size_t>(kLeanWideRuns) || len >= 0xffffffffull) return AQE_OK;
             // row of ordinal o: row0 + seg pitch - shard_lo + (o - seg seg_len)   (device_common.hpp, sweep_family; wraps like it)
             uint64_t row = d.row0 + seg * d.pitch - sw.shard_lo + d.ord_lo - seg * d.seg_len;
             if (is_topup) row += static_cast<uint64_t>(base_gap);  // one launch has one column base: the rounds'
-            runs.row0[nruns] = row;
-            runs.tile_begin[nruns] = static_cast<uint32_t>(tiles);
-            runs.rows[nruns] = static_cast<uint32_t>(len);
-            runs.meta[nruns] = static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8);
+            runs.push_back(Run{row, static_cast<uint32_t>(tiles), static_cast<uint32_t>(len), static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8)});
             tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
             samples += len;
-            ++nruns;
         }
         if (tiles == round_begin[r]) return AQE_OK;  // a slot without tiles: the other forms deal with it
     }
@@ -350,14 +347,31 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
         F.slot_begin[r + 1] = F.slot_begin[r] + static_cast<uint32_t>(last - first + 1);
     }
     if (F.slot_begin[S] > static_cast<uint32_t>(kLeanMaxSlots)) return AQE_OK;
-    for (uint32_t i = 0; i < nruns; ++i) {
-        const uint32_t r = runs.meta[i] & 0xffu;
-        runs.slot[i] = F.slot_begin[r] | (part_first[r] << 16);
+    const size_t nruns = runs.size();
+    F.wide = nruns > static_cast<size_t>(kLeanMaxRuns);
+    const size_t ppart_bytes = sizeof(double) * kVec * F.slot_begin[S];
+    // the partial list: every slot is written by its workgroup in every launch, nothing to initialise.  (The run table
+    // travels in the launch descriptor; a wide plan's sits behind the partials, in the same block.)
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), ppart_bytes + (F.wide ? sizeof(LeanWideRuns) : 0)));
+    F.h_runs = LeanRuns{};
+    for (int i = 0; i < kLeanMaxRuns; ++i) F.h_runs.tile_begin[i] = 0xffffffffu;
+    F.nruns = static_cast<uint32_t>(nruns);
+    if (F.wide) {
+        auto w = std::make_unique<LeanWideRuns>();
+        for (size_t i = 0; i < nruns; ++i) {
+            const uint32_t r = runs[i].meta & 0xffu;
+            w->row0[i] = runs[i].row0; w->tile_begin[i] = runs[i].tile_begin; w->rows[i] = runs[i].rows; w->meta[i] = runs[i].meta;
+            w->slot[i] = F.slot_begin[r] | (part_first[r] << 16);
+        }
+        F.d_wide = reinterpret_cast<LeanWideRuns*>(reinterpret_cast<char*>(F.d_ppart) + ppart_bytes);
+        HIPCHK(c, hipMemcpy(F.d_wide, w.get(), sizeof(LeanWideRuns), hipMemcpyHostToDevice));
+    } else {
+        for (size_t i = 0; i < nruns; ++i) {
+            const uint32_t r = runs[i].meta & 0xffu;
+            F.h_runs.row0[i] = runs[i].row0; F.h_runs.tile_begin[i] = runs[i].tile_begin; F.h_runs.rows[i] = runs[i].rows; F.h_runs.meta[i] = runs[i].meta;
+            F.h_runs.slot[i] = F.slot_begin[r] | (part_first[r] << 16);
+        }
     }
-    // the partial list: every slot is written by its workgroup in every launch, nothing to initialise (the run table
-    // travels in the launch descriptor)
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&F.d_ppart), sizeof(double) * kVec * F.slot_begin[S]));
-    F.h_runs = runs;
     F.lean = true;
     F.tiles_per_wg = static_cast<uint32_t>(K);
     F.slots = static_cast<uint32_t>(S);
@@ -688,6 +702,8 @@ void fill_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_to
     const SweepCommon sw = sweep_common(p, nullptr, 0);
     a.amount = sw.amount;
     a.runs = L.h_runs;
+    a.wide = L.wide ? L.d_wide : nullptr;
+    a.nruns = L.nruns;
     a.ntiles = static_cast<uint32_t>(L.ntiles);
     a.tiles_per_wg = L.tiles_per_wg;
     a.rounds = L.slots;
@@ -1101,7 +1117,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
             if (p->q.flags & AQE_Q_NO_LEAN) { all = false; break; }
             int rc = build_lean_form(p, head[i] != 0, lf[i], gs[i], head[i] ? p->r_head : p->rounds.size());
             if (rc != AQE_OK) { for (SweepForm& f : lf) if (f.d_ppart) (void)hipFree(f.d_ppart); return rc; }
-            all = lf[i].ok;
+            all = lf[i].ok && !lf[i].wide;  // (the groups of a batch read their run table out of the batch's descriptor table)
         }
         if (all) {
             m.lean = true;

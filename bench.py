@@ -318,6 +318,9 @@ def run_configs(eng, nat, make_query, st, max_rows, Batch=None):
     q_inplace.flags |= nat.Q_NO_LAYOUT
     out.append(measure_config(eng, st, f"{tag} CLT AVG e=0.01% swept IN PLACE (what a plan gets when all 8 stride-major views of a table are held)",
                               q_inplace, note="rows 0 and 2 of every 5: 40 % of every line touched; the view form of the same query is the headline"))
+    out.append(measure_config(eng, st, f"{tag} CLT AVG e=0.01% with T=256 pointers (one pointer per compute unit: the tuned variant of config 2)",
+                              make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.01, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH, num_threads=256),
+                              note="512 runs: the wide form of the lean launch (run table in LDS, a tile's run found by bisection)"))
     if Batch is not None:  # configs[0] as a service: 32 different 1 % queries per launch
         qs = [make_query(nat.M_MEMORY_STRIDE, 1.0, agg=(nat.SUM, nat.AVG, nat.COUNT)[i % 3], rows=(100_000 * i, n - 50_000 * i)) for i in range(16)]  # key-range windows
         qs += [make_query(nat.M_BLOCK, 1.0, block_size=500 + 100 * i, where=(100.0 + i, 900.0 - i), convention=nat.EST_CPP) for i in range(16)]

@@ -740,6 +740,13 @@ def test_single_launch_kernel_choice(nat, engines):
     assert (k_wide, k_wide_mon) == (nat.KERNEL_SWEEP_LEAN, nat.KERNEL_SWEEP_PERSIST)
     assert (r_wide.n, r_wide.visited, r_wide.converged, r_wide.rounds) == (r_wide_mon.n, r_wide_mon.visited, r_wide_mon.converged, r_wide_mon.rounds)
     assert rel(r_wide.sum, r_wide_mon.sum) <= 1e-14 and rel(r_wide.sumsq, r_wide_mon.sumsq) <= 1e-14 and rel(r_wide.ci_lower, r_wide_mon.ci_lower) <= 1e-13
+    # 64 and 256 pointers: 192 and 512 runs — the wide form of the lean launch (run table in LDS, found by bisection)
+    for T in (64, 256):
+        k_w, r_w = kernel_of(0, num_threads=T)
+        k_m, r_m = kernel_of(nat.Q_NO_LEAN, num_threads=T)
+        assert (k_w, k_m) == (nat.KERNEL_SWEEP_LEAN, nat.KERNEL_SWEEP_PERSIST), T
+        assert (r_w.n, r_w.visited, r_w.converged, r_w.rounds) == (r_m.n, r_m.visited, r_m.converged, r_m.rounds)
+        assert rel(r_w.sum, r_m.sum) <= 1e-14 and rel(r_w.sumsq, r_m.sumsq) <= 1e-14 and rel(r_w.ci_lower, r_m.ci_lower) <= 1e-13
     # a batch of early-stopping queries: lean groups, each its plan's head form with the top-up as a slot
     from approximatequeryengine_amd.engine import Batch
     qs = [make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=(nat.AVG, nat.SUM)[i % 2], max_error_percent=1.0 + 0.01 * i, clt_round0=4096, clt_growth=4,
