@@ -24,7 +24,10 @@
 //     a wave costs ~8 ns of wall time while all waves do the same thing, which they do at the start and at the end of a
 //     short query: k_sweep_persist's general tile path (~500 vector instructions of window arithmetic per tile) had the
 //     first tile of a 10 M-row query folded after 3.3 us and the last after 8.3, where a lean loop needs 0.4 and 3.7
-//     (tools/exp_latency.hip) — 17.7 us per launch against 10.
+//     (tools/exp_latency.hip) — 17.7 us per launch against 9.5.
+//
+// Plans of more runs than the lanes hold (up to 512: 64 ... 256 pointers on 10 M rows) take the WIDE instantiation: the
+// table goes through LDS, one copy per workgroup, and a tile's run is found by bisection.
 //
 // Same forms as the persistent sweep (PersistLaunch): decisions in the kernel, the head form (rounds + the top-up as
 // one more slot, `more_rounds`), totals only (multi-GPU: every slot's total for the all-reduce).  Nothing in it waits
