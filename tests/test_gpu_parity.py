@@ -213,6 +213,7 @@ CLT_CASES = [
     (100_007, 20.0, 0.95, 10, 64, 1.0, 8, 2),      # 64 pointers
     (1_000_000, 20.0, 0.95, 10, 4, 2.0, 10, 1),    # the reference's cadence and defaults: 5000 rounds planned, stops early
     (200_000, 20.0, 0.95, 10, 4, 0.0, 10, 1),      # ... and never converging: 1000 rounds, launched chunk by chunk
+    (1_000_000, 20.0, 0.95, 10, 128, 0.0, 1024, 4),  # 128 pointers: 256 runs, the wide form of the lean launch
     (10_000_000, 20.0, 0.95, 10, 4, 0.01, 4096, 4),  # the bench query at its own size: 4 M samples, never converges
     (10_000_000, 20.0, 0.95, 10, 4, 1.0, 4096, 4),   # ... and its other reading: stops after round 0, 500 000-row top-up
 ]
