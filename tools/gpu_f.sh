@@ -7,8 +7,8 @@ rm -rf $O; mkdir -p $O
 echo "--- kernel trace + stats: bench headline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o b -- python3 bench.py --headline-only --steps 200 --warmup 20 > $O/bench_line.txt 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
 head -6 $O/bench/b_kernel_stats.csv | cut -c1-220
-echo "--- kernel trace + stats: 100 M and 1 B rows"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/configs -o c -- python3 tools/bench_configs.py 100000000,1000000000 > $O/configs_lines.txt 2> $O/configs.err || { tail -5 $O/configs.err; exit 1; }
+echo "--- kernel trace + stats: 10 M, 100 M and 1 B rows"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/configs -o c -- python3 tools/bench_configs.py 10000000,100000000,1000000000 > $O/configs_lines.txt 2> $O/configs.err || { tail -5 $O/configs.err; exit 1; }
 head -8 $O/configs/c_kernel_stats.csv | cut -c1-220
 echo "--- kernel trace + stats: grouped reductions"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/group -o g -- python3 tools/group_time.py > $O/group_lines.txt 2> $O/group.err || { tail -5 $O/group.err; exit 1; }
