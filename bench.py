@@ -9,23 +9,22 @@ Workload (BASELINE.json configs[1]): 10 M-row synthetic `sales` table per GPU (f
 `SELECT AVG(amount) ... --e 0.01` through the CLT dual-pointer monitor exactly as the reference CLI
 issues it (enhanced_aqe_cli.py:243-255): pct = 20 (e <= 1), confidence 0.95, check_interval 10,
 e = 0.01 PERCENT — which cannot converge on 10 M rows, so every query performs the full fast+slow sweep
-(4 M samples per GPU) with the should_stop test armed.  One step = one BATCH of B such queries (value +
-95 % interval each) with the table resident in HBM, executed as ONE launch (k_sweep_multi: a group of
-workgroups, a monitor wave and a should_stop word per query).  The queries of a batch are not copies of one
-another: pointer counts (T = 4, 6, ... 16), aggregates (AVG / SUM / COUNT) and thresholds differ, every
-query does all of its own loads, and EVERY result is fetched inside the timed loop (two batches alternate:
-while one sweeps, the previous one's results are read).
+(4 M samples per GPU) with the should_stop test armed.  The table is resident in HBM.
 
-N GPUs: weak scaling.  Each rank holds its own 10 M-row region of an N x 10 M-row table; a query runs
-T x N pointers over the global table, each rank sweeps what falls in its region (the same one launch,
-decisions left out), ONE RCCL all-reduce of the per-round moment vectors serves the whole batch, and one
-launch replays the stop rules.  `value` counts one 10 M-row region aggregate per GPU per query (so a
-global query over N regions counts N); the global query rate is reported beside it.
+One STEP = `--launches-per-step` (100) launches; one launch = one BATCH of `--batch` (32) different queries
+(pointer counts T = 4, 6, ... 16, aggregates AVG / SUM / COUNT, thresholds a hair apart), every query doing all of
+its own loads and producing value + 95 % interval; two batches alternate so that EVERY result is fetched inside
+the timed loop.  value = queries completed per second.
 
-Besides the headline the line carries `configs` (every other BASELINE.json configuration that fits one GPU,
-each with its own launch time, algorithmic bytes and roofline fraction), `cold` (staging from a file in the
-page cache + building the stride-major views) and `cpu_baseline` (the reference's own C++ on this box's
-host cores).  `--headline-only` skips those.
+N GPUs (weak scaling: per-GPU rows fixed): each rank holds its own 10 M-row region of an N x 10 M-row table; a query
+runs T x N pointers over the global table, each rank sweeps what falls in its region (the same one launch, decisions
+left out), ONE RCCL all-reduce of the per-round moment vectors serves the whole batch, and one launch replays the stop
+rules.  `value` is GLOBAL queries per second (a query over N regions counts once).
+
+Output: the LAST stdout line is one compact JSON object (< 3 KB: metric, value, roofline, roofline_hbm,
+cpu_baseline); everything else — per-configuration lines, cold staging, open loop, every CPU leg — goes to
+bench_report.json (repo root, and gpurun_out/ when present) and, one object per line, to stderr.
+`--headline-only` skips those.
 """
 from __future__ import annotations
 
@@ -45,14 +44,17 @@ ROWS_PER_GPU = 10_000_000
 SEED = 42
 CLT_ROUND0 = 4096   # samples per pointer in round 0 ...
 CLT_GROWTH = 4      # ... times 4 every round: 5 rounds cover the 1 M-sample progressions
-PMC_FILE = ROOT / "profiles" / "round2_pmc_raw.json"
+PMC_FILE = ROOT / "profiles" / "round3_pmc_raw.json"
+LAUNCHES_PER_STEP = 100  # batch launches per step: the timed region at --steps 20 is ~100 ms
+LINE_LIMIT = 3000       # the driver keeps ~8 KB of stdout; the final line stays well inside it
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--launches-per-step", type=int, default=LAUNCHES_PER_STEP, help="batch launches per step")
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--error-percent", type=float, default=0.01, help="--e of the reference CLI, in percent")
     ap.add_argument("--batch", type=int, default=32, help="independent queries per step (one launch serves them all)")
@@ -388,6 +390,100 @@ def cold_numbers(Engine, nat, make_query, rows: int, e: float) -> dict:
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The line the driver parses (pure functions: tests/test_bench_line.py formats one from canned numbers)
+# ---------------------------------------------------------------------------------------------------------------
+def unique_sampled_rows(nat, queries, n_global: int, lo: int = 0, hi=None) -> int:
+    """How many DISTINCT rows of [lo, hi) the queries of one launch sample (host-side planner, no GPU): the bytes a launch
+    has to fetch at least once, whatever its queries share in the caches."""
+    import numpy as np
+    hi = n_global if hi is None else hi
+    seen = np.zeros(hi - lo, dtype=bool)
+    done = set()
+    for q in queries:
+        key = (q.method, q.sample_percent, q.num_threads, q.clt_round0, q.clt_growth, q.check_interval, q.row_lo, q.row_hi)
+        if key in done:  # aggregate and threshold do not change which rows a never-converging query sweeps
+            continue
+        done.add(key)
+        _, rounds, _ = nat.plan_families(q, n_global, lo, hi, 0)
+        for r in range(rounds):
+            for f in nat.plan_families(q, n_global, lo, hi, r)[0]:
+                o = np.arange(f.ord_lo, f.ord_hi, dtype=np.int64)
+                seen[f.row0 + (o // f.seg_len) * f.pitch + (o % f.seg_len) * f.step - lo] = True
+                if f.flags & nat.F_PAIR:
+                    o = np.arange(f.ord_lo_b, f.ord_hi_b, dtype=np.int64)
+                    seen[f.row0_b + o * f.step - lo] = True
+    return int(seen.sum())
+
+
+def headline_roofline(kernel: str, avg_launch_us: float, algorithmic_bytes: float, unique_bytes: float, traffic, executed_bytes: float,
+                      traffic_source=None) -> dict:
+    """HBM roofline of the launch that serves a batch.  `algorithmic` = 8 B x the rows the SUM / AVG queries of the batch
+    sample (COUNT is metadata, SURVEY 8d: 0 B).  The queries of a batch sample the same rows and meet in the compute dies'
+    L2s, so most of those bytes never cross the fabric: `achieved` is priced on the bytes that DO — the PMC traffic when
+    profiles/ holds it for these very sources, else the distinct sampled bytes (each fetched at least once) — never more
+    than the algorithmic bytes.  The rate of all executed loads is kept as `l2_rate`: informational, not a roofline."""
+    t = avg_launch_us * 1e-6
+    basis, moved = ("pmc_traffic", float(traffic)) if traffic else ("unique_bytes", float(unique_bytes))
+    moved = min(moved, float(algorithmic_bytes))
+    achieved = moved / t / 1e9
+    return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": min(achieved / HBM_PEAK_GBPS, 1.0), "traffic": traffic, "basis": basis, "bytes_priced": moved,
+            "algorithmic_bytes_per_launch": float(algorithmic_bytes), "unique_bytes_per_launch": float(unique_bytes),
+            "avg_launch_us": avg_launch_us, "l2_rate_GBps": executed_bytes / t / 1e9, "traffic_source": traffic_source}
+
+
+def _r(x, nd=4):
+    return None if x is None else (round(x, nd) if isinstance(x, float) else x)
+
+
+def compact_line(rep: dict) -> dict:
+    """bench_report.json -> the one line on stdout: the contract's keys, `roofline`, `roofline_hbm`, `cpu_baseline`."""
+    cfg, rf = rep["config"], rep["roofline"]
+    line = {k: rep[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(line["value"], 1), _r(line["ms_per_step"], 4)
+    line["config"] = {k: cfg[k] for k in ("workload", "rows_per_gpu", "global_rows", "queries_per_step", "launches_per_step", "queries_per_launch",
+                                          "samples_per_query_per_gpu", "collectives_per_step", "collective") if k in cfg}
+    line["roofline"] = {k: _r(rf.get(k), 4 if k == "frac" else 1) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "basis",
+                                                                            "algorithmic_bytes_per_launch", "unique_bytes_per_launch", "avg_launch_us", "l2_rate_GBps")}
+    if rep.get("roofline_hbm"):
+        line["roofline_hbm"] = [{k: _r(c.get(k), 4 if k == "frac" else 1) for k in ("case", "kernel", "avg_launch_us", "algorithmic_bytes", "achieved", "frac")}
+                                for c in rep["roofline_hbm"][:4]]
+    if rep.get("single_query"):
+        sq = rep["single_query"]
+        line["single_query"] = {"kernel": sq["kernel"], "avg_launch_us": _r(sq["avg_launch_us"], 2), "frac": _r(sq["frac"], 4),
+                                "closed_loop_us_p50": _r(sq["closed_loop_latency_us"]["p50"], 2)}
+    cb = rep.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: (_r(cb.get(k), 5) if k == "value" else cb.get(k)) for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}
+        if line["cpu_baseline"].get("sample") and len(line["cpu_baseline"]["sample"]) > 240:
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:237] + "..."
+    line["report"] = "bench_report.json"
+    if len(json.dumps(line)) > LINE_LIMIT:  # never let a long string cost the driver the whole line
+        line["config"]["workload"] = line["config"]["workload"][:200]
+        line.pop("single_query", None)
+    assert len(json.dumps(line)) <= LINE_LIMIT, len(json.dumps(line))
+    return line
+
+
+def write_report(rep: dict):
+    text = json.dumps(rep, indent=1)
+    for d in (ROOT, ROOT / "gpurun_out"):
+        if d.is_dir():
+            try:
+                (d / "bench_report.json").write_text(text)
+            except OSError:
+                pass
+    for k, v in rep.items():  # one object per line on stderr: readable in a log tail, never in the way of the stdout line
+        if isinstance(v, list) and v and isinstance(v[0], dict):
+            for item in v:
+                print(json.dumps({k: item}), file=sys.stderr)
+        elif isinstance(v, dict):
+            print(json.dumps({k: v}), file=sys.stderr)
+    sys.stderr.flush()
+
+
 def main():
     args = parse()
     import torch
@@ -511,7 +607,7 @@ def main():
 
         # ---- roofline of the dominant kernel (k_sweep_lean_multi): ONE batch in flight, the launch's own begin/end
         #      timestamps (event pair attached to the dispatch), before the throughput loop ----
-        prof_steps = max(10, min(100, args.steps))
+        prof_steps = 100
         natives[0].set_profiling(True)
         ms_sum, ms_min, swept, wgs = 0.0, 1e9, 0, 0
         for _ in range(prof_steps):
@@ -598,7 +694,7 @@ def main():
                 nb2[0].fetch()
                 acc2.append(nb2[0].launch_info())
             nb2[0].set_profiling(False)
-            k2 = max(10, min(200, args.steps))
+            k2 = 200
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             for k in range(k2):
@@ -652,14 +748,15 @@ def main():
                 for p_ in ps_:
                     p_.close()
 
-        # ---- the timed region: K steps, every result fetched ----
-        for _ in range(max(args.warmup, 1)):
+        # ---- the timed region: K steps of L launches each, every result fetched ----
+        L = max(1, args.launches_per_step)
+        for _ in range(max(args.warmup, 1) * L):
             step()
         drain()
         fence()
         k_state["k"] = 0
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps * L):
             step()
         lasts = drain()
         fence()
@@ -690,57 +787,58 @@ def main():
         traffic = None
 
     if rank == 0:
-        line = {
-            "metric": "aggregates/sec (10M-row region APPROX SUM/AVG/COUNT with 95% CI, CLT --e 0.01) + achieved HBM GB/s",
-            "value": world * B * args.steps / dt,
+        qs0 = batch_queries(e)
+        # algorithmic bytes: 8 B per row the SUM / AVG queries sample (COUNT is metadata, SURVEY 8d: 0 B although the
+        # reference — and this launch — run the sampler for it); executed: every load of every query
+        per_q = [int(r.visited) for r in firsts[:B]] if not use_dist else [int(swept // B)] * B
+        alg_bytes = 8.0 * sum(v for q_, v in zip(qs0, per_q) if q_.agg != nat.COUNT)
+        try:
+            uniq_bytes = 8.0 * unique_sampled_rows(nat, qs0, n_global, lo, hi)
+        except Exception:
+            uniq_bytes = 8.0 * (hi - lo)  # every row of the shard at most once
+        roof = headline_roofline(batch_kernel, 1e3 * avg_launch_ms, alg_bytes, uniq_bytes, traffic, bytes_per_launch, traffic_src)
+        roof.update({"min_launch_us": 1e3 * ms_min, "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps,
+                     "executed_bytes_per_launch": bytes_per_launch, "packed_layout": packed,
+                     "l2_rate_guide_GBps": [16800, 18800],
+                     "note": "the queries of a batch sample the same 20 % of the rows (the reference's samplers are deterministic in (N, pct)) and the "
+                             "launch is XCD-aware (workgroup k of every group on compute die k mod 8, sweeping the k-th share of its query's tiles), so "
+                             "they read them out of that die's L2 together: `l2_rate_GBps` is the rate of all executed loads (the guide measures 16.8-18.8 "
+                             "TB/s for L2-served reads) and is NOT a roofline figure; `achieved` prices only the bytes that cross the fabric.  HBM proper: "
+                             "`roofline_hbm` (tables far larger than the 256 MiB Infinity Cache)"})
+        info = eng.info()
+        Lps = max(1, args.launches_per_step)
+        rep = {
+            "metric": "aggregates/sec (10M-row-per-GPU APPROX AVG/SUM/COUNT with 95% CI, CLT --e 0.01) + achieved HBM GB/s",
+            "value": B * args.steps * Lps / dt,
             "unit": "aggregates/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "configs[1]: 10M-row APPROX AVG/SUM/COUNT (same moments), CLT --e 0.01 (percent, as the reference CLI "
-                            "reads it: never converges -> full 20% dual-pointer sweep, should_stop armed), table resident in HBM; "
-                            f"one step = a batch of {B} different queries in ONE launch, every result fetched",
+                "workload": f"configs[1]: 10M-row APPROX AVG/SUM/COUNT, CLT --e 0.01 percent (never converges: full 20% dual-pointer sweep, "
+                            f"should_stop armed), table resident in HBM; step = {Lps} launches x {B} different queries per launch, every result fetched",
                 "rows_per_gpu": rows, "global_rows": n_global, "sample_percent": pct, "error_percent": e,
                 "pointers": "4,6,...,16 per GPU (x n_gpus)", "samples_per_query_per_gpu": int(swept // B),
-                "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_step": 1 if not use_dist else 2,
-                "queries_per_step": B, "batches_in_flight": 2, "fetched_every_step": True,
-                "collectives_per_step": collectives_per_step, "collective": collective,
-                "unit_definition": "one 10M-row region aggregate per GPU per query; a global query over N regions counts N",
+                "clt_round0": CLT_ROUND0, "clt_growth": CLT_GROWTH, "launches_per_step": Lps * (1 if not use_dist else 2),
+                "queries_per_launch": B, "queries_per_step": B * Lps, "batches_in_flight": 2, "fetched_every_step": True,
+                "collectives_per_step": collectives_per_step * Lps, "collective": collective,
+                "unit_definition": "one completed query (value + 95 % interval) over the GLOBAL table; with N GPUs every rank sweeps its 10M-row region of it",
+                "cadence_note": "rounds of 4096 x 4^r rows per pointer, not the reference's check every 10 samples: immaterial at e = 0.01 % (never "
+                                "converges); at e = 1 % the geometric schedule stops at 20 480 rows per pointer where the reference's T = 2 run stops at 12 390",
             },
-            "global_queries_per_sec": B * args.steps / dt,
+            "region_aggregates_per_sec": world * B * args.steps * Lps / dt,
+            "rows_swept_per_sec": float(swept) * world * args.steps * Lps / dt,
+            "timed_seconds": dt,
             "result": {"value": last.value, "ci": [last.ci_lower, last.ci_upper], "n": int(last.n), "converged": int(last.converged),
                        "rounds": int(last.rounds), "same_as_first_execution": bool(agree)},
-            "roofline": {
-                "bound": "hbm", "kernel": batch_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
-                "algorithmic_over_traffic": (bytes_per_launch / traffic) if traffic else None,
-                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e3 * avg_launch_ms, "min_launch_us": 1e3 * ms_min,
-                "queries_per_launch": B, "workgroups": int(wgs), "launches_timed": prof_steps, "packed_layout": packed,
-                "served_from": "L2 of the compute dies (the batch's queries sample the same rows; the launch is XCD-aware), backed by the "
-                               "Infinity Cache: NOT HBM-bound - see `traffic` and `l2_rate`",
-                "l2_rate": {"achieved_GBps": achieved, "guide_measured_GBps": [16800, 18800],
-                            "frac_of_guide_max": achieved / 18800.0,
-                            "source": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': rows shared by every workgroup, served by the XCDs' L2s, "
-                                      "read at 16.8-18.8 TB/s chip-wide"},
-                "note": "`achieved` is what the contract defines: 8 B per sampled row (SoA f64 amount column) x the rows all queries of the "
-                        "batch sweep / mean duration of the ONE launch that serves the batch (the dispatch's own begin/end timestamps: HIP "
-                        "events attached to the launch, hipExtLaunchKernelGGL, on the launch stream - the clock rocprofv3 reports, "
-                        "profiles/round2_bench_kernel_stats.csv).  A `frac` ABOVE 1 says that these bytes do not come out of HBM: every "
-                        "query executes all of its own loads, but the launch is XCD-aware - workgroup k of every group sits on compute "
-                        "die k mod 8 and sweeps the k-th share of its query's tiles - and the queries of a batch sample the same rows (the "
-                        "reference's samplers are deterministic in (N, pct)), so they read them out of that die's L2 together: the fabric "
-                        "moves a fifth of the algorithmic bytes (`traffic`, PMC) and the launch runs at the rate the guide measures for "
-                        "L2-served reads (`l2_rate`).  `packed_layout` is the same batch without the alignment: traffic ~ algorithmic, "
-                        "Infinity-Cache bandwidth (a 10 M-row column with its stride-major views, 80 MB each, stays in the 256 MiB cache). "
-                        " HBM proper: `configs` has the same kernel on a batch whose queries share no byte (32 disjoint 10 M-row key "
-                        "ranges of a 320 M-row table: traffic = algorithmic) and the 100 M / 1 B-row lines",
-            },
+            "roofline": roof,
             "single_query": single,
             "open_loop_by_batch_size": open_loop,
             "early_termination_reading": other,
+            "table": {"hbm_bytes": int(info.hbm_bytes), "view_bytes": int(info.view_bytes), "n_views": int(info.n_views),
+                      "view_evictions": int(info.view_evictions), "view_fallbacks": int(info.view_fallbacks)},
+            "source_hash": source_hash(),
         }
         if packed is not None:
             packed["traffic"] = packed_traffic
@@ -749,22 +847,30 @@ def main():
         if extras and not use_dist:
             if not args.no_configs:
                 try:
-                    line["configs"] = run_configs(eng, nat, make_query, st, args.max_config_rows, Batch)
+                    rep["configs"] = run_configs(eng, nat, make_query, st, args.max_config_rows, Batch)
+                    # HBM proper: the streaming cases on the largest tables measured (1 B rows = 8 GB column, then 100 M)
+                    # (single-query launches and the batch over disjoint key ranges: nothing shared between queries in a cache)
+                    big = [c for c in rep["configs"] if c.get("frac") and c.get("algorithmic_bytes", 0) >= 1.0e9
+                           and ("queries_per_launch" not in c or "DISJOINT" in c["config"])]
+                    big.sort(key=lambda c: -c["algorithmic_bytes"])
+                    rep["roofline_hbm"] = [{"case": c["config"][:60], "kernel": c["kernel"], "avg_launch_us": c["kernel_us"],
+                                            "algorithmic_bytes": c["algorithmic_bytes"], "achieved": c["achieved_GBps"], "frac": c["frac"]} for c in big]
                 except Exception as ex:
-                    line["configs"] = [{"error": repr(ex)}]
+                    rep["configs"] = [{"error": repr(ex)}]
             try:
                 eng.release_table()
-                line["cold"] = cold_numbers(Engine, nat, make_query, rows, e)
+                rep["cold"] = cold_numbers(Engine, nat, make_query, rows, e)
             except Exception as ex:
-                line["cold"] = {"error": repr(ex)}
+                rep["cold"] = {"error": repr(ex)}
             if not args.no_cpu_baseline:
                 try:
                     cb = cpu_baseline(rows, e, args.cpu_sample_rows)
-                    line["cpu_baseline"] = cb.get("reference", cb["port"])
-                    line["cpu_baseline_all"] = cb
+                    rep["cpu_baseline"] = cb.get("reference", cb["port"])
+                    rep["cpu_baseline_all"] = cb
                 except Exception as ex:  # the bench line must still print
-                    line["cpu_baseline"] = {"value": None, "unit": "aggregates/sec", "cores": 0, "kind": "port", "sample": f"failed: {ex!r}"}
-        print(json.dumps(line), flush=True)
+                    rep["cpu_baseline"] = {"value": None, "unit": "aggregates/sec", "cores": 0, "kind": "port", "sample": f"failed: {ex!r}"}
+        write_report(rep)
+        print(json.dumps(compact_line(rep)), flush=True)
 
     for nb in natives:
         nb.close()
