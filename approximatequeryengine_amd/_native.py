@@ -26,6 +26,7 @@ Q_FORCE_PERSIST = 4
 Q_NO_LAYOUT = 8
 Q_SHARE_GPU = 16
 Q_NO_LEAN = 32
+Q_FORCE_LEAN = 64
 KERNEL_ROUND, KERNEL_SWEEP_PERSIST, KERNEL_SWEEP_LEAN, KERNEL_SWEEP_MULTI, KERNEL_SWEEP_LEAN_MULTI = 0, 1, 2, 3, 4
 KERNEL_NAMES = {0: "k_round", 1: "k_sweep_persist", 2: "k_sweep_lean", 3: "k_sweep_multi", 4: "k_sweep_lean_multi"}
 F_TOPUP = 1
@@ -81,6 +82,14 @@ class TableInfo(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class StageStats(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("device_alloc_ms", C.c_double), ("pinned_alloc_ms", C.c_double), ("fill_ms", C.c_double),
+                ("wait_ms", C.c_double), ("host_bytes", C.c_uint64), ("link_bytes", C.c_uint64), ("chunks", C.c_uint32), ("fill_threads", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class AqeError(RuntimeError):
     """A C-ABI call failed; mirrors pybind11 turning C++ exceptions into RuntimeError."""
 
@@ -119,6 +128,7 @@ def lib() -> C.CDLL:
         "aqe_stage_records": (C.c_int, [vp, vp, u64, u64, u64, u32]),
         "aqe_stage_file": (C.c_int, [vp, C.c_char_p, u64, u64, u32]),
         "aqe_file_rows": (C.c_int, [C.c_char_p, P(u64)]),
+        "aqe_last_stage_stats": (C.c_int, [vp, P(StageStats)]),
         "aqe_save_file": (C.c_int, [vp, C.c_char_p]),
         "aqe_generate_synthetic": (C.c_int, [vp, u64, u64, u64, u64, u32]),
         "aqe_attach_device": (C.c_int, [vp, vp, vp, u64, u64, u64, dbl]),

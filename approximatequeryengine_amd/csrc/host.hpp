@@ -41,7 +41,8 @@ struct LaunchDesc {
     uint64_t samples = 0;  // ordinals in this launch's windows (upper bound for the top-up)
 };
 
-constexpr size_t kStageChunkRows = 1u << 21;  // 2 Mi rows: 64 MiB of AoS per pinned buffer
+constexpr size_t kStageChunkRows = 1u << 19;  // 512 Ki rows: 16 MiB of AoS per pinned buffer
+constexpr int kStageRing = 4;                 // pinned buffers of the staging ring (kept by the context between stagings)
 constexpr size_t kMaxStrideViews = 8;  // stride-major copies of the column a table may hold (one per pointer step in use)
 constexpr size_t kBatchLanes = 3;  // side streams of the batched multi-GPU form (see ensure_lanes)
 constexpr size_t kInfinityCacheBytes = 256ull << 20;  // MI355X: a column beyond it is streamed with non-temporal loads
@@ -78,7 +79,17 @@ struct StrideView {
     uint64_t last_use = 0;
 };
 
+// Pinned bounce buffers of the staging path: allocated on the first staging (pinning memory is the most expensive step
+// of a small load: ~0.1 ms per MiB) and kept with the context, so that restaging and sharded loads pay it once.
+struct StageRing {
+    void* buf[aqe::kStageRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[aqe::kStageRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t bytes_each = 0;
+};
+
 struct aqe_ctx {
+    StageRing ring;
+    aqe_stage_stats stage_stats{};  // of the most recent staging (aqe_last_stage_stats)
     std::vector<PlanScratch> scratch_pool;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -187,6 +198,7 @@ struct aqe_plan {
     bool persist = false;
     SweepForm decide, totals;
     SweepForm decide_lean, totals_lean, head_lean;  // their lean variants (lean.hip), ok when the plan qualifies
+    SweepForm single_lean;                          // a plan of ONE round as a lean launch (runs and rows of blocks; tiles dealt out wave by wave)
     uint64_t last_samples = 0;                      // samples the most recent single launch swept
     bool last_topup_swept = false;                  // ... and whether it swept the top-up along (as one more slot)
     hipGraphExec_t round_graph = nullptr;  // one-launch-per-round form: the launches, captured once

@@ -201,17 +201,23 @@ hipError_t launch_sweep_persist(const PersistLaunch& a, unsigned grid, hipStream
 hipError_t launch_sweep_multi(const PersistLaunch* table, const unsigned long long* wg_map, unsigned long long epoch, unsigned grid, bool nt,
                               hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
-// ---- lean single-launch sweep of a multi-round query whose whole sweep is in flight at once: lean.hip -------------
+// ---- lean single-launch sweep: lean.hip ----------------------------------------------------------------------------
 // A RUN is a family in its simplest form: `rows` consecutive rows of the column (or of a stride-major view) that all
-// belong to the sample — what every strided pointer read through a view comes to.
+// belong to the sample — what every strided pointer read through a view comes to, and what an exact scan is.  A SEGMENTED
+// run is a row of equal blocks `pitch` rows apart (block_sample, DB.cpp:1151-1181): tile t of it lies in block
+// t / tiles_per_block.
 constexpr int kLeanMaxRuns = 128;                                       // two runs per lane of a wave: lane i holds runs i and i + 64
 constexpr int kLeanMaxSlots = kMaxPersistGrid + kMaxPersistRounds;      // a round boundary splits at most one workgroup
+constexpr uint32_t kLeanMetaGroupB = 1u << 8;   // meta: the run feeds group b (every CLT worker but the leader)
+constexpr uint32_t kLeanMetaSeg = 1u << 9;      // meta: segmented run; entry i + 64 holds its geometry (see LeanRuns)
 struct LeanRuns {  // part of the launch descriptor, structure of arrays: lane i of every wave holds runs i and i + 64 in registers
     uint64_t row0[kLeanMaxRuns];        // first row, relative to LeanLaunch::amount
     uint32_t tile_begin[kLeanMaxRuns];  // first tile of the run in the launch's tile list; 0xffffffff past the table
-    uint32_t rows[kLeanMaxRuns];
-    uint32_t meta[kLeanMaxRuns];        // round | group << 8
+    uint32_t rows[kLeanMaxRuns];        // rows of the run (of ONE block for a segmented run)
+    uint32_t meta[kLeanMaxRuns];        // round | kLeanMeta*
     uint32_t slot[kLeanMaxRuns];        // of the run's round: its first slot | the first workgroup that sweeps tiles of it << 16
+    // A segmented run i (< 64; such plans hold at most 64 runs) keeps its geometry in entry i + 64, whose tile_begin stays
+    // 0xffffffff: row0[i + 64] = rows between block starts, meta[i + 64] = tiles per block.
 };
 // Plans of more runs than the lanes hold (many pointers: T >= 64 on 10 M rows) bring their table in device memory; every
 // workgroup copies it to LDS and finds a tile's run by bisection (k_sweep_lean<.., wide>).
@@ -220,25 +226,34 @@ struct LeanWideRuns {
     uint64_t row0[kLeanWideRuns];
     uint32_t tile_begin[kLeanWideRuns], rows[kLeanWideRuns], meta[kLeanWideRuns], slot[kLeanWideRuns];
 };
-struct LeanLaunch {
-    const double* amount;
-    uint32_t ntiles, rounds;
-    int32_t has_where;
-    uint32_t tiles_per_wg;     // workgroup b owns the tiles [b tiles_per_wg, (b + 1) tiles_per_wg)
-    double wmin, wmax, shift;
+// What only the workgroup that finishes the query needs.  One wave of every workgroup loads it beside its first tile and
+// parks it in LDS, so that after the last ticket nothing is fetched from the descriptor any more: each such fetch was a
+// dependent round trip on the query's critical path (profiles/round2_lean_timeline.txt: 5 us of tail behind a 3.5 us sweep).
+struct LeanTail {
+    uint32_t rounds, finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only, pad0;  // as in PersistLaunch
     uint32_t slot_begin[kMaxPersistRounds + 1];  // round r owns the slots [slot_begin[r], slot_begin[r + 1]) of the flat list
-    double* partials;          // [slots][kVec]: doubles 0..6 = a workgroup's partial of one round
-    unsigned* counter;         // arrival tickets (k_round's), zero between launches
-    double* out_totals;        // totals_only: [rounds][kVec]
-    QueryState* state;
+    uint32_t pad1;
     FoldParams fold;
     FinalizeParams fin;
+    double* out_totals;        // totals_only: [rounds][kVec]
+    QueryState* state;
     aqe_result* result;
     unsigned long long* result_seq;
+};
+static_assert(sizeof(LeanTail) % 8 == 0 && sizeof(LeanTail) <= 64 * 8, "one 8-byte load per lane of a wave stages the tail");
+struct LeanLaunch {
+    const double* amount;
+    uint32_t ntiles;
+    int32_t has_where;
+    uint32_t tiles_per_wg;     // workgroup b owns the tiles [b tiles_per_wg, (b + 1) tiles_per_wg); 0: tiles are dealt out
+                               // wave by wave across the whole launch (single-round plans: one slot per workgroup)
+    uint32_t nruns;
+    double wmin, wmax, shift;
+    double* partials;          // [slots][kVec]: doubles 0..6 = a workgroup's partial of one round
+    unsigned* counter;         // arrival tickets (k_round's), zero between launches
     unsigned long long epoch;
-    uint32_t finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only;  // as in PersistLaunch
     const LeanWideRuns* wide;  // null: the run table below; else the plan's table of `nruns` > kLeanMaxRuns runs
-    uint32_t nruns, pad1;
+    LeanTail tail;
     // The run table travels IN the descriptor — the kernel arguments of a single launch, the batch's table otherwise — so a
     // wave's very first loads (its lane's two runs) depend on nothing but the descriptor's address.
     LeanRuns runs;

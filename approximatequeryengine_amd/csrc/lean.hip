@@ -74,12 +74,12 @@ __device__ __forceinline__ u64* lean_t0_word(unsigned* counter) { return reinter
 struct __attribute__((packed, aligned(8))) Row2 { double x, y; };
 
 // One tile = up to 1024 consecutive rows from `base` (two rows per lane per 16-byte load, eight loads in flight);
-// `rem` rows of the run are left from `base` on.
+// `rem` rows of the run (or of the block) are left from `base` on.
 template <bool kNT>
 __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, const double* safe, int lane, int has_where, double wmin, double wmax,
                                           double shift, TileAcc& ta) {
+    Row2 v2[kTileUnroll];
     if (rem >= static_cast<unsigned>(kDenseTileOrdinals)) {  // inside the run: no masks
-        Row2 v2[kTileUnroll];
         const Row2* const p = reinterpret_cast<const Row2*>(base) + lane;
 #pragma unroll
         for (int k = 0; k < kTileUnroll; ++k) {
@@ -112,23 +112,36 @@ __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, cons
         }
         return;
     }
-    // the run's last tile (every tile of a run of short segments): one row per lane per load, sixteen loads in flight, rows
-    // past the end masked — and never addressed: such a lane reads row 0 of the column instead
-    double v[2 * kTileUnroll];
-    bool ok[2 * kTileUnroll];
+    // the last tile of a run — every tile of a run of 1000-row blocks: the same 16-byte loads, a pair masked where it
+    // leaves the run and never addressed there (such a lane reads rows 0 and 1 of the column instead)
+    bool ok[kTileUnroll];
 #pragma unroll
-    for (int k = 0; k < 2 * kTileUnroll; ++k) {
-        const unsigned r0 = static_cast<unsigned>(lane) + 64u * static_cast<unsigned>(k);
-        ok[k] = r0 < rem;
-        const double* const p = ok[k] ? base + r0 : safe;
-        v[k] = kNT ? __builtin_nontemporal_load(p) : *p;
+    for (int k = 0; k < kTileUnroll; ++k) {
+        const unsigned oi = 2u * static_cast<unsigned>(lane) + 128u * static_cast<unsigned>(k);
+        ok[k] = oi + 1u < rem;  // both rows of the pair inside the run
+        const Row2* const p = reinterpret_cast<const Row2*>(ok[k] ? base + oi : safe);
+        if (kNT) {
+            v2[k].x = __builtin_nontemporal_load(&p->x);
+            v2[k].y = __builtin_nontemporal_load(&p->y);
+        } else {
+            v2[k] = *p;
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 2 * kTileUnroll; ++k) {
-        const double x = v[k];
-        const bool px = ok[k] && (!has_where || (x >= wmin && x <= wmax));
+    for (int k = 0; k < kTileUnroll; ++k) {
+        const double x = v2[k].x, y = v2[k].y;
+        const bool px = ok[k] && (!has_where || (x >= wmin && x <= wmax)), py = ok[k] && (!has_where || (y >= wmin && y <= wmax));
+        const double dx = px ? x - shift : 0.0, dy = py ? y - shift : 0.0;
+        ta.nv += ok[k] ? 2u : 0u;
+        ta.n += (px ? 1u : 0u) + (py ? 1u : 0u);
+        ta.s += dx; ta.q += dx * dx;
+        ta.s += dy; ta.q += dy * dy;
+    }
+    if (rem & 1u) {  // (wave-uniform) a run of odd length ends in half a pair: that row on its own, folded by lane 0
+        const double x = base[rem - 1u];
+        const bool px = lane == 0 && (!has_where || (x >= wmin && x <= wmax));
         const double dx = px ? x - shift : 0.0;
-        ta.nv += ok[k] ? 1u : 0u;
+        ta.nv += lane == 0 ? 1u : 0u;
         ta.n += px ? 1u : 0u;
         ta.s += dx; ta.q += dx * dx;
     }
@@ -136,26 +149,23 @@ __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, cons
 
 // Wave 0 of the folding workgroup, lane q holding the moments through round q (or a slot's own total where the form
 // asks for that): the decision and the result.  The rules and what follows them are the monitor's (persist.hip,
-// monitor_fold), evaluated once, for every round at the same time.
-__device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], unsigned lane, unsigned long long t0, unsigned long long epoch) {
-    const unsigned rounds = K->rounds;
-    const bool tslot = K->topup_slot != 0;  // the last slot is the top-up: summed on its own, never judged
+// monitor_fold), evaluated once, for every round at the same time.  T: the launch's tail, in LDS.
+__device__ __forceinline__ void lean_judge(const LeanTail& T, const double (&tot)[7], unsigned lane, unsigned long long t0, unsigned long long epoch) {
+    const unsigned rounds = T.rounds;
+    const bool tslot = T.topup_slot != 0;  // the last slot is the top-up: summed on its own, never judged
     const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
-    if (K->totals_only) {  // multi-GPU form: hand the slot totals out; the decision is taken after the all-reduce
+    if (T.totals_only) {  // multi-GPU form: hand the slot totals out; the decision is taken after the all-reduce
         if (lane < rounds) {
-            double* o = K->out_totals + static_cast<size_t>(lane) * kVec;
+            double* o = T.out_totals + static_cast<size_t>(lane) * kVec;
 #pragma unroll
             for (int cc = 0; cc < 7; ++cc) o[cc] = tot[cc];
             o[7] = 0.0;
         }
         return;
     }
-    FoldParams fp;
-    fp.shift = K->fold.shift; fp.z = K->fold.z; fp.e = K->fold.e; fp.base = K->fold.base; fp.is_clt = K->fold.is_clt; fp.is_topup = 0; fp.pad = 0;
-    FinalizeParams fin;
-    fin.n_global = K->fin.n_global; fin.pct = K->fin.pct; fin.shift = K->fin.shift; fin.agg = K->fin.agg;
-    fin.convention = K->fin.convention; fin.is_exact = K->fin.is_exact; fin.is_clt = K->fin.is_clt;
-    const bool with_result = K->finalize_here != 0;
+    const FoldParams fp = T.fold;
+    const FinalizeParams fin = T.fin;
+    const bool with_result = T.finalize_here != 0;
     QueryState st{};
     st.n_a = tot[0]; st.sd_a = tot[1]; st.qd_a = tot[2];
     st.n_b = tot[3]; st.sd_b = tot[4]; st.qd_b = tot[5];
@@ -183,8 +193,8 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
     st.stop = code != 0;
     // DB.cpp:1032: too few rows collected -> the top-up is due.  Swept with the rounds (head form): it is added here.
     // Otherwise the result is marked and the host launches it (rarely due).
-    const bool goes_on = code == 0 && K->more_rounds;  // head form: out of rounds, not out of samples
-    bool due = K->topup_gate && st.n_p < static_cast<double>(fp.base / 4);
+    const bool goes_on = code == 0 && T.more_rounds;  // head form: out of rounds, not out of samples
+    bool due = T.topup_gate && st.n_p < static_cast<double>(fp.base / 4);
     if (tslot && due && !goes_on) {  // the fold of a top-up vector (device_common.hpp, fold)
         st.n_p += tup[0]; st.sd_p += tup[1]; st.qd_p += tup[2];
         st.topup += tup[0];
@@ -192,19 +202,19 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
         due = false;
     }
     if (with_result && !result_now) res = make_result(st, fin);
-    if (K->want_ticks) {
+    if (T.want_ticks) {
         st.t0 = t0;
         res.kernel_ms = static_cast<double>(__builtin_amdgcn_s_memrealtime() - st.t0) * 1e-5;
     }
     res.rounds = st.rounds;
     res.converged = code;
     res.topup_pending = goes_on ? 2 : due ? 1 : 0;  // 2: the host launches the plan's remaining rounds
-    lean_state_store(K->state, st);
+    lean_state_store(T.state, st);
     if (with_result) {
-        *K->result = res;
+        *T.result = res;
         // the host polls the pinned result instead of waiting for the end of the launch: the check word tells it when
         // every field has landed (kernels.hpp, result_check)
-        __hip_atomic_store(K->result_seq, result_check(res, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(T.result_seq, result_check(res, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef AQE_LEAN_STAMPS
     g_lean_stamps[static_cast<size_t>(kMaxPersistGrid) * kPersistWaves * 8 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -212,14 +222,17 @@ __device__ __forceinline__ void lean_judge(LeanKarg K, const double (&tot)[7], u
 }
 
 // One query on the workgroups bid = 0 .. G-1 (a launch of its own, or one group of a batch's launch).  `a`: the fields
-// the sweep needs, in registers; K: the descriptor the folding workgroup reads the rest from (the kernel arguments of
-// a single launch, the batch's table in device memory otherwise).
+// the sweep needs, in registers; K: the descriptor (the kernel arguments of a single launch, the batch's table in device
+// memory otherwise) — read twice: a lane's two runs, and the tail.
 template <bool kNT, bool kWide>
 __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* const runs, const LeanKarg K, const unsigned bid, const unsigned G, const unsigned long long epoch) {
-    __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];  // a wave's sums of a round (zero where it swept none)
+    // a wave's sums of a round (zero where it swept none); in the folding workgroup, later, the launch's whole partial list
+    __shared__ double lds_part[kMaxPersistRounds][kPersistWaves][kVec];
+    static_assert(kMaxPersistRounds * kPersistWaves >= kLeanMaxSlots, "the partial list fits where the workgroup's own sums were");
     __shared__ double lds_round[kMaxPersistRounds][kVec];
     __shared__ unsigned lds_slot[kMaxPersistRounds];
     __shared__ unsigned lds_mask[kPersistWaves];  // rounds a wave swept tiles of
+    __shared__ u64 lds_tail[64];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63;
     const unsigned wave = threadIdx.x >> 6;
@@ -241,20 +254,32 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
         my_tb = runs->tile_begin[lane]; my_rows = runs->rows[lane]; my_meta = runs->meta[lane]; my_slot = runs->slot[lane];
         my_tb_hi = runs->tile_begin[lane + 64]; my_rows_hi = runs->rows[lane + 64]; my_meta_hi = runs->meta[lane + 64]; my_slot_hi = runs->slot[lane + 64];
     }
+    // The tail of the descriptor — what only the folding workgroup reads — is fetched NOW, by the last wave, one word per
+    // lane, and parked in LDS after the sweep: nobody knows yet who will fold, and whoever does must not start fetching
+    // descriptor words then, one dependent round trip after the other.
+    const bool stager = wave == kPersistWaves - 1u;
+    u64 tail_word = 0;
+    if (stager && static_cast<unsigned>(lane) < sizeof(LeanTail) / 8u) tail_word = reinterpret_cast<const AQE_KARG u64*>(&K->tail)[lane];
     // every wave clears its own rows of lds_part: nothing to wait for before the sweep
 #pragma unroll
     for (unsigned i = 0; i < kMaxPersistRounds * kVec / 64; ++i) {
         const unsigned x = static_cast<unsigned>(lane) + 64u * i;
         lds_part[x >> 3][wave][x & 7u] = 0.0;
     }
-    if (a.want_ticks && bid == 0 && threadIdx.x == 0)
+    if (a.tail.want_ticks && bid == 0 && threadIdx.x == 0)
         __hip_atomic_store(lean_t0_word(a.counter), static_cast<u64>(__builtin_amdgcn_s_memrealtime()), AQE_RLX);
 #ifdef AQE_LEAN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LEAN_STAMP(1);
 #endif
 
-    const unsigned t_lo = bid * a.tiles_per_wg, t_end = t_lo + a.tiles_per_wg < a.ntiles ? t_lo + a.tiles_per_wg : a.ntiles;
+    // Tiles: a contiguous share per workgroup (its wave j takes the j-th, (j + 16)-th, ... of them: the 16 waves stream one
+    // window of the column, and the share holds tiles of one round or of a few consecutive ones) — or, for a plan of ONE
+    // round, dealt out wave by wave across the launch (tile t to wave t mod 16 G: every HBM channel busy from the start)
+    const bool dealt = a.tiles_per_wg == 0u;
+    const unsigned t_lo = dealt ? bid * kPersistWaves : bid * a.tiles_per_wg;
+    const unsigned t_end = dealt ? a.ntiles : (t_lo + a.tiles_per_wg < a.ntiles ? t_lo + a.tiles_per_wg : a.ntiles);
+    const unsigned t_step = dealt ? G * kPersistWaves : kPersistWaves;
     Acc acc;
     unsigned cur = ~0u, cur_slot = 0, touched = 0;  // the round this wave is in; the rounds it has been in
     auto flush = [&]() {
@@ -264,9 +289,9 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
         if (lane == 0) lds_slot[cur] = cur_slot;
         touched |= 1u << cur;
     };
-    for (unsigned t = __builtin_amdgcn_readfirstlane(t_lo + wave); t < t_end; t += kPersistWaves) {
+    for (unsigned t = __builtin_amdgcn_readfirstlane(t_lo + wave); t < t_end; t += t_step) {
         // the run that owns tile t: the last whose first tile is <= t (ascending; 0xffffffff past the table)
-        unsigned meta, run_slot, run_tb, run_rows;
+        unsigned meta, run_slot, run_tb, run_rows, first;
         u64 run_row0;
         if (kWide) {
             unsigned lo = 0, hi = a.nruns;
@@ -277,6 +302,7 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
             meta = __builtin_amdgcn_readfirstlane(lds_meta[lo]); run_slot = __builtin_amdgcn_readfirstlane(lds_rslot[lo]);
             run_tb = __builtin_amdgcn_readfirstlane(lds_tb[lo]); run_rows = __builtin_amdgcn_readfirstlane(lds_rows[lo]);
             run_row0 = uniform64(lds_row0[lo]);
+            first = (t - run_tb) * static_cast<unsigned>(kDenseTileOrdinals);
         } else {
             const unsigned below = static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb <= t))) + static_cast<unsigned>(__builtin_popcountll(__ballot(my_tb_hi <= t)));
             const bool hi = below > 64u;           // wave-uniform: the run sits in the lanes' second set
@@ -286,6 +312,13 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
             run_tb = hi ? __builtin_amdgcn_readlane(my_tb_hi, i) : __builtin_amdgcn_readlane(my_tb, i);
             run_rows = hi ? __builtin_amdgcn_readlane(my_rows_hi, i) : __builtin_amdgcn_readlane(my_rows, i);
             run_row0 = hi ? read_lane_u64(my_row0_hi, i) : read_lane_u64(my_row0, i);
+            first = (t - run_tb) * static_cast<unsigned>(kDenseTileOrdinals);
+            if (meta & kLeanMetaSeg) {  // a row of equal blocks: the tile's block and its place in it (geometry in entry i + 64)
+                const unsigned tps = __builtin_amdgcn_readlane(my_meta_hi, i), rel = t - run_tb;
+                const unsigned blk = tps == 1u ? rel : rel / tps;
+                run_row0 += static_cast<u64>(blk) * read_lane_u64(my_row0_hi, i);
+                first = (rel - blk * tps) * static_cast<unsigned>(kDenseTileOrdinals);
+            }
         }
         const unsigned r = meta & 0xffu;
         if (r != cur) {
@@ -293,12 +326,11 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
             cur = r;
             cur_slot = run_slot;
         }
-        const unsigned first = (t - run_tb) * static_cast<unsigned>(kDenseTileOrdinals);
         const unsigned rem = run_rows - first;
         const double* const base = a.amount + (run_row0 + first);
         TileAcc ta;
         lean_tile<kNT>(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
-        merge_tile(acc, ta, ((meta >> 8) & 1u) != 0);
+        merge_tile(acc, ta, (meta & kLeanMetaGroupB) != 0);
 #ifdef AQE_LEAN_STAMPS
         if (t == t_lo + wave) LEAN_STAMP(2);
 #endif
@@ -306,6 +338,7 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     LEAN_STAMP(3);
     if (cur != ~0u) flush();
     if (lane == 0) lds_mask[wave] = touched;
+    if (stager) lds_tail[lane] = tail_word;
     LEAN_STAMP(4);
     __syncthreads();
 
@@ -355,49 +388,66 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     __syncthreads();
     if (!s_last) return;
 
-    // ---- the last workgroup to arrive folds the launch.  Thread (q, c, part) — 64 threads per round, 16 rounds per
-    //      pass — sums component c of every eighth slot of round q straight out of the partial list (its loads in flight
-    //      together), eight neighbouring lanes combine their parts in a fixed order: bit-reproducible ----
-    const unsigned rounds = K->rounds;
-    const unsigned long long t0 = a.want_ticks ? __hip_atomic_load(lean_t0_word(a.counter), AQE_RLX) : 0ull;  // (in flight beside the partials)
-    for (unsigned q0 = 0; q0 < rounds; q0 += kPersistWaves) {
-        const unsigned q = q0 + wave, c = (static_cast<unsigned>(lane) >> 3) & 7u, part = static_cast<unsigned>(lane) & 7u;
-        const bool mine = q < rounds && c < 7u;
-        const unsigned b = mine ? K->slot_begin[q] : 0u, e = mine ? K->slot_begin[q + 1u] : 0u;
-        double s = 0.0;
-        constexpr unsigned kInFlight = 10;  // covers a round of 80 slots in one turn (a 10 M-row query's rounds: ~65)
-        for (unsigned sl0 = b + part; __ballot(sl0 < e) != 0; sl0 += 8u * kInFlight) {
-            double x[kInFlight];
+    // ---- the last workgroup to arrive folds the launch.  Everything it needs from the descriptor is in LDS already.  The
+    //      whole partial list — fewer than workgroups + rounds slots, whatever the size of the sweep — is fetched in ONE batch
+    //      of coalesced loads (three words per thread at most) into the space the workgroup's own sums occupied ----
+    const LeanTail& T = *reinterpret_cast<const LeanTail*>(lds_tail);
+    const unsigned rounds = T.rounds;
+    const unsigned long long t0 = T.want_ticks ? __hip_atomic_load(lean_t0_word(a.counter), AQE_RLX) : 0ull;  // (in flight beside the partials)
+    double* const words = &lds_part[0][0][0];
+    {
+        const unsigned nwords = T.slot_begin[rounds] * static_cast<unsigned>(kVec);
+        constexpr unsigned kPerThread = (kLeanMaxSlots * kVec + kPersistThreads - 1) / kPersistThreads;
+        double x[kPerThread];
 #pragma unroll
-            for (unsigned i = 0; i < kInFlight; ++i) {
-                const unsigned sl = sl0 + 8u * i;
-                x[i] = sl < e ? __hip_atomic_load(a.partials + static_cast<size_t>(sl) * kVec + c, AQE_RLX) : 0.0;
-            }
-#pragma unroll
-            for (unsigned i = 0; i < kInFlight; ++i) s += x[i];
+        for (unsigned i = 0; i < kPerThread; ++i) {
+            const unsigned w = threadIdx.x + i * kPersistThreads;
+            x[i] = w < nwords ? __hip_atomic_load(a.partials + w, AQE_RLX) : 0.0;
         }
+#pragma unroll
+        for (unsigned i = 0; i < kPerThread; ++i) {
+            const unsigned w = threadIdx.x + i * kPersistThreads;
+            if (w < nwords) words[w] = x[i];
+        }
+    }
+    __syncthreads();
+    // W waves per round (a power of two; one when the plan has more than eight rounds).  Thread (part, c) of a round's waves
+    // sums component c of every (8 W)-th slot of the round, ascending; the eight parts of a wave combine by DPP, the W waves
+    // of a round through LDS, in wave order: a fixed order whatever arrives when — bit-reproducible.
+    unsigned W = 1;
+    while (2u * W * rounds <= kPersistWaves) W *= 2u;
+    const unsigned per_pass = kPersistWaves / W;
+    for (unsigned q0 = 0; q0 < rounds; q0 += per_pass) {
+        const unsigned q = q0 + wave / W, wsub = wave % W;
+        const unsigned c = (static_cast<unsigned>(lane) >> 3) & 7u, part = (static_cast<unsigned>(lane) & 7u) + 8u * wsub;
+        const bool mine = q < rounds && c < 7u;
+        const unsigned b = mine ? T.slot_begin[q] : 0u, e = mine ? T.slot_begin[q + 1u] : 0u;
+        double s = 0.0;
+        for (unsigned sl = b + part; sl < e; sl += 8u * W) s += words[static_cast<size_t>(sl) * kVec + c];
         s += dpp_f64<0xB1>(s);   // lane ^ 1
         s += dpp_f64<0x4E>(s);   // lane ^ 2
         s += dpp_f64<0x141>(s);  // the other quad of the eight
-        if (mine && part == 0u) lds_round[q][c] = s;
+        if (mine && (lane & 7) == 0) lds_round[q * W + wsub][c] = s;
     }
     __syncthreads();
     LEAN_STAMP_FOLD(1);
     if (wave != 0) return;
     // lane q: the moments through round q (a slot's own total in the totals form, and for the top-up slot)
-    const bool tslot = K->topup_slot != 0;
+    const bool tslot = T.topup_slot != 0;
     const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
-    const bool own = K->totals_only != 0 || (tslot && static_cast<unsigned>(lane) == rounds - 1u);
+    const bool own = T.totals_only != 0 || (tslot && static_cast<unsigned>(lane) == rounds - 1u);
     double tot[7] = {0, 0, 0, 0, 0, 0, 0};
     for (unsigned r = 0; r < rounds; ++r) {
         const bool take = own ? r == static_cast<unsigned>(lane) : (r <= static_cast<unsigned>(lane) && r < rounds_j);
+        for (unsigned ws = 0; ws < W; ++ws) {
 #pragma unroll
-        for (int cc = 0; cc < 7; ++cc) {
-            const double x = lds_round[r][cc];
-            tot[cc] += take ? x : 0.0;
+            for (int cc = 0; cc < 7; ++cc) {
+                const double x = lds_round[r * W + ws][cc];
+                tot[cc] += take ? x : 0.0;
+            }
         }
     }
-    lean_judge(K, tot, static_cast<unsigned>(lane), t0, epoch);
+    lean_judge(T, tot, static_cast<unsigned>(lane), t0, epoch);
 }
 
 template <bool kNT, bool kWide>
@@ -418,7 +468,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_sweep_lean_multi(const Lean
     LeanLaunch a;  // what the sweep reads, out of the table once
     a.amount = K->amount; a.ntiles = K->ntiles; a.tiles_per_wg = K->tiles_per_wg;
     a.has_where = K->has_where; a.wmin = K->wmin; a.wmax = K->wmax; a.shift = K->shift;
-    a.partials = K->partials; a.counter = K->counter; a.want_ticks = 0; a.wide = nullptr; a.nruns = 0;
+    a.partials = K->partials; a.counter = K->counter; a.tail.want_ticks = 0; a.wide = nullptr; a.nruns = 0;
     lean_query<kNT, false>(a, &(table + (me >> 32))->runs, K, static_cast<unsigned>(me) & 0xffffu, static_cast<unsigned>(me >> 16) & 0xffffu, epoch);
 }
 

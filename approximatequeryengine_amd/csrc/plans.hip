@@ -28,7 +28,7 @@ void destroy_plan(aqe_plan* p) {
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_rehearsal) (void)hipFree(p->d_rehearsal);
     if (p->d_fams_small) (void)hipFree(p->d_fams_small);
-    for (SweepForm* f : {&p->decide, &p->totals, &p->head, &p->decide_lean, &p->totals_lean, &p->head_lean}) {
+    for (SweepForm* f : {&p->decide, &p->totals, &p->head, &p->decide_lean, &p->totals_lean, &p->head_lean, &p->single_lean}) {
         if (f->d_ppart) (void)hipFree(f->d_ppart);  // (the form's family table lives in the same block)
     }
     if (p->d_state) (void)hipFree(p->d_state);
@@ -293,12 +293,15 @@ int materialize_form(aqe_ctx* c, SweepForm& F) {
 }
 
 
-// The lean variant of a form (lean.hip, k_sweep_lean): for a plan whose families are all plain runs of rows.  Its own
-// tile list — a run is tiled from its first row — cut into one contiguous share per workgroup, and its own slot list:
-// round r owns one slot per workgroup whose share holds tiles of it (consecutive workgroups; a round boundary splits
-// at most one share, so there are fewer than workgroups + rounds slots whatever the size of the sweep).
-// Leaves F.ok false (and returns AQE_OK) when the plan does not qualify.
-int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t grid, size_t nrounds) {
+// The lean variant of a form (lean.hip, k_sweep_lean): for a plan whose families are all plain runs of rows, or rows of
+// equal blocks (block_sample: a SEGMENTED run).  Its own tile list — a run is tiled from its first row, a block from its
+// first row — and its own slot list.  Several rounds: the tile list is cut into one contiguous share per workgroup and
+// round r owns one slot per workgroup whose share holds tiles of it (consecutive workgroups; a round boundary splits at
+// most one share, so there are fewer than workgroups + rounds slots whatever the size of the sweep).  ONE round (the
+// single-round samplers: exact scans, strided samples through a view, blocks): tiles are dealt out wave by wave across
+// the launch, every workgroup owns one slot, and the grid is no larger than one tile per wave needs (`exact_grid`: the
+// caller — a batch — has fixed the group's size).  Leaves F.ok false (and returns AQE_OK) when the plan does not qualify.
+int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t grid, size_t nrounds, bool exact_grid = true) {
     aqe_ctx* c = p->ctx;
     static const bool off = [] { const char* e = std::getenv("AQE_LEAN"); return e && e[0] == '0'; }();  // diagnostics: AQE_LEAN=0
     if (off || !c->dense16 || grid == 0 || grid > static_cast<uint32_t>(kMaxPersistGrid)) return AQE_OK;
@@ -312,9 +315,10 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
     const int64_t base_gap = static_cast<int64_t>(reinterpret_cast<uintptr_t>(sw_t.amount) - reinterpret_cast<uintptr_t>(sw_r.amount)) / 8;  // rows (build_sweep_form)
     // up to kLeanMaxRuns runs travel in the launch descriptor (two per lane of a wave); up to kLeanWideRuns in a table of
     // their own in device memory (copied to LDS by every workgroup, searched by bisection)
-    struct Run { uint64_t row0; uint32_t tile_begin, rows, meta; };
+    struct Run { uint64_t row0; uint32_t tile_begin, rows, meta; uint64_t pitch; uint32_t tps; };  // pitch != 0: segmented
     std::vector<Run> runs;
     uint64_t tiles = 0, samples = 0;
+    bool any_seg = false;
     uint64_t round_begin[kMaxPersistRounds + 1] = {0};
     for (size_t r = 0; r < S; ++r) {
         const LaunchDesc& L = *slots[r];
@@ -323,31 +327,74 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
         round_begin[r] = tiles;
         for (uint32_t i = 0; i < L.nfam; ++i) {
             const DevFamily& d = p->h_fams[L.fam_offset + i];
-            // a plain run: one pointer, step 1, its window inside one segment
-            if (!is_dense16(d.step, d.flags, d.seg_len) || (d.flags & kFamLinear) || d.ord_hi <= d.ord_lo) return AQE_OK;
-            const uint64_t seg = d.ord_lo / d.seg_len, len = d.ord_hi - d.ord_lo;
-            if ((d.ord_hi - 1) / d.seg_len != seg || runs.size() == static_cast<size_t>(kLeanWideRuns) || len >= 0xffffffffull) return AQE_OK;
+            // one pointer, step 1, segments of at least half a tile
+            if (!is_dense16(d.step, d.flags, d.seg_len) || (d.flags & kFamLinear) || d.ord_hi <= d.ord_lo || d.seg_len >= 0xffffffffull) return AQE_OK;
+            const uint32_t meta = static_cast<uint32_t>(r) | (d.group != 0 ? kLeanMetaGroupB : 0u);
             // row of ordinal o: row0 + seg pitch - shard_lo + (o - seg seg_len)   (device_common.hpp, sweep_family; wraps like it)
-            uint64_t row = d.row0 + seg * d.pitch - sw.shard_lo + d.ord_lo - seg * d.seg_len;
-            if (is_topup) row += static_cast<uint64_t>(base_gap);  // one launch has one column base: the rounds'
-            runs.push_back(Run{row, static_cast<uint32_t>(tiles), static_cast<uint32_t>(len), static_cast<uint32_t>(r) | ((d.group != 0 ? 1u : 0u) << 8)});
-            tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
-            samples += len;
+            auto row_of = [&](uint64_t seg, uint64_t off) {
+                uint64_t row = d.row0 + seg * d.pitch - sw.shard_lo + off;
+                if (is_topup) row += static_cast<uint64_t>(base_gap);  // one launch has one column base: the rounds'
+                return row;
+            };
+            auto plain = [&](uint64_t seg, uint64_t off, uint64_t len) {
+                if (runs.size() == static_cast<size_t>(kLeanWideRuns) || len >= 0xffffffffull) return false;
+                runs.push_back(Run{row_of(seg, off), static_cast<uint32_t>(tiles), static_cast<uint32_t>(len), meta, 0, 0});
+                tiles += (len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
+                samples += len;
+                return true;
+            };
+            const uint64_t seg_lo = d.ord_lo / d.seg_len, seg_hi = (d.ord_hi - 1) / d.seg_len;
+            if (seg_lo == seg_hi) {
+                if (!plain(seg_lo, d.ord_lo - seg_lo * d.seg_len, d.ord_hi - d.ord_lo)) return AQE_OK;
+                continue;
+            }
+            // a window over several blocks: what it cuts off the first and the last block are plain runs, the whole blocks
+            // between them one segmented run
+            uint64_t first_full = seg_lo, end_full = seg_hi + 1;  // [first_full, end_full)
+            const uint64_t off_lo = d.ord_lo - seg_lo * d.seg_len, rows_hi = d.ord_hi - seg_hi * d.seg_len;
+            if (off_lo) { if (!plain(seg_lo, off_lo, d.seg_len - off_lo)) return AQE_OK; ++first_full; }
+            if (rows_hi < d.seg_len) --end_full;
+            if (end_full > first_full) {
+                const uint64_t nseg = end_full - first_full, tps = (d.seg_len + kDenseTileOrdinals - 1) / kDenseTileOrdinals;
+                if (nseg == 1) {
+                    if (!plain(first_full, 0, d.seg_len)) return AQE_OK;
+                } else {
+                    if (runs.size() == static_cast<size_t>(kLeanWideRuns) || nseg * tps >= 0xffffffffull) return AQE_OK;
+                    runs.push_back(Run{row_of(first_full, 0), static_cast<uint32_t>(tiles), static_cast<uint32_t>(d.seg_len), meta | kLeanMetaSeg, d.pitch, static_cast<uint32_t>(tps)});
+                    tiles += nseg * tps;
+                    samples += nseg * d.seg_len;
+                    any_seg = true;
+                }
+            }
+            if (rows_hi < d.seg_len && !plain(seg_hi, 0, rows_hi)) return AQE_OK;
         }
         if (tiles == round_begin[r]) return AQE_OK;  // a slot without tiles: the other forms deal with it
     }
     round_begin[S] = tiles;
-    const uint64_t G = grid;
-    if (tiles == 0 || tiles + G >= 0xffffffffull) return AQE_OK;
-    const uint64_t K = (tiles + G - 1) / G;  // workgroup b owns the tiles [b K, (b + 1) K)
+    const size_t nruns = runs.size();
+    if (any_seg && nruns > static_cast<size_t>(kLeanMaxRuns) / 2) return AQE_OK;  // (a segmented run's geometry takes entry i + 64)
+    if (tiles == 0 || tiles + grid >= 0xffffffffull) return AQE_OK;
+    // one round: dealt out wave by wave, on no more workgroups than one tile per wave needs — every workgroup then has a tile
+    uint64_t G = grid;
+    bool dealt = S == 1;
+    if (dealt) {
+        const uint64_t need = (tiles + kPersistWaves - 1) / kPersistWaves;
+        if (!exact_grid) G = std::min<uint64_t>(G, need);
+        else if (need < G) dealt = false;
+    }
     uint32_t part_first[kMaxPersistRounds] = {0};
-    for (size_t r = 0; r < S; ++r) {
-        const uint64_t first = round_begin[r] / K, last = (round_begin[r + 1] - 1) / K;
-        part_first[r] = static_cast<uint32_t>(first);
-        F.slot_begin[r + 1] = F.slot_begin[r] + static_cast<uint32_t>(last - first + 1);
+    uint64_t K = 0;
+    if (dealt) {
+        F.slot_begin[1] = static_cast<uint32_t>(G);
+    } else {
+        K = (tiles + G - 1) / G;  // workgroup b owns the tiles [b K, (b + 1) K)
+        for (size_t r = 0; r < S; ++r) {
+            const uint64_t first = round_begin[r] / K, last = (round_begin[r + 1] - 1) / K;
+            part_first[r] = static_cast<uint32_t>(first);
+            F.slot_begin[r + 1] = F.slot_begin[r] + static_cast<uint32_t>(last - first + 1);
+        }
     }
     if (F.slot_begin[S] > static_cast<uint32_t>(kLeanMaxSlots)) return AQE_OK;
-    const size_t nruns = runs.size();
     F.wide = nruns > static_cast<size_t>(kLeanMaxRuns);
     const size_t ppart_bytes = sizeof(double) * kVec * F.slot_begin[S];
     // the partial list: every slot is written by its workgroup in every launch, nothing to initialise.  (The run table
@@ -370,14 +417,15 @@ int build_lean_form(aqe_plan* p, bool with_topup_slot, SweepForm& F, uint32_t gr
             const uint32_t r = runs[i].meta & 0xffu;
             F.h_runs.row0[i] = runs[i].row0; F.h_runs.tile_begin[i] = runs[i].tile_begin; F.h_runs.rows[i] = runs[i].rows; F.h_runs.meta[i] = runs[i].meta;
             F.h_runs.slot[i] = F.slot_begin[r] | (part_first[r] << 16);
+            if (runs[i].meta & kLeanMetaSeg) { F.h_runs.row0[i + 64] = runs[i].pitch; F.h_runs.meta[i + 64] = runs[i].tps; }
         }
     }
     F.lean = true;
-    F.tiles_per_wg = static_cast<uint32_t>(K);
+    F.tiles_per_wg = static_cast<uint32_t>(K);  // 0: dealt
     F.slots = static_cast<uint32_t>(S);
     F.ntiles = tiles;
     F.samples = samples;
-    F.grid = grid;
+    F.grid = static_cast<uint32_t>(G);
     F.more_rounds = nrounds < p->rounds.size() ? 1u : 0u;
     F.topup_slot = tslot ? 1u : 0u;
     F.ok = true;
@@ -630,6 +678,16 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
             if (rc2 == AQE_OK) rc2 = build_lean_form(p.get(), false, p->totals_lean, p->grid, R);
             if (rc2 != AQE_OK) return rc2;
         }
+        // ONE round — exact scans (DB.cpp:242-251), strided samples read through a view (DB.cpp:1526-1603), blocks
+        // (DB.cpp:1151-1181) — as a lean launch of its own: the same sweep loop and hand-off as a CLT query's, tiles dealt out
+        // wave by wave.  k_round keeps the rest (pages, strided samples in place) and the stepwise multi-GPU form.
+        // (Below ~1 500 tiles — 12 MB — a launch is all latency and k_round's 4-wave workgroups spread a small sweep over
+        // more compute units than 16-wave ones do: 100 M rows stride 1 %, 977 tiles: 6.8 against 7.8 us.  AQE_SINGLE_LEAN_MIN_TILES moves the line.)
+        static const uint64_t min_tiles = [] { const char* e = std::getenv("AQE_SINGLE_LEAN_MIN_TILES"); return e ? std::strtoull(e, nullptr, 10) : 1536ull; }();
+        if (R == 1 && !p->host.is_random && !p->host.is_perm && !p->host.has_topup && p->grid > 0 && p->rounds[0].ntiles >= ((q->flags & AQE_Q_FORCE_LEAN) ? 1ull : std::max<uint64_t>(min_tiles, 1))) {
+            int rc2 = build_lean_form(p.get(), false, p->single_lean, p->grid, 1, false);
+            if (rc2 != AQE_OK) return rc2;
+        }
     }
     *out = p.release();
     return AQE_OK;
@@ -706,25 +764,26 @@ void fill_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_to
     a.nruns = L.nruns;
     a.ntiles = static_cast<uint32_t>(L.ntiles);
     a.tiles_per_wg = L.tiles_per_wg;
-    a.rounds = L.slots;
     a.has_where = sw.has_where;
     a.wmin = sw.wmin; a.wmax = sw.wmax; a.shift = sw.shift;
-    for (uint32_t r = 0; r <= L.slots; ++r) a.slot_begin[r] = L.slot_begin[r];
     a.partials = L.d_ppart;
     a.counter = p->counter;
-    a.out_totals = out_totals;
-    a.state = p->d_state;
-    a.fold = fold_params(p, false);
-    a.fin = finalize_params(p);
-    a.result = p->d_result;
-    a.result_seq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p->d_result) + (reinterpret_cast<const volatile char*>(p->h_seq) - reinterpret_cast<const char*>(p->h_result)));
     a.epoch = epoch;
-    a.finalize_here = 1u;
-    a.topup_gate = p->host.has_topup ? 1u : 0u;
-    a.more_rounds = L.more_rounds;
-    a.topup_slot = totals_only ? 0u : L.topup_slot;
-    a.want_ticks = (p->want_ticks && !totals_only) ? 1u : 0u;
-    a.totals_only = totals_only ? 1u : 0u;
+    LeanTail& t = a.tail;
+    t.rounds = L.slots;
+    for (uint32_t r = 0; r <= L.slots; ++r) t.slot_begin[r] = L.slot_begin[r];
+    t.out_totals = out_totals;
+    t.state = p->d_state;
+    t.fold = fold_params(p, false);
+    t.fin = finalize_params(p);
+    t.result = p->d_result;
+    t.result_seq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p->d_result) + (reinterpret_cast<const volatile char*>(p->h_seq) - reinterpret_cast<const char*>(p->h_result)));
+    t.finalize_here = 1u;
+    t.topup_gate = p->host.has_topup ? 1u : 0u;
+    t.more_rounds = L.more_rounds;
+    t.topup_slot = totals_only ? 0u : L.topup_slot;
+    t.want_ticks = (p->want_ticks && !totals_only) ? 1u : 0u;
+    t.totals_only = totals_only ? 1u : 0u;
 }
 
 int launch_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_totals, hipStream_t s) {
@@ -827,6 +886,9 @@ int enqueue_all(aqe_plan* p, hipStream_t s, bool timed) {
             p->last_exec = 0;
             HIPCHK(c, hipGraphLaunch(p->round_graph, s));
             topup_done = true;
+        } else if (p->single_lean.ok && !(p->q.flags & AQE_Q_NO_LEAN) && !c->d_stamps) {  // a single-round plan of runs / blocks (no top-up)
+            int rc = launch_lean(p, p->single_lean, false, nullptr, s);
+            if (rc != AQE_OK) return rc;
         } else {
             plain_epoch = c->epoch++;  // launch by launch: the one that finishes the query writes the check word
             for (uint32_t i = 0; i < p->rounds.size(); ++i) {
@@ -1124,7 +1186,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
             ltable.resize(n);
             for (size_t i = 0; i < n; ++i) {
                 fill_lean(b->plans[i], lf[i], kind == 1, kind == 1 ? dev_totals + i * row_stride : nullptr, 0, ltable[i]);
-                ltable[i].want_ticks = 0;
+                ltable[i].tail.want_ticks = 0;
                 m.samples += lf[i].samples;
             }
             m.forms = std::move(lf);

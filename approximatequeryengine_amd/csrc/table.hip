@@ -311,80 +311,160 @@ class FillPool {
     bool stop_ = false;
 };
 
-int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64_t shard_lo, uint64_t n_global,
-                    uint32_t flags) {
+double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void free_ring(aqe_ctx* c) {
+    for (int b = 0; b < kStageRing; ++b) {
+        if (c->ring.buf[b]) (void)hipHostFree(c->ring.buf[b]);
+        if (c->ring.done[b]) (void)hipEventDestroy(c->ring.done[b]);
+        c->ring.buf[b] = nullptr;
+        c->ring.done[b] = nullptr;
+    }
+    c->ring.bytes_each = 0;
+}
+
+int ensure_ring(aqe_ctx* c, size_t bytes_each) {
+    if (c->ring.bytes_each >= bytes_each) return AQE_OK;
+    free_ring(c);
+    for (int b = 0; b < kStageRing; ++b) {
+        if (hipHostMalloc(&c->ring.buf[b], bytes_each, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ring.done[b], hipEventDisableTiming) != hipSuccess) {
+            free_ring(c);
+            return fail(c, AQE_ERR_HIP, "staging: cannot allocate pinned bounce buffers");
+        }
+    }
+    c->ring.bytes_each = bytes_each;
+    return AQE_OK;
+}
+
+// Where the rows of a staging come from: host memory (aqe_stage_records) or a file in the reference's format, read with
+// pread straight into the pinned ring — the kernel copies out of the page cache without a page fault per 4 KB page, which
+// is what capped a copy out of a fresh mmap at 11 GB/s (a fault per page against ~0.1 us of copying).
+struct RowSource {
+    const aqe_record* rows = nullptr;  // memory
+    int fd = -1;                       // else: file, row i of the staging at byte file_off + 32 i
+    uint64_t file_off = 0;
+};
+
+bool read_fully(int fd, void* dst, size_t bytes, uint64_t off) {
+    char* p = static_cast<char*>(dst);
+    while (bytes) {
+        const ssize_t got = pread(fd, p, bytes, static_cast<off_t>(off));
+        if (got <= 0) return false;
+        p += got; off += static_cast<uint64_t>(got); bytes -= static_cast<size_t>(got);
+    }
+    return true;
+}
+
+int stage_rows(aqe_ctx* c, const RowSource& src, uint64_t n_local, uint64_t shard_lo, uint64_t n_global, uint32_t flags, int64_t id0) {
+    const auto t_all = std::chrono::steady_clock::now();
+    aqe_stage_stats st{};
     if (shard_lo + n_local > n_global) return fail(c, AQE_ERR_INVALID, "shard exceeds the table");
-    if (n_local && !rows) return fail(c, AQE_ERR_INVALID, "null rows");
     const bool keep = flags & AQE_STAGE_KEEP_AOS;
+    auto t0 = std::chrono::steady_clock::now();
     int rc = alloc_table(c, n_local, keep);
     if (rc != AQE_OK) return rc;
+    st.device_alloc_ms = ms_since(t0);
     c->n_global = n_global;
     c->shard_lo = shard_lo;
     c->n_local = n_local;
     c->staged = true;
-    c->shift = shift_of_rows(rows, n_local);  // shards other than the first are given the table's value (aqe_set_shift)
-    c->head_cv = cv_of_rows(rows, n_local);
+    c->stage_stats = st;
     if (n_local == 0) return AQE_OK;
-    // Double-buffered pinned bounce: the CPU fills buffer b while the DMA engine drains buffer b^1.
+    // A ring of pinned buffers: host threads fill buffer b while the copy engine drains the ones before it.
     // Without KEEP_AOS only the amount column crosses PCIe (8 of every 32 bytes).
     const size_t row_bytes = keep ? sizeof(aqe_record) : sizeof(double);
-    struct Bounce {  // two pinned buffers + their "drained" events, released on every exit path
-        void* pinned[2] = {nullptr, nullptr};
-        hipEvent_t done[2] = {nullptr, nullptr};
-        ~Bounce() {
-            for (int b = 0; b < 2; ++b) {
-                if (pinned[b]) (void)hipHostFree(pinned[b]);
-                if (done[b]) (void)hipEventDestroy(done[b]);
-            }
-        }
-    } bounce;
-    void** pinned = bounce.pinned;
-    hipEvent_t* done = bounce.done;
-    for (int b = 0; b < 2; ++b) {
-        if (hipHostMalloc(&pinned[b], std::min<uint64_t>(kStageChunkRows, n_local) * row_bytes, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) {
-            free_table(c);
-            return fail(c, AQE_ERR_HIP, "staging: cannot allocate pinned bounce buffers");
-        }
-    }
+    const uint64_t chunk_rows = std::min<uint64_t>(kStageChunkRows, n_local);
+    t0 = std::chrono::steady_clock::now();
+    const bool had_ring = c->ring.bytes_each >= chunk_rows * row_bytes;
+    rc = ensure_ring(c, chunk_rows * row_bytes);
+    if (rc != AQE_OK) { free_table(c); return rc; }
+    st.pinned_alloc_ms = had_ring ? 0.0 : ms_since(t0);
     int status = AQE_OK;
-    std::atomic<bool> dense_ids{true};
-    const int64_t id0 = rows[0].id;
+    std::atomic<bool> dense_ids{true}, io_ok{true};
     const unsigned hw = std::thread::hardware_concurrency();
     FillPool pool(n_local < (1u << 18) ? 1u : std::max(1u, std::min(16u, hw ? hw : 4u)));
-    for (uint64_t off = 0, k = 0; off < n_local && status == AQE_OK; off += kStageChunkRows, ++k) {
-        const int b = static_cast<int>(k & 1);
-        const uint64_t m = std::min<uint64_t>(kStageChunkRows, n_local - off);
-        if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) { status = fail(c, AQE_ERR_HIP, "event sync"); break; }
+    st.fill_threads = n_local < (1u << 18) ? 1u : std::max(1u, std::min(16u, hw ? hw : 4u));
+    for (uint64_t off = 0, k = 0; off < n_local && status == AQE_OK; off += chunk_rows, ++k) {
+        const int b = static_cast<int>(k % kStageRing);
+        const uint64_t m = std::min<uint64_t>(chunk_rows, n_local - off);
+        if (k >= static_cast<uint64_t>(kStageRing)) {
+            t0 = std::chrono::steady_clock::now();
+            if (hipEventSynchronize(c->ring.done[b]) != hipSuccess) { status = fail(c, AQE_ERR_HIP, "event sync"); break; }
+            st.wait_ms += ms_since(t0);
+        }
         hipError_t e;
-        void* const dst_buf = pinned[b];
+        void* const dst_buf = c->ring.buf[b];
+        t0 = std::chrono::steady_clock::now();
         pool.run([&, dst_buf](unsigned part, unsigned parts) {  // rows [lo, hi) of the chunk: fill + dense-id check
             const uint64_t lo = m * part / parts, hi = m * (part + 1) / parts;
             bool dense = true;
-            for (uint64_t i = lo; i < hi; ++i) dense = dense && rows[off + i].id == id0 + static_cast<int64_t>(off + i);
-            if (!dense) dense_ids.store(false, std::memory_order_relaxed);
-            if (keep) {
-                std::memcpy(static_cast<aqe_record*>(dst_buf) + lo, rows + off + lo, (hi - lo) * sizeof(aqe_record));
+            if (src.rows) {
+                const aqe_record* rows = src.rows;
+                for (uint64_t i = lo; i < hi; ++i) dense = dense && rows[off + i].id == id0 + static_cast<int64_t>(off + i);
+                if (keep) {
+                    std::memcpy(static_cast<aqe_record*>(dst_buf) + lo, rows + off + lo, (hi - lo) * sizeof(aqe_record));
+                } else {
+                    double* dst = static_cast<double*>(dst_buf);
+                    for (uint64_t i = lo; i < hi; ++i) dst[i] = rows[off + i].amount;
+                }
+            } else if (keep) {
+                aqe_record* dst = static_cast<aqe_record*>(dst_buf) + lo;
+                if (!read_fully(src.fd, dst, (hi - lo) * sizeof(aqe_record), src.file_off + (off + lo) * sizeof(aqe_record))) { io_ok.store(false); return; }
+                for (uint64_t i = lo; i < hi; ++i) dense = dense && dst[i - lo].id == id0 + static_cast<int64_t>(off + i);
             } else {
+                constexpr uint64_t kPiece = 4096;  // rows: 128 KiB of file through a cache-resident buffer, the amounts picked out of it
+                std::vector<aqe_record> tmp(std::min<uint64_t>(kPiece, hi - lo));
                 double* dst = static_cast<double*>(dst_buf);
-                for (uint64_t i = lo; i < hi; ++i) dst[i] = rows[off + i].amount;
+                for (uint64_t i = lo; i < hi; i += kPiece) {
+                    const uint64_t cnt = std::min<uint64_t>(kPiece, hi - i);
+                    if (!read_fully(src.fd, tmp.data(), cnt * sizeof(aqe_record), src.file_off + (off + i) * sizeof(aqe_record))) { io_ok.store(false); return; }
+                    for (uint64_t j = 0; j < cnt; ++j) {
+                        dense = dense && tmp[j].id == id0 + static_cast<int64_t>(off + i + j);
+                        dst[i + j] = tmp[j].amount;
+                    }
+                }
             }
+            if (!dense) dense_ids.store(false, std::memory_order_relaxed);
         });
+        st.fill_ms += ms_since(t0);
+        if (!io_ok.load()) { status = fail(c, AQE_ERR_IO, "staging: short read from the database file"); break; }
         if (keep) {
-            e = hipMemcpyAsync(c->aos + off, pinned[b], m * sizeof(aqe_record), hipMemcpyHostToDevice, c->stream);
+            e = hipMemcpyAsync(c->aos + off, dst_buf, m * sizeof(aqe_record), hipMemcpyHostToDevice, c->stream);
             if (e == hipSuccess) e = launch_split_amount(c->aos + off, c->amount + off, m, c->stream);
         } else {
-            e = hipMemcpyAsync(c->amount + off, pinned[b], m * sizeof(double), hipMemcpyHostToDevice, c->stream);
+            e = hipMemcpyAsync(c->amount + off, dst_buf, m * sizeof(double), hipMemcpyHostToDevice, c->stream);
         }
-        if (e == hipSuccess) e = hipEventRecord(done[b], c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ring.done[b], c->stream);
         if (e != hipSuccess) status = fail(c, AQE_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
+        st.chunks++;
     }
+    t0 = std::chrono::steady_clock::now();
     hipError_t e = hipStreamSynchronize(c->stream);
+    st.wait_ms += ms_since(t0);
     if (e != hipSuccess && status == AQE_OK) status = fail(c, AQE_ERR_HIP, std::string("staging sync: ") + hipGetErrorString(e));
     if (status != AQE_OK) { free_table(c); return status; }
     c->ids_dense = dense_ids.load();
     c->first_id = id0 - static_cast<int64_t>(shard_lo);  // id of global row 0 when the ids are dense
+    st.host_bytes = n_local * sizeof(aqe_record);
+    st.link_bytes = n_local * row_bytes;
+    st.total_ms = ms_since(t_all);
+    c->stage_stats = st;
     return status;
+}
+
+int stage_from_host(aqe_ctx* c, const aqe_record* rows, uint64_t n_local, uint64_t shard_lo, uint64_t n_global,
+                    uint32_t flags) {
+    if (n_local && !rows) return fail(c, AQE_ERR_INVALID, "null rows");
+    RowSource src;
+    src.rows = rows;
+    int rc = stage_rows(c, src, n_local, shard_lo, n_global, flags, n_local ? rows[0].id : 0);
+    if (rc != AQE_OK) return rc;
+    c->shift = shift_of_rows(rows, n_local);  // shards other than the first are given the table's value (aqe_set_shift)
+    c->head_cv = cv_of_rows(rows, n_local);
+    return AQE_OK;
 }
 
 struct MappedFile {
@@ -462,6 +542,7 @@ void aqe_destroy(aqe_ctx* c) {
     }
     c->scratch_pool.clear();
     free_table(c);
+    free_ring(c);
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->grp_partial) (void)hipFree(c->grp_partial);
     if (c->grp_out_host) (void)hipHostFree(c->grp_out_host);
@@ -474,6 +555,12 @@ int aqe_stage_records(aqe_ctx* c, const void* aos32, uint64_t n_local, uint64_t 
     if (!c) return AQE_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     return stage_from_host(c, static_cast<const aqe_record*>(aos32), n_local, shard_lo, n_global, flags);
+}
+
+int aqe_last_stage_stats(const aqe_ctx* c, aqe_stage_stats* out) {
+    if (!c || !out) return AQE_ERR_INVALID;
+    *out = c->stage_stats;
+    return AQE_OK;
 }
 
 int aqe_file_rows(const char* path, uint64_t* n_rows) {
@@ -498,10 +585,13 @@ int aqe_stage_file(aqe_ctx* c, const char* path, uint64_t shard_lo, uint64_t n_l
     if (shard_lo > count) return fail(c, AQE_ERR_INVALID, "shard_lo beyond the end of the file");
     if (n_local == 0) n_local = count - shard_lo;
     if (shard_lo + n_local > count) return fail(c, AQE_ERR_INVALID, "shard exceeds the file");
-    (void)madvise(mf.base, mf.bytes, MADV_SEQUENTIAL);
+    // (the header and the table's head are read through the mapping; the rows themselves with pread into the pinned ring)
     const aqe_record* rows = reinterpret_cast<const aqe_record*>(static_cast<const char*>(mf.base) + 24);
-    rc = stage_from_host(c, rows + shard_lo, n_local, shard_lo, count, flags);
-    if (rc == AQE_OK && count) {  // from the table's head: identical on every shard
+    RowSource src;
+    src.fd = mf.fd;
+    src.file_off = 24 + shard_lo * sizeof(aqe_record);
+    rc = stage_rows(c, src, n_local, shard_lo, count, flags, n_local ? rows[shard_lo].id : 0);
+    if (rc == AQE_OK) {  // from the table's head: identical on every shard
         c->shift = shift_of_rows(rows, count);
         c->head_cv = cv_of_rows(rows, count);
     }

@@ -274,6 +274,12 @@ class Engine:
         self._chk(nat.lib().aqe_stage_file(self._h, str(path).encode(), shard_lo, n_local,
                                            nat.STAGE_KEEP_AOS if keep_aos else 0))
 
+    def stage_stats(self) -> nat.StageStats:
+        """Where the time of the most recent stage_records / stage_file went (aqe_last_stage_stats)."""
+        st = nat.StageStats()
+        self._chk(nat.lib().aqe_last_stage_stats(self._h, C.byref(st)))
+        return st
+
     def save_file(self, path):
         self._chk(nat.lib().aqe_save_file(self._h, str(path).encode()))
 

@@ -224,21 +224,41 @@ def cpu_baseline(rows_per_gpu: int, e: float, sample_rows: int) -> dict:
 # ---------------------------------------------------------------------------------------------------------------
 # Per-configuration roofline lines (one query in flight, per-launch HIP events attached to the dispatch)
 # ---------------------------------------------------------------------------------------------------------------
+# Every measured case runs its timed launches on a stream of its OWN (nothing else ever runs there), and says how many
+# launches that were: tools/cases_from_trace.py splits a `rocprofv3 --kernel-trace` of this very command by stream and
+# writes profiles/round3_configs_cases.csv — one row per (case, kernel, grid) from which every `frac` here can be recomputed.
+CASES = []
+
+
+def fresh_stream():
+    import torch
+    return torch.cuda.Stream()
+
+
+def log_case(name, kernel, launches, queries, alg_bytes, event_us):
+    CASES.append({"case": name, "kernel": kernel, "launches": int(launches), "queries": int(queries), "algorithmic_bytes_per_query": float(alg_bytes),
+                  "event_us_per_query": float(event_us)})
+
+
 def measure_config(eng, st, name, q, reps=20, note=None):
     import statistics
+    import torch
     from approximatequeryengine_amd import _native as nat
     plan = eng.plan(q)
     try:
         for _ in range(3):
             plan.enqueue_all(st)
             r = plan.fetch(st)
+        torch.cuda.synchronize()
+        own = fresh_stream()
         plan.set_profiling(True)
         per_query, lat = [], []
         for _ in range(reps):
-            plan.enqueue_all(st)
-            r = plan.fetch(st)
+            plan.enqueue_all(own.cuda_stream)
+            r = plan.fetch(own.cuda_stream)
             per_query.append(plan.launch_ms())
         plan.set_profiling(False)
+        torch.cuda.synchronize()
         for _ in range(reps):  # closed loop without the profiling events (the fetch then polls the pinned result)
             t0 = time.perf_counter()
             plan.enqueue_all(st)
@@ -255,6 +275,7 @@ def measure_config(eng, st, name, q, reps=20, note=None):
                "closed_loop_us_p50": 1e6 * statistics.median(lat)}
         if note:
             out["note"] = note
+        log_case(name, out["kernel"], sum(len(x) for x in per_query), reps, nbytes, us)
         return out
     finally:
         plan.close()
@@ -271,19 +292,24 @@ def measure_batch(eng, Batch, st, name, queries, reps=20):
         for _ in range(3):
             b.enqueue_all(st)
             rs = b.fetch()
+        import torch
+        torch.cuda.synchronize()
+        own = fresh_stream()
         b.set_profiling(True)
         ms, lat = [], []
         for _ in range(reps):
             t0 = time.perf_counter()
-            b.enqueue_all(st)
+            b.enqueue_all(own.cuda_stream)
             rs = b.fetch()
             lat.append(time.perf_counter() - t0)
             m, swept, wgs = b.launch_info()
             ms.append(m)
         b.set_profiling(False)
+        torch.cuda.synchronize()
         us = 1e3 * statistics.median(ms)
         nbytes = 8.0 * sum(r.visited for r in rs)
         wall = statistics.median(lat)
+        log_case(name, nat.KERNEL_NAMES.get(plans[0].last_kernel(), "?"), reps, reps, nbytes, us)
         return {"config": name, "kernel": nat.KERNEL_NAMES.get(plans[0].last_kernel(), "?"), "queries_per_launch": len(queries),
                 "samples": int(sum(r.visited for r in rs)), "kernel_us": us,
                 "kernel_us_min": 1e3 * min(ms), "workgroups": int(wgs), "algorithmic_bytes": nbytes,
@@ -359,34 +385,43 @@ def run_configs(eng, nat, make_query, st, max_rows, Batch=None):
 
 
 def cold_numbers(Engine, nat, make_query, rows: int, e: float) -> dict:
-    """Cold path: a table in the reference's file format (page cache) -> HBM, then the first CLT query
-    (which builds the stride-major views of the column), then the same query warm."""
+    """Cold path (SURVEY §8d, config 3's staging leg): a table in the reference's file format (page cache) -> HBM, then the
+    first CLT query (which builds the stride-major views of the column), then the same query warm.  Per staging: where the
+    time went (aqe_last_stage_stats) — device allocation, pinning the ring (first staging of a context only), host threads
+    filling pinned buffers (pread out of the page cache), the host waiting for the copy engine."""
     import tempfile
     pct = e_to_pct(e)
     q = make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, max_error_percent=e, clt_round0=CLT_ROUND0, clt_growth=CLT_GROWTH)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "sales.db")
+        t0 = time.perf_counter()
         with Engine(0) as g:
             g.generate_synthetic(rows, keep_aos=True)
             g.save_file(path)
         size = os.path.getsize(path)
-        out = {"rows": rows, "file_bytes": size}
+        out = {"rows": rows, "file_bytes": size, "write_file_s": time.perf_counter() - t0}
         for keep in (False, True):
             with Engine(0) as eng:
                 t0 = time.perf_counter()
                 eng.stage_file(path, keep_aos=keep)
                 t1 = time.perf_counter()
+                st1 = eng.stage_stats().as_dict()
                 r = eng.reduce(q)  # plan + both stride-major views + the query
                 t2 = time.perf_counter()
                 r = eng.reduce(q)
                 t3 = time.perf_counter()
                 info = eng.info()
+                eng.stage_file(path, keep_aos=keep)  # the same context again: the pinned ring is there already
+                t4 = time.perf_counter()
+                st2 = eng.stage_stats().as_dict()
                 out["amounts_only" if not keep else "rows_kept"] = {
-                    "stage_file_ms": 1e3 * (t1 - t0), "file_GBps": size / (t1 - t0) / 1e9,
+                    "stage_file_ms": 1e3 * (t1 - t0), "file_GBps": size / (t1 - t0) / 1e9, "stages": st1,
+                    "restage_ms (pinned ring kept)": st2["total_ms"], "restage_file_GBps": size / (st2["total_ms"] * 1e-3) / 1e9, "restage_stages": st2,
                     "first_query_ms (plan + view build + sweep)": 1e3 * (t2 - t1), "second_query_ms": 1e3 * (t3 - t2),
                     "hbm_bytes": int(info.hbm_bytes), "avg": r.value}
         out["note"] = ("file written by aqe_save_file in the reference's format (24-byte header + 32-byte rows, custom_bplus_db.cpp:665-711), read back from "
-                       "the page cache through mmap + pinned double buffers; replaces load_from_file + collect_leaf_records (DB.cpp:685-735)")
+                       "the page cache with pread into a ring of pinned buffers (16 host threads), hipMemcpyAsync from there; replaces load_from_file + "
+                       "collect_leaf_records (DB.cpp:685-735)")
     return out
 
 
@@ -454,6 +489,9 @@ def compact_line(rep: dict) -> dict:
         sq = rep["single_query"]
         line["single_query"] = {"kernel": sq["kernel"], "avg_launch_us": _r(sq["avg_launch_us"], 2), "frac": _r(sq["frac"], 4),
                                 "closed_loop_us_p50": _r(sq["closed_loop_latency_us"]["p50"], 2)}
+        ch = sq.get("closed_loop_c_host")
+        if isinstance(ch, list) and ch:
+            line["single_query"]["closed_loop_c_host_us_p50"] = _r(ch[0].get("p50_us"), 2)
     cb = rep.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: (_r(cb.get(k), 5) if k == "value" else cb.get(k)) for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}
@@ -482,6 +520,27 @@ def write_report(rep: dict):
         elif isinstance(v, dict):
             print(json.dumps({k: v}), file=sys.stderr)
     sys.stderr.flush()
+
+
+def c_host_closed_loop(rows: int, reps: int = 300):
+    """The same closed loop from a plain-C host (tests/c_host/closed_loop.c: no Python, no ctypes): built with gcc here,
+    run as a child process while this one keeps its table (two contexts on one GPU)."""
+    import subprocess
+    import tempfile
+    from approximatequeryengine_amd.build import LIB
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            exe = os.path.join(td, "closed_loop")
+            subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-I", str(ROOT / "include"), str(ROOT / "tests" / "c_host" / "closed_loop.c"), "-o", exe,
+                                   "-L", str(LIB.parent), "-laqe_hip", f"-Wl,-rpath,{LIB.parent}", "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            env = dict(os.environ)
+            env["LD_LIBRARY_PATH"] = os.pathsep.join(["/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+            out = subprocess.run([exe, str(rows), str(reps)], env=env, capture_output=True, text=True, timeout=120)
+            if out.returncode != 0:
+                return {"error": (out.stderr or out.stdout)[-300:]}
+            return [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    except Exception as ex:
+        return {"error": repr(ex)}
 
 
 def main():
@@ -608,6 +667,10 @@ def main():
         # ---- roofline of the dominant kernel (k_sweep_lean_multi): ONE batch in flight, the launch's own begin/end
         #      timestamps (event pair attached to the dispatch), before the throughput loop ----
         prof_steps = 100
+        own_h = fresh_stream()
+        if not use_dist:
+            def one():  # (the timed launches on a stream of their own: see CASES)
+                natives[0].enqueue_all(own_h.cuda_stream)
         natives[0].set_profiling(True)
         ms_sum, ms_min, swept, wgs = 0.0, 1e9, 0, 0
         for _ in range(prof_steps):
@@ -623,6 +686,10 @@ def main():
         avg_launch_ms = ms_sum / prof_steps
         batch_kernel = nat.KERNEL_NAMES.get(plan_sets[0][0].last_kernel(), "?")  # k_sweep_lean_multi when every plan of the batch qualifies
         bytes_per_launch = 8.0 * swept
+        torch.cuda.synchronize()
+        if not use_dist:
+            log_case(f"HEADLINE 10M: batch of {B} CLT e={e}% queries in ONE launch (executed bytes; see roofline for what is priced)", batch_kernel, prof_steps, prof_steps,
+                     bytes_per_launch, 1e3 * avg_launch_ms)
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
 
         # ---- the same batch with the XCD alignment of the groups turned off (AQE_MULTI_LAYOUT=packed): the layout in which
@@ -655,10 +722,12 @@ def main():
         # ---- a single query on the whole chip (k_sweep_lean), one in flight: launch time and closed loop ----
         single = None
         if not use_dist:
+            own_s = fresh_stream()
+            torch.cuda.synchronize()
             plan_one.set_profiling(True)
             acc = []
             for _ in range(prof_steps):
-                plan_one.enqueue_all(st)
+                plan_one.enqueue_all(own_s.cuda_stream)
                 torch.cuda.synchronize()
                 acc.append(sum(plan_one.launch_ms()))
             plan_one.set_profiling(False)
@@ -675,6 +744,9 @@ def main():
                       "achieved_GBps": 8.0 * r_one.visited / (s_us * 1e-6) / 1e9, "frac": 8.0 * r_one.visited / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                       "closed_loop_latency_us": {"p50": 1e6 * lat[len(lat) // 2], "min": 1e6 * lat[0]},
                       "aggregates_per_sec_one_in_flight": 1.0 / lat[len(lat) // 2]}
+            log_case("10M: the bench query alone (CLT AVG e=0.01%, T=4)", single["kernel"], prof_steps, prof_steps, 8.0 * r_one.visited, s_us)
+            if extras:
+                single["closed_loop_c_host"] = c_host_closed_loop(rows)
 
         # ---- the other reading of "--e 0.01" (SURVEY §8d config 2): the FRACTION 0.01 = 1 percent.  That query
         #      converges after the first round, should_stop fires, and the reference's top-up (custom_bplus_db.cpp:
@@ -860,6 +932,8 @@ def main():
             try:
                 eng.release_table()
                 rep["cold"] = cold_numbers(Engine, nat, make_query, rows, e)
+                if args.max_config_rows >= 100_000_000:  # config 3's staging leg at size: a 3.2 GB file
+                    rep["cold_100M"] = cold_numbers(Engine, nat, make_query, 100_000_000, e)
             except Exception as ex:
                 rep["cold"] = {"error": repr(ex)}
             if not args.no_cpu_baseline:
@@ -869,6 +943,7 @@ def main():
                     rep["cpu_baseline_all"] = cb
                 except Exception as ex:  # the bench line must still print
                     rep["cpu_baseline"] = {"value": None, "unit": "aggregates/sec", "cores": 0, "kind": "port", "sample": f"failed: {ex!r}"}
+        rep["cases"] = CASES
         write_report(rep)
         print(json.dumps(compact_line(rep)), flush=True)
 

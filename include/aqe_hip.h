@@ -139,6 +139,9 @@ typedef struct aqe_query {
                              plan would qualify for the lean launch that judges every round once, at the end (k_sweep_lean:
                              small sweeps, every family a plain run of rows).  Same decision rule on the same partial
                              moments; the sums are taken in another order */
+#define AQE_Q_FORCE_LEAN 64u /* a single-round sampler (exact scan, strided sample through a view, blocks) takes the lean
+                               launch at any size; by default only sweeps of >= 1536 tiles (12 MB) do, smaller ones stay
+                               with k_round.  Same rows, same answer */
 #define AQE_Q_FORCE_PERSIST 4u /* take the single-launch form whenever the plan has one, also where the query is
                                   predicted to stop early (by default such plans are launched round by round) */
 
@@ -216,6 +219,20 @@ AQE_API int aqe_stage_records(aqe_ctx* ctx, const void* aos32, uint64_t n_local,
 AQE_API int aqe_stage_file(aqe_ctx* ctx, const char* path, uint64_t shard_lo, uint64_t n_local,
                            uint32_t flags);
 AQE_API int aqe_file_rows(const char* path, uint64_t* n_rows); /* header only */
+/* Where the time of the most recent aqe_stage_records / aqe_stage_file of this context went (wall clock, milliseconds).
+ * Rows travel host -> ring of pinned buffers (filled by a pool of host threads: memcpy from host rows, pread from a file)
+ * -> hipMemcpyAsync -> HBM; the ring stays with the context, so only the first staging pays pinned_alloc_ms. */
+typedef struct aqe_stage_stats {
+    double total_ms;         /* the whole call                                                          */
+    double device_alloc_ms;  /* hipMalloc of the column (and of the rows with AQE_STAGE_KEEP_AOS)       */
+    double pinned_alloc_ms;  /* allocating the pinned ring (0 when the context already had it)          */
+    double fill_ms;          /* host threads filling pinned buffers (wall time, summed over chunks)     */
+    double wait_ms;          /* the host waiting for the copy engine: a buffer still draining, the final drain */
+    uint64_t host_bytes;     /* bytes read from host rows / the file                                    */
+    uint64_t link_bytes;     /* bytes sent over PCIe                                                    */
+    uint32_t chunks, fill_threads;
+} aqe_stage_stats;
+AQE_API int aqe_last_stage_stats(const aqe_ctx* ctx, aqe_stage_stats* out);
 /* Writes the staged shard back in the reference's format (save_to_file, DB.cpp:665-683). */
 AQE_API int aqe_save_file(aqe_ctx* ctx, const char* path);
 /* Synthetic `sales` shard generated in HBM: id=i+1, amount=1+999*u(splitmix64(seed,i)). */

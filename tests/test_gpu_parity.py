@@ -108,7 +108,7 @@ def test_golden_calls_reduce_and_gather(nat, oracle, golden, table, engines, n):
             assert rel(res.sumsq, call["fsumsq"]) <= SUM_TOL, call
         # the same call through the other kernels (a multi-round plan takes the lean launch by default: the monitor-wave
         # kernel, and one launch per round): same counts, sums to rounding
-        for other in (nat.Q_NO_LEAN, nat.Q_NO_PERSIST):
+        for other in (nat.Q_NO_LEAN, nat.Q_NO_PERSIST, nat.Q_FORCE_LEAN):  # (FORCE_LEAN: single-round samplers through k_sweep_lean at any size)
             q.flags = other
             alt = eng.reduce(q)
             assert (alt.visited, alt.n, alt.rounds, alt.converged, alt.topup) == (res.visited, res.n, res.rounds, res.converged, res.topup), call
@@ -192,6 +192,17 @@ def test_exact_scans(nat, oracle, golden, table, engines, n):
     for w in T["exact"]["where"]:
         rw = eng.reduce(make_query(nat.M_EXACT, 100.0, where=tuple(w["range"])))
         assert (rel(rw.value, w["sum"]) <= SUM_TOL) if w["sum"] else rw.value == 0.0
+    # the same scans as lean launches (what scans of 12 MB and more take by themselves), and over a row window with odd ends
+    rl = eng.reduce(make_query(nat.M_EXACT, 100.0, agg=nat.SUM, flags=nat.Q_FORCE_LEAN))
+    assert (rl.n, rl.visited) == (n, n) and rel(rl.value, T["exact"]["sum_amount"]) <= SUM_TOL and rel(rl.sumsq, r.sumsq) <= SUM_TOL
+    for w in T["exact"]["where"]:
+        rw = eng.reduce(make_query(nat.M_EXACT, 100.0, where=tuple(w["range"]), flags=nat.Q_FORCE_LEAN))
+        assert (rel(rw.value, w["sum"]) <= SUM_TOL) if w["sum"] else rw.value == 0.0
+    lo, hi = 1 + n // 7, n - n // 5 - 1
+    a = eng.reduce(make_query(nat.M_EXACT, 100.0, rows=(lo, hi)))
+    b = eng.reduce(make_query(nat.M_EXACT, 100.0, rows=(lo, hi), flags=nat.Q_FORCE_LEAN))
+    want = oracle.moments_idx(table(n), np.arange(lo, hi, dtype=np.uint64))
+    assert a.n == b.n == want.n == hi - lo and rel(a.sum, want.sum) <= SUM_TOL and rel(b.sum, want.sum) <= SUM_TOL
 
 
 CLT_CASES = [
@@ -501,7 +512,13 @@ def test_randomised_sampler_parameters_against_the_oracle(nat, oracle):
                     lo = float(rng.uniform(1.0, 600.0))
                     q.has_where, q.where_min, q.where_max = 1, lo, lo + float(rng.uniform(0.0, 500.0))
                     _check_against_oracle(nat, oracle, eng, rows, q, idx, where=(q.where_min, q.where_max))
+                    # the same sample through the lean launch (single-round samplers take it from 12 MB on by themselves:
+                    # runs, rows of blocks whose first and last block the window cuts, odd lengths, tiles dealt out wave by wave)
+                    q.flags |= nat.Q_FORCE_LEAN
+                    _check_against_oracle(nat, oracle, eng, rows, q, idx, where=(q.where_min, q.where_max))
                     q.has_where = 0
+                    _check_against_oracle(nat, oracle, eng, rows, q, idx)
+                    q.flags &= ~nat.Q_FORCE_LEAN
                 got = eng.gather(q)
                 assert np.array_equal(np.sort(got["id"] - 1), np.sort(np.asarray(idx, dtype=np.int64))), (n, call)
                 cases += 1
