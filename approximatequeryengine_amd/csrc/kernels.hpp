@@ -230,7 +230,8 @@ struct LeanWideRuns {
 // parks it in LDS, so that after the last ticket nothing is fetched from the descriptor any more: each such fetch was a
 // dependent round trip on the query's critical path (profiles/round2_lean_timeline.txt: 5 us of tail behind a 3.5 us sweep).
 struct LeanTail {
-    uint32_t rounds, finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only, pad0;  // as in PersistLaunch
+    uint32_t rounds, finalize_here, topup_gate, more_rounds, topup_slot, want_ticks, totals_only;  // as in PersistLaunch
+    uint32_t keep_state;       // 1: a launch that reads the query state is already enqueued behind this one (the top-up, device-gated)
     uint32_t slot_begin[kMaxPersistRounds + 1];  // round r owns the slots [slot_begin[r], slot_begin[r + 1]) of the flat list
     uint32_t pad1;
     FoldParams fold;

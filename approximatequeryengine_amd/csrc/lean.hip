@@ -150,7 +150,7 @@ __device__ __forceinline__ void lean_tile(const double* base, unsigned rem, cons
 // Wave 0 of the folding workgroup, lane q holding the moments through round q (or a slot's own total where the form
 // asks for that): the decision and the result.  The rules and what follows them are the monitor's (persist.hip,
 // monitor_fold), evaluated once, for every round at the same time.  T: the launch's tail, in LDS.
-__device__ __forceinline__ void lean_judge(const LeanTail& T, const double (&tot)[7], unsigned lane, unsigned long long t0, unsigned long long epoch) {
+__device__ __forceinline__ void lean_judge(const LeanTail& T, const double (&tot)[7], unsigned lane, unsigned long long t0, unsigned long long epoch, unsigned long long* res_words) {
     const unsigned rounds = T.rounds;
     const bool tslot = T.topup_slot != 0;  // the last slot is the top-up: summed on its own, never judged
     const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
@@ -181,10 +181,14 @@ __device__ __forceinline__ void lean_judge(const LeanTail& T, const double (&tot
     // every lane works its round's estimate out beside the rules: the two chains of f64 operations overlap (with a
     // top-up slot the estimate depends on the decision and follows it)
     const bool result_now = with_result && !tslot;
+#ifndef AQE_ABL_NOJUDGE
     if (lane < rounds_j) {
         if (fp.is_clt) code = clt_rules(tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], fp);
         if (result_now) res = make_result(st, fin);
     }
+#else
+    res.sum = st.sd_p; res.n = static_cast<uint64_t>(st.n_p);
+#endif
     const unsigned long long stops = __ballot(code != 0);
     const unsigned last_round = stops ? static_cast<unsigned>(__builtin_ctzll(stops)) : rounds_j - 1u;  // the rule holds after this round / samples exhausted
     if (lane != last_round) return;
@@ -209,16 +213,43 @@ __device__ __forceinline__ void lean_judge(const LeanTail& T, const double (&tot
     res.rounds = st.rounds;
     res.converged = code;
     res.topup_pending = goes_on ? 2 : due ? 1 : 0;  // 2: the host launches the plan's remaining rounds
+#ifdef AQE_ABL_NOSTORE  // (ablation: everything computed, ONE 8-byte store to device memory)
+    T.state->n_a = res.value + res.ci_lower + st.n_p + static_cast<double>(result_check(res, epoch) & 0xffu);
+    return;
+#endif
+#ifdef AQE_ABL_RESDEV  // (ablation: the result into device memory instead of the pinned host block)
     lean_state_store(T.state, st);
+    *reinterpret_cast<aqe_result*>(reinterpret_cast<char*>(T.state) + 256) = res;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(T.state) + 512), result_check(res, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+#endif
+    // The state is read by a later LAUNCH of the same execution only — the top-up when it is due (launched by fetch(), or
+    // already enqueued behind this launch: keep_state), the remaining rounds of a head form — and by the stepwise forms,
+    // which do not come here: otherwise its fourteen stores stay home (a store instruction costs one lane what it costs
+    // sixty-four: ~25 ns each on this path).
+    if (due || goes_on || T.keep_state || !with_result) lean_state_store(T.state, st);
     if (with_result) {
-        *T.result = res;
-        // the host polls the pinned result instead of waiting for the end of the launch: the check word tells it when
-        // every field has landed (kernels.hpp, result_check)
-        __hip_atomic_store(T.result_seq, result_check(res, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // The result leaves as ONE store instruction: the finishing lane parks its words in LDS (cheap), lane i of the wave
+        // sends word i.  The host polls the pinned result instead of waiting for the end of the launch: the check word
+        // tells it when every field has landed (kernels.hpp, result_check).
+        static_assert(sizeof(aqe_result) % 8 == 0 && sizeof(aqe_result) / 8 < 63, "one word per lane, the check word after them");
+        *reinterpret_cast<aqe_result*>(res_words) = res;
+        res_words[sizeof(aqe_result) / 8] = result_check(res, epoch);
     }
 #ifdef AQE_LEAN_STAMPS
     g_lean_stamps[static_cast<size_t>(kMaxPersistGrid) * kPersistWaves * 8 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// (all lanes of wave 0, after lean_judge: lane i sends word i of the result, lane sizeof/8 the check word)
+__device__ __forceinline__ void lean_send_result(const LeanTail& T, const unsigned long long* res_words, unsigned lane) {
+#if defined(AQE_ABL_NOSTORE) || defined(AQE_ABL_RESDEV)
+    return;
+#endif
+    if (T.totals_only || !T.finalize_here) return;
+    constexpr unsigned kWords = sizeof(aqe_result) / 8;
+    if (lane < kWords) __hip_atomic_store(reinterpret_cast<unsigned long long*>(T.result) + lane, res_words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (lane == kWords) __hip_atomic_store(T.result_seq, res_words[kWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One query on the workgroups bid = 0 .. G-1 (a launch of its own, or one group of a batch's launch).  `a`: the fields
@@ -233,6 +264,7 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     __shared__ unsigned lds_slot[kMaxPersistRounds];
     __shared__ unsigned lds_mask[kPersistWaves];  // rounds a wave swept tiles of
     __shared__ u64 lds_tail[64];
+    __shared__ unsigned long long lds_res[64];  // the finishing lane's result, word by word (lean_send_result)
     __shared__ int s_last;
     const int lane = threadIdx.x & 63;
     const unsigned wave = threadIdx.x >> 6;
@@ -329,7 +361,11 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
         const unsigned rem = run_rows - first;
         const double* const base = a.amount + (run_row0 + first);
         TileAcc ta;
+#ifndef AQE_ABL_NOSWEEP  // (ablation builds, tools/ab_ablate.sh: what each stage of a launch costs; results are then wrong)
         lean_tile<kNT>(base, rem, a.amount, lane, a.has_where, a.wmin, a.wmax, a.shift, ta);
+#else
+        ta.s = static_cast<double>(reinterpret_cast<uintptr_t>(base) & 1u) + rem;
+#endif
         merge_tile(acc, ta, (meta & kLeanMetaGroupB) != 0);
 #ifdef AQE_LEAN_STAMPS
         if (t == t_lo + wave) LEAN_STAMP(2);
@@ -341,6 +377,9 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     if (stager) lds_tail[lane] = tail_word;
     LEAN_STAMP(4);
     __syncthreads();
+#ifdef AQE_ABL_NOTICKET
+    return;
+#endif
 
     // ---- the workgroup's partial of every round it swept tiles of: data, drain, ticket (cdna_hip_programming.md G16) ----
     if (wave == 0) {
@@ -387,6 +426,9 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     }
     __syncthreads();
     if (!s_last) return;
+#ifdef AQE_ABL_NOFOLD
+    return;
+#endif
 
     // ---- the last workgroup to arrive folds the launch.  Everything it needs from the descriptor is in LDS already.  The
     //      whole partial list — fewer than workgroups + rounds slots, whatever the size of the sweep — is fetched in ONE batch
@@ -394,26 +436,11 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     const LeanTail& T = *reinterpret_cast<const LeanTail*>(lds_tail);
     const unsigned rounds = T.rounds;
     const unsigned long long t0 = T.want_ticks ? __hip_atomic_load(lean_t0_word(a.counter), AQE_RLX) : 0ull;  // (in flight beside the partials)
-    double* const words = &lds_part[0][0][0];
-    {
-        const unsigned nwords = T.slot_begin[rounds] * static_cast<unsigned>(kVec);
-        constexpr unsigned kPerThread = (kLeanMaxSlots * kVec + kPersistThreads - 1) / kPersistThreads;
-        double x[kPerThread];
-#pragma unroll
-        for (unsigned i = 0; i < kPerThread; ++i) {
-            const unsigned w = threadIdx.x + i * kPersistThreads;
-            x[i] = w < nwords ? __hip_atomic_load(a.partials + w, AQE_RLX) : 0.0;
-        }
-#pragma unroll
-        for (unsigned i = 0; i < kPerThread; ++i) {
-            const unsigned w = threadIdx.x + i * kPersistThreads;
-            if (w < nwords) words[w] = x[i];
-        }
-    }
-    __syncthreads();
     // W waves per round (a power of two; one when the plan has more than eight rounds).  Thread (part, c) of a round's waves
-    // sums component c of every (8 W)-th slot of the round, ascending; the eight parts of a wave combine by DPP, the W waves
-    // of a round through LDS, in wave order: a fixed order whatever arrives when — bit-reproducible.
+    // sums component c of every (8 W)-th slot of the round straight out of the partial list — fewer than workgroups + rounds
+    // slots, whatever the size of the sweep: all of a thread's loads in flight together, ONE round trip for the launch — in
+    // ascending order; the eight parts of a wave combine by DPP, the W waves of a round through LDS, in wave order: a fixed
+    // order whatever arrives when — bit-reproducible.
     unsigned W = 1;
     while (2u * W * rounds <= kPersistWaves) W *= 2u;
     const unsigned per_pass = kPersistWaves / W;
@@ -423,7 +450,21 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
         const bool mine = q < rounds && c < 7u;
         const unsigned b = mine ? T.slot_begin[q] : 0u, e = mine ? T.slot_begin[q + 1u] : 0u;
         double s = 0.0;
-        for (unsigned sl = b + part; sl < e; sl += 8u * W) s += words[static_cast<size_t>(sl) * kVec + c];
+        constexpr unsigned kInFlight = 6;  // covers a round of 96 W slots in one turn (a 10 M-row query's rounds: ~65 slots, W = 2)
+        for (unsigned sl0 = b + part; __ballot(sl0 < e) != 0; sl0 += 8u * W * kInFlight) {
+            double x[kInFlight];
+#pragma unroll
+            for (unsigned i = 0; i < kInFlight; ++i) {
+                const unsigned sl = sl0 + 8u * W * i;
+#ifndef AQE_ABL_NOGATHER
+                x[i] = sl < e ? __hip_atomic_load(a.partials + static_cast<size_t>(sl) * kVec + c, AQE_RLX) : 0.0;
+#else
+                x[i] = 1.0;
+#endif
+            }
+#pragma unroll
+            for (unsigned i = 0; i < kInFlight; ++i) s += x[i];
+        }
         s += dpp_f64<0xB1>(s);   // lane ^ 1
         s += dpp_f64<0x4E>(s);   // lane ^ 2
         s += dpp_f64<0x141>(s);  // the other quad of the eight
@@ -437,17 +478,27 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
     const bool own = T.totals_only != 0 || (tslot && static_cast<unsigned>(lane) == rounds - 1u);
     double tot[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (unsigned r = 0; r < rounds; ++r) {
-        const bool take = own ? r == static_cast<unsigned>(lane) : (r <= static_cast<unsigned>(lane) && r < rounds_j);
-        for (unsigned ws = 0; ws < W; ++ws) {
+    {   // rows of lds_round in order (round-major, the W waves of a round in wave order); the next row's reads are in
+        // flight while this one is added: the loop is a chain of LDS round trips otherwise
+        const unsigned nrow = rounds * W;
+        double nx[7];
 #pragma unroll
-            for (int cc = 0; cc < 7; ++cc) {
-                const double x = lds_round[r * W + ws][cc];
-                tot[cc] += take ? x : 0.0;
-            }
+        for (int cc = 0; cc < 7; ++cc) nx[cc] = lds_round[0][cc];
+        for (unsigned i = 0; i < nrow; ++i) {
+            double cur[7];
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc) cur[cc] = nx[cc];
+            const unsigned j = i + 1u < nrow ? i + 1u : i;
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc) nx[cc] = lds_round[j][cc];
+            const unsigned r = i / W;
+            const bool take = own ? r == static_cast<unsigned>(lane) : (r <= static_cast<unsigned>(lane) && r < rounds_j);
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc) tot[cc] += take ? cur[cc] : 0.0;
         }
     }
-    lean_judge(T, tot, static_cast<unsigned>(lane), t0, epoch);
+    lean_judge(T, tot, static_cast<unsigned>(lane), t0, epoch, lds_res);
+    lean_send_result(T, lds_res, static_cast<unsigned>(lane));  // (same wave: LDS accesses of a wave are in order)
 }
 
 template <bool kNT, bool kWide>

@@ -551,7 +551,8 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
         HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(QueryState)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), 1024));  // (QueryState; the rest is scratch of the ablation builds, tools/ab_ablate.sh)
+        static_assert(sizeof(QueryState) <= 256, "state block");
         HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
         // (coherent, i.e. fine-grained: the device's stores must reach host memory while the launch is still running — fetch() polls)
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -784,6 +785,8 @@ void fill_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_to
     t.topup_slot = totals_only ? 0u : L.topup_slot;
     t.want_ticks = (p->want_ticks && !totals_only) ? 1u : 0u;
     t.totals_only = totals_only ? 1u : 0u;
+    // (aqe_plan_enqueue_all puts the device-gated top-up launch behind this one when the plan's last execution needed it)
+    t.keep_state = (!totals_only && p->host.has_topup && p->expect_topup && !L.topup_slot) ? 1u : 0u;
 }
 
 int launch_lean(aqe_plan* p, const SweepForm& L, bool totals_only, double* out_totals, hipStream_t s) {
@@ -1187,6 +1190,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
             for (size_t i = 0; i < n; ++i) {
                 fill_lean(b->plans[i], lf[i], kind == 1, kind == 1 ? dev_totals + i * row_stride : nullptr, 0, ltable[i]);
                 ltable[i].tail.want_ticks = 0;
+                ltable[i].tail.keep_state = 0;  // (a batch never enqueues a top-up launch up front: fetch() runs the due ones)
                 m.samples += lf[i].samples;
             }
             m.forms = std::move(lf);
