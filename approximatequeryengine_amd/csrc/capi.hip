@@ -165,7 +165,7 @@ int aqe_group_key_range(aqe_ctx* c, int group_column, int32_t* key_min, int32_t*
 namespace {
 // The sweep of a grouped reduction: this shard's sampled rows binned per workgroup into c->grp_partial
 // ([*grid][nbins][4]); *grid == 0 when nothing of the sample lies in this shard.
-int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, hipStream_t s, unsigned* grid_out) {
+int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_min, uint32_t nbins, hipStream_t s, unsigned* grid_out, const GroupFuse* fuse = nullptr) {
     *grid_out = 0;
     aqe_plan* p = nullptr;
     int rc = cached_plan(c, q, &p);
@@ -189,7 +189,7 @@ int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_
     }
     const LaunchDesc& L = p->rounds[0];
     const unsigned grid = grouped_grid(L.ntiles);
-    const size_t need = static_cast<size_t>(grid) * nbins * 4 * sizeof(double);
+    const size_t need = fuse ? 0 : static_cast<size_t>(grid) * nbins * 4 * sizeof(double);  // (the fused form adds into its accumulator)
     if (c->grp_partial_bytes < need) {  // scratch lives with the context: no allocation on the query path after the first call
         if (c->grp_partial) (void)hipFree(c->grp_partial);
         c->grp_partial = nullptr;
@@ -197,7 +197,7 @@ int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_partial), need));
         c->grp_partial_bytes = need;
     }
-    HIPCHK(c, launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, keys, key_min, nbins, c->grp_partial, grid, s));
+    HIPCHK(c, launch_grouped(sweep_common(p, p->d_fams + L.fam_offset, L.nfam), L.ntiles, keys, key_min, nbins, c->grp_partial, grid, s, fuse));
     *grid_out = grid;
     return AQE_OK;
 }
@@ -205,8 +205,24 @@ int grouped_sweep(aqe_ctx* c, const aqe_query* q, int group_column, int32_t key_
 // results leave through a pinned host buffer the device writes directly (no copy launch on the way out)
 int ensure_group_out(aqe_ctx* c) {
     if (c->grp_out) return AQE_OK;
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->grp_out_host), kMaxGroupBins * sizeof(aqe_group_result), hipHostMallocMapped));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->grp_out_host), kMaxGroupBins * sizeof(aqe_group_result), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->grp_out), c->grp_out_host, 0));
+    return AQE_OK;
+}
+
+// scratch of the fused form: accumulator and tickets (device, zeroed once: every launch leaves them at zero), check words (pinned)
+int ensure_group_fuse(aqe_ctx* c) {
+    if (c->grp_acc) return AQE_OK;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->grp_check_host), kMaxGroupBins * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->grp_check_host, 0, kMaxGroupBins * sizeof(unsigned long long));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->grp_check), c->grp_check_host, 0));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->grp_ticket), sizeof(unsigned) * kCounterWords));
+    HIPCHK(c, hipMemset(c->grp_ticket, 0, sizeof(unsigned) * kCounterWords));
+    double* acc = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&acc), sizeof(double) * 4 * kMaxGroupBins));
+    HIPCHK(c, hipMemset(acc, 0, sizeof(double) * 4 * kMaxGroupBins));
+    HIPCHK(c, hipDeviceSynchronize());  // (the memsets run on the null stream, which the context's stream does not wait for)
+    c->grp_acc = acc;
     return AQE_OK;
 }
 
@@ -269,16 +285,44 @@ int aqe_reduce_grouped(aqe_ctx* c, const aqe_query* q, int group_column, aqe_gro
     const uint32_t nbins = static_cast<uint32_t>(span);
     if (q->agg < AQE_SUM || q->agg > AQE_COUNT) return fail(c, AQE_ERR_INVALID, "bad agg");
     HIPCHK(c, hipSetDevice(c->device));
-    // a world of one needs no all-reduce between the sums and the estimates: sweep, then ONE launch that adds the
-    // workgroups' bins and works every group out, straight into the pinned result buffer
+    // A world of one needs no all-reduce between the sums and the estimates: ONE launch — the sweep, whose last workgroup
+    // adds the bins up and works every group out, straight into the pinned result buffer — and the host polls the groups'
+    // check words instead of waiting for the stream (AQE_GROUP_UNFUSED=1: the sweep, a second launch, a stream wait).
+    rc = ensure_group_out(c);
+    if (rc == AQE_OK) rc = ensure_group_fuse(c);
+    if (rc != AQE_OK) return rc;
+    static const bool unfused = std::getenv("AQE_GROUP_UNFUSED") != nullptr;
     unsigned grid = 0;
-    rc = grouped_sweep(c, q, group_column, kmin, nbins, c->stream, &grid);
+    if (unfused) {
+        rc = grouped_sweep(c, q, group_column, kmin, nbins, c->stream, &grid);
+        if (rc != AQE_OK) return rc;
+        if (grid == 0) return AQE_OK;  // nothing sampled: no groups
+        HIPCHK(c, launch_grouped_sum_finish(c->grp_partial, grid, nbins, kmin, query_shift(c, *q), q->sample_percent, q->agg, c->grp_out, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return collect_groups(c, nbins, out, cap, n_groups);
+    }
+    GroupFuse f;
+    f.acc = c->grp_acc; f.ticket = c->grp_ticket; f.out = c->grp_out; f.check = c->grp_check;
+    f.epoch = c->epoch++;
+    f.shift = query_shift(c, *q); f.pct = q->sample_percent; f.agg = q->agg;
+    rc = grouped_sweep(c, q, group_column, kmin, nbins, c->stream, &grid, &f);
     if (rc != AQE_OK) return rc;
     if (grid == 0) return AQE_OK;  // nothing sampled: no groups
-    rc = ensure_group_out(c);
-    if (rc != AQE_OK) return rc;
-    HIPCHK(c, launch_grouped_sum_finish(c->grp_partial, grid, nbins, kmin, query_shift(c, *q), q->sample_percent, q->agg, c->grp_out, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   // every bin's group has landed when its check word agrees with its fields (the stores may arrive in any order)
+        const auto t0 = std::chrono::steady_clock::now();
+        const volatile unsigned long long* chk = c->grp_check_host;
+        uint32_t b = 0;
+        for (unsigned spins = 0; b < nbins; ++spins) {
+            aqe_group_result snap;
+            const volatile unsigned long long* src = reinterpret_cast<const volatile unsigned long long*>(c->grp_out_host + b);
+            unsigned long long w[sizeof(aqe_group_result) / 8];
+            for (size_t i = 0; i < sizeof(aqe_group_result) / 8; ++i) w[i] = src[i];
+            std::memcpy(&snap, w, sizeof snap);
+            if (chk[b] == group_check(snap, f.epoch)) { ++b; continue; }
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (b < nbins) HIPCHK(c, hipStreamSynchronize(c->stream));  // (never seen; the launch's end says the same)
+    }
     return collect_groups(c, nbins, out, cap, n_groups);
 }
 

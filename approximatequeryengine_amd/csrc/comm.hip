@@ -24,6 +24,9 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    int version = 0;
     std::string error;
 };
 
@@ -58,6 +61,19 @@ Rccl& rccl() {
         R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
         R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
         R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+        R.GetVersion = reinterpret_cast<decltype(R.GetVersion)>(sym("ncclGetVersion"));
+        R.CommAbort = reinterpret_cast<decltype(R.CommAbort)>(sym("ncclCommAbort"));
+        // The function-pointer types above come from THIS build's <rccl/rccl.h>; the library found at run time may be
+        // another copy (PyTorch's).  The calls used here have kept their signatures across NCCL 2.x: a library of another
+        // major version is refused rather than called through the wrong prototypes.
+        if (R.error.empty() && R.GetVersion) {
+            if (R.GetVersion(&R.version) != ncclSuccess) R.error = "ncclGetVersion failed";
+            else {
+                const int major = R.version >= 10000 ? R.version / 10000 : R.version / 1000;  // NCCL_VERSION(): X*10000 + Y*100 + Z from 2.9 on
+                if (major != NCCL_MAJOR)
+                    R.error = "librccl reports NCCL version " + std::to_string(R.version) + ", this library was built against major version " + std::to_string(NCCL_MAJOR);
+            }
+        }
     });
     return R;
 }
@@ -150,6 +166,18 @@ void aqe_comm_destroy(aqe_comm* m) {
     delete m;
 }
 
+// A rank that fails between two collectives of a sharded run must not simply return: its peers would block in the next
+// all-reduce for ever.  The communicator is aborted instead (ncclCommAbort: peers' pending and later collectives fail)
+// and the handle is dead from then on; the caller tears the group down.
+static int abort_after(aqe_comm* m, int rc) {
+    if (rc != AQE_OK && m && m->comm && m->nranks > 1 && rccl().CommAbort) {
+        (void)hipSetDevice(m->device);
+        (void)rccl().CommAbort(m->comm);
+        m->comm = nullptr;
+    }
+    return rc;
+}
+
 int aqe_comm_info(const aqe_comm* m, int* nranks, int* rank) {
     if (!m) return AQE_ERR_INVALID;
     if (nranks) *nranks = m->nranks;
@@ -163,6 +191,7 @@ static int all_reduce(aqe_comm* m, double* buf, uint64_t count, ncclRedOp_t op, 
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (count == 0) return AQE_OK;
+    if (!m->comm) return fail(c, AQE_ERR_INVALID, "the communicator was aborted after a failure on this rank");
     RCCLCHK(c, rccl().AllReduce(buf, buf, static_cast<size_t>(count), ncclFloat64, op, m->comm, s));
     return AQE_OK;
 }
@@ -192,7 +221,7 @@ int aqe_batch_run_sharded(aqe_batch* b, aqe_comm* m, double* dev_totals, uint64_
     if (rc == AQE_OK) rc = aqe_batch_join(b, stream);
     if (rc == AQE_OK) rc = aqe_comm_all_reduce_sum(m, dev_totals, static_cast<uint64_t>(n_plans) * row_stride, stream);
     if (rc == AQE_OK) rc = aqe_batch_enqueue_replays(b, dev_totals, row_stride, stream);
-    return rc;
+    return abort_after(m, rc);
 }
 
 // One query over the ranks of a communicator, in the form the plan offers: batched (one collective for the whole
@@ -219,7 +248,7 @@ int aqe_plan_run_sharded(aqe_plan* p, aqe_comm* m, double* dev_vec, void* stream
         if (rc == AQE_OK) rc = aqe_comm_all_reduce_sum(m, dev_vec, len, s);
         if (rc == AQE_OK) rc = aqe_plan_enqueue_replay(p, dev_vec, s);
         if (rc == AQE_OK) rc = aqe_plan_fetch(p, out, s);
-        if (rc != AQE_OK || !out->topup_pending) return rc;
+        if (rc != AQE_OK || !out->topup_pending) return abort_after(m, rc);
         rc = step(rounds);  // every rank reads the same mark: every rank comes here
     } else {
         rc = aqe_plan_reset(p, s);
@@ -227,7 +256,7 @@ int aqe_plan_run_sharded(aqe_plan* p, aqe_comm* m, double* dev_vec, void* stream
     }
     if (rc == AQE_OK) rc = aqe_plan_enqueue_finalize(p, s);
     if (rc == AQE_OK) rc = aqe_plan_fetch(p, out, s);
-    return rc;
+    return abort_after(m, rc);
 }
 
 }  // extern "C"

@@ -123,12 +123,84 @@ struct GroupLaunch {
     int32_t key_min;
     uint32_t nbins;
     double* partial;      // [gridDim.x][nbins][4]: n, S - c n, Q (shifted), visited
+    GroupFuse fuse;       // kFused: the launch also adds the workgroups' bins up and works every group out (single GPU)
 };
+
+// Estimate and interval of one group from its sums (executor.cpp:277-296).
+__device__ __forceinline__ aqe_group_result group_result(double n, double sd, double qd, double visited, int64_t key, double shift, double pct, int agg) {
+    aqe_group_result r;
+    r.key = key;
+    r.n = static_cast<uint64_t>(n);
+    r.visited = static_cast<uint64_t>(visited);
+    const double c = shift;
+    r.sum = sd + n * c;
+    r.sumsq = qd + 2.0 * c * sd + n * c * c;
+    double mean = 0.0, m2 = 0.0;
+    if (n > 0.0) mean_m2(n, sd, qd, c, mean, m2);
+    r.mean = mean;
+    const double scale = 100.0 / pct;
+    double margin = 0.0;
+    if (n >= 2.0) margin = 1.96 * sqrt((m2 / (n - 1.0)) / n);  // executor.cpp:280-286
+    double value;
+    if (agg == AQE_SUM) { value = r.sum * scale; margin *= scale; }  // executor.cpp:289-296 scales the interval so
+    else if (agg == AQE_AVG) { value = mean; }
+    else { value = n * scale; margin = 0.0; }
+    r.value = value;
+    r.ci_lower = value - margin;
+    r.ci_upper = value + margin;
+    return r;
+}
+
+// The fused epilogue (single GPU, aqe_reduce_grouped): every workgroup ADDS its bins to one [nbins][4] accumulator in
+// device memory (f64 atomic adds, executed at the memory side; counts are integers and stay exact, the sums were
+// arrival-ordered within a workgroup already), drains, draws a ticket (sharded, as k_round's); the workgroup that draws
+// the last one reads the accumulator, clears it for the next launch, works every group out and writes it — with a check
+// word over its fields — into the pinned block the host polls.  One launch and no stream synchronisation, where the sweep,
+// a second launch over the workgroups' bins and a wait for the stream took 35-60 us per call for a 9-28 us sweep.
+__device__ __forceinline__ void grouped_fused_epilogue(const GroupLaunch& a, const double* mine /* LDS: this workgroup's [nbins][4] */, double* lds_tot) {
+    __shared__ int s_last;
+    const unsigned nb = a.nbins, words = nb * 4;
+    for (unsigned i = threadIdx.x; i < words; i += kBlockThreads) {
+        const double v = mine[i];
+        if (v != 0.0) unsafeAtomicAdd(a.fuse.acc + i, v);  // (global_atomic_add_f64: device memory, no compare-and-swap loop)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's adds have been performed ...
+    __syncthreads();                                    // ... and so have the workgroup's, before its ticket is drawn
+    if (threadIdx.x == 0) {
+        const unsigned G = gridDim.x, shards = G < static_cast<unsigned>(kShards) ? G : static_cast<unsigned>(kShards);
+        unsigned* const ct = a.fuse.ticket + static_cast<size_t>(kShards) * kShardStride;
+        int last = 0;
+        if (G <= 16u) {
+            if (__hip_atomic_fetch_add(ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1u) { __hip_atomic_store(ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
+        } else {
+            const unsigned sh = blockIdx.x % shards, members = (G - sh + shards - 1u) / shards;
+            unsigned* const cs = a.fuse.ticket + static_cast<size_t>(sh) * kShardStride;
+            if (__hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+                __hip_atomic_store(cs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u) { __hip_atomic_store(ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
+            }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (unsigned i = threadIdx.x; i < words; i += kBlockThreads) {
+        lds_tot[i] = __hip_atomic_load(a.fuse.acc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.fuse.acc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next launch starts from zero)
+    }
+    __syncthreads();
+    for (unsigned b = threadIdx.x; b < nb; b += kBlockThreads) {
+        const aqe_group_result r = group_result(lds_tot[b * 4 + 0], lds_tot[b * 4 + 1], lds_tot[b * 4 + 2], lds_tot[b * 4 + 3], static_cast<int64_t>(a.key_min) + b,
+                                                a.fuse.shift, a.fuse.pct, a.fuse.agg);
+        a.fuse.out[b] = r;
+        __hip_atomic_store(a.fuse.check + b, group_check(r, a.fuse.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // One wave folds one tile of the family table (the decomposition add_family made: kDenseTileOrdinals for dense
 // families — two rows per lane per load: 16 bytes of amounts, 8 bytes of keys — kTileOrdinals otherwise; PAIR families
 // do not occur in single-round samplers).
-template <bool kPrivate>
+template <bool kPrivate, bool kFused>
 __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
     extern __shared__ double lds[];
     __shared__ DevFamily lds_fams[kMaxLdsFams];
@@ -241,7 +313,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
         }
     }
     __syncthreads();
-    double* out = a.partial + static_cast<size_t>(blockIdx.x) * nb * 4;  // [nbins][4]: n, S - c n, Q, visited
+    // [nbins][4]: n, S - c n, Q, visited — into the workgroup's slice of the partial buffer, or (fused) into LDS behind the bins
+    double* out = kFused ? lds + words : a.partial + static_cast<size_t>(blockIdx.x) * nb * 4;
     if (kPrivate) {
         // the workgroup's 256 private words per (bin, component), summed by a fixed binary tree over the threads
         for (unsigned stride = kBlockThreads / 2; stride > 0; stride >>= 1) {
@@ -268,6 +341,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_grouped(GroupLaunch a) {
             out[i] = t;
         }
     }
+    if (kFused) {
+        __syncthreads();
+        grouped_fused_epilogue(a, out, out + nb * 4);
+    }
 }
 
 // One wave per (bin, component): lane l adds the workgroups l, l + 64, ... in order, then a fixed xor butterfly
@@ -280,31 +357,6 @@ __global__ __launch_bounds__(64) void k_grouped_sum(const double* __restrict__ p
     for (unsigned w = lane; w < nblocks; w += 64) t += partial[static_cast<size_t>(w) * nbins * 4 + i];
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
     if (lane == 0) bins[i] = t;
-}
-
-// Estimate and interval of one group from its sums (executor.cpp:277-296).
-__device__ __forceinline__ aqe_group_result group_result(double n, double sd, double qd, double visited, int64_t key, double shift, double pct, int agg) {
-    aqe_group_result r;
-    r.key = key;
-    r.n = static_cast<uint64_t>(n);
-    r.visited = static_cast<uint64_t>(visited);
-    const double c = shift;
-    r.sum = sd + n * c;
-    r.sumsq = qd + 2.0 * c * sd + n * c * c;
-    double mean = 0.0, m2 = 0.0;
-    if (n > 0.0) mean_m2(n, sd, qd, c, mean, m2);
-    r.mean = mean;
-    const double scale = 100.0 / pct;
-    double margin = 0.0;
-    if (n >= 2.0) margin = 1.96 * sqrt((m2 / (n - 1.0)) / n);  // executor.cpp:280-286
-    double value;
-    if (agg == AQE_SUM) { value = r.sum * scale; margin *= scale; }  // executor.cpp:289-296 scales the interval so
-    else if (agg == AQE_AVG) { value = mean; }
-    else { value = n * scale; margin = 0.0; }
-    r.value = value;
-    r.ci_lower = value - margin;
-    r.ci_upper = value + margin;
-    return r;
 }
 
 // One thread per bin: estimate and interval of the group from its (all-reduced) sums.
@@ -362,10 +414,18 @@ hipError_t launch_key_range(const int32_t* keys, uint64_t n, int32_t* out2, hipS
 unsigned grouped_grid(uint64_t ntiles) { return blocks_for(ntiles, kWavesPerBlock, kGroupedMaxBlocks); }
 
 hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t* keys, int32_t key_min, uint32_t nbins, double* partial,
-                          unsigned grid, hipStream_t s) {
-    GroupLaunch a{sw, ntiles, keys, key_min, nbins, partial};
-    if (nbins <= kPrivBins) hipLaunchKernelGGL(k_grouped<true>, dim3(grid), dim3(kBlockThreads), static_cast<size_t>(nbins) * kBlockThreads * 3 * sizeof(double), s, a);
-    else hipLaunchKernelGGL(k_grouped<false>, dim3(grid), dim3(kBlockThreads), static_cast<size_t>(replicas_for(nbins)) * replica_stride(nbins) * 4 * sizeof(double), s, a);
+                          unsigned grid, hipStream_t s, const GroupFuse* fuse) {
+    GroupLaunch a{sw, ntiles, keys, key_min, nbins, partial, fuse ? *fuse : GroupFuse{}};
+    const size_t bins_bytes = nbins <= kPrivBins ? static_cast<size_t>(nbins) * kBlockThreads * 3 * sizeof(double)
+                                                 : static_cast<size_t>(replicas_for(nbins)) * replica_stride(nbins) * 4 * sizeof(double);
+    const size_t fuse_bytes = fuse ? static_cast<size_t>(nbins) * 8 * sizeof(double) : 0;  // the workgroup's [nbins][4] + the folded [nbins][4]
+    if (nbins <= kPrivBins) {
+        if (fuse) hipLaunchKernelGGL((k_grouped<true, true>), dim3(grid), dim3(kBlockThreads), bins_bytes + fuse_bytes, s, a);
+        else hipLaunchKernelGGL((k_grouped<true, false>), dim3(grid), dim3(kBlockThreads), bins_bytes, s, a);
+    } else {
+        if (fuse) hipLaunchKernelGGL((k_grouped<false, true>), dim3(grid), dim3(kBlockThreads), bins_bytes + fuse_bytes, s, a);
+        else hipLaunchKernelGGL((k_grouped<false, false>), dim3(grid), dim3(kBlockThreads), bins_bytes, s, a);
+    }
     return hipGetLastError();
 }
 

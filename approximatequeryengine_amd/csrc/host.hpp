@@ -43,7 +43,7 @@ struct LaunchDesc {
 
 constexpr size_t kStageChunkRows = 1u << 19;  // 512 Ki rows: 16 MiB of AoS per pinned buffer
 constexpr int kStageRing = 4;                 // pinned buffers of the staging ring (kept by the context between stagings)
-constexpr size_t kMaxStrideViews = 8;  // stride-major copies of the column a table may hold (one per pointer step in use)
+constexpr size_t kMaxStrideViews = 8;  // stride-major copies of the column a table may hold whatever their size; more while they fit the view budget (table.hip)
 constexpr size_t kBatchLanes = 3;  // side streams of the batched multi-GPU form (see ensure_lanes)
 constexpr size_t kInfinityCacheBytes = 256ull << 20;  // MI355X: a column beyond it is streamed with non-temporal loads
 constexpr size_t kGraphMinRounds = 4, kGraphMaxRounds = 8192;  // one-launch-per-round plans replayed as a HIP graph
@@ -121,6 +121,12 @@ struct aqe_ctx {
     size_t grp_partial_bytes = 0;
     aqe_group_result* grp_out = nullptr;    // [aqe::kMaxGroupBins]: device address of grp_out_host
     aqe_group_result* grp_out_host = nullptr;  // pinned, mapped: the finishing kernel writes the groups here
+    // the fused single-GPU form (grouped.hip, grouped_fused_epilogue): accumulator + tickets in device memory (zero between
+    // launches), a check word per bin beside the pinned groups — what aqe_reduce_grouped polls instead of waiting for the stream
+    double* grp_acc = nullptr;
+    unsigned* grp_ticket = nullptr;
+    unsigned long long* grp_check = nullptr;
+    unsigned long long* grp_check_host = nullptr;
     bool ids_dense = false;  // id == first_id + row for every row (detected at staging): key bounds are arithmetic
     int64_t first_id = 0;
     bool dense16 = true;  // dense families may use 16-byte loads (tile sizes depend on it: fixed per table)
@@ -262,7 +268,7 @@ inline double query_shift(const aqe_ctx* c, const aqe_query& q) {
 }
 
 // plans.hip
-void destroy_plan(aqe_plan* p);
+void destroy_plan(aqe_plan* p, bool device_idle = false);  // device_idle: the caller has just synchronised the device
 void drop_cache(aqe_ctx* c);
 SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam, bool topup = false);
 FoldParams fold_params(const aqe_plan* p, bool topup);

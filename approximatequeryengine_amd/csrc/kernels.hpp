@@ -311,8 +311,27 @@ hipError_t launch_extract_key(const aqe_record* aos, int32_t* out, uint64_t n, i
 hipError_t launch_synth_key(int32_t* out, uint64_t n, uint64_t first_row, int column, hipStream_t s);
 hipError_t launch_key_range(const int32_t* keys, uint64_t n, int32_t* out2, hipStream_t s);
 unsigned grouped_grid(uint64_t ntiles);
+// the fused single-GPU form of a grouped sweep (grouped.hip, grouped_fused_epilogue)
+struct GroupFuse {
+    double* acc = nullptr;          // [nbins][4], zero between launches
+    unsigned* ticket = nullptr;     // kCounterWords sharded arrival tickets, zero between launches
+    aqe_group_result* out = nullptr;       // pinned: every bin's group
+    unsigned long long* check = nullptr;   // pinned: group_check(out[b], epoch) per bin — what the host polls
+    unsigned long long epoch = 0;
+    double shift = 0.0, pct = 0.0;
+    int32_t agg = 0, pad = 0;
+};
+// (as result_check: the stores of a group and of its check word may land in any order; they agree when all have)
+__host__ __device__ inline unsigned long long group_check(const aqe_group_result& r, unsigned long long epoch) {
+    unsigned long long a = epoch * 0x9E3779B97F4A7C15ull + 1ull, b = 0;
+    auto mix = [&a, &b](unsigned long long w) { a += w; b += a; };
+    auto bits = [](double d) { unsigned long long u; __builtin_memcpy(&u, &d, 8); return u; };
+    mix(static_cast<unsigned long long>(r.key)); mix(r.n); mix(r.visited);
+    mix(bits(r.sum)); mix(bits(r.sumsq)); mix(bits(r.mean)); mix(bits(r.value)); mix(bits(r.ci_lower)); mix(bits(r.ci_upper));
+    return a ^ ((b << 32) | (b >> 32));
+}
 hipError_t launch_grouped(const SweepCommon& sw, uint64_t ntiles, const int32_t* keys, int32_t key_min, uint32_t nbins, double* partial,
-                          unsigned grid, hipStream_t s);
+                          unsigned grid, hipStream_t s, const GroupFuse* fuse = nullptr);
 hipError_t launch_grouped_sum(const double* partial, unsigned nblocks, uint32_t nbins, double* bins, hipStream_t s);
 hipError_t launch_grouped_sum_finish(const double* partial, unsigned nblocks, uint32_t nbins, int32_t key_min, double shift, double pct, int agg,
                                      aqe_group_result* out, hipStream_t s);

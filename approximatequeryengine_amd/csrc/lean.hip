@@ -443,9 +443,9 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     // order whatever arrives when — bit-reproducible.
     unsigned W = 1;
     while (2u * W * rounds <= kPersistWaves) W *= 2u;
-    const unsigned per_pass = kPersistWaves / W;
+    const unsigned wshift = static_cast<unsigned>(__builtin_ctz(W)), per_pass = kPersistWaves >> wshift;
     for (unsigned q0 = 0; q0 < rounds; q0 += per_pass) {
-        const unsigned q = q0 + wave / W, wsub = wave % W;
+        const unsigned q = q0 + (wave >> wshift), wsub = wave & (W - 1u);
         const unsigned c = (static_cast<unsigned>(lane) >> 3) & 7u, part = (static_cast<unsigned>(lane) & 7u) + 8u * wsub;
         const bool mine = q < rounds && c < 7u;
         const unsigned b = mine ? T.slot_begin[q] : 0u, e = mine ? T.slot_begin[q + 1u] : 0u;
@@ -491,7 +491,7 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
             const unsigned j = i + 1u < nrow ? i + 1u : i;
 #pragma unroll
             for (int cc = 0; cc < 7; ++cc) nx[cc] = lds_round[j][cc];
-            const unsigned r = i / W;
+            const unsigned r = i >> wshift;  // (W is a power of two)
             const bool take = own ? r == static_cast<unsigned>(lane) : (r <= static_cast<unsigned>(lane) && r < rounds_j);
 #pragma unroll
             for (int cc = 0; cc < 7; ++cc) tot[cc] += take ? cur[cc] : 0.0;

@@ -6,9 +6,9 @@ using namespace aqe;
 
 namespace aqe {
 
-void destroy_plan(aqe_plan* p) {
+void destroy_plan(aqe_plan* p, bool device_idle) {
     if (!p) return;
-    (void)hipDeviceSynchronize();  // fetch() may have returned before the plan's last launch had ended
+    if (!device_idle) (void)hipDeviceSynchronize();  // fetch() may have returned before the plan's last launch had ended
     if (p->ctx && p->table_epoch == p->ctx->table_epoch) {  // (a replaced table took its views with it)
         if (p->view_step_rounds) release_stride_view(p->ctx, p->view_step_rounds, p->cached);
         if (p->view_step_topup) release_stride_view(p->ctx, p->view_step_topup, p->cached);
@@ -493,7 +493,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     if (q->agg < AQE_SUM || q->agg > AQE_COUNT) return fail(c, AQE_ERR_INVALID, "agg must be AQE_SUM, AQE_AVG or AQE_COUNT");
     if (q->convention < AQE_EST_CLI || q->convention > AQE_EST_RAW) return fail(c, AQE_ERR_INVALID, "convention must be AQE_EST_CLI, AQE_EST_CPP or AQE_EST_RAW");
     if (q->has_where && (q->where_min != q->where_min || q->where_max != q->where_max)) return fail(c, AQE_ERR_INVALID, "WHERE bound is NaN");
-    std::unique_ptr<aqe_plan, void (*)(aqe_plan*)> p(new aqe_plan(), destroy_plan);
+    std::unique_ptr<aqe_plan, void (*)(aqe_plan*)> p(new aqe_plan(), [](aqe_plan* x) { destroy_plan(x); });
     p->ctx = c;
     p->q = *q;
     p->table_epoch = c->table_epoch;

@@ -179,17 +179,17 @@ bool evict_one_view(aqe_ctx* c) {
         if (it->second.refs == it->second.cache_refs && (victim == c->stride_views.end() || it->second.last_use < victim->second.last_use)) victim = it;
     if (victim == c->stride_views.end()) return false;
     const uint64_t step = victim->first;
+    (void)hipDeviceSynchronize();  // ONE wait for whatever still reads the view; the plans below then go without one each
     for (size_t i = 0; i < c->cache.size();) {
         aqe_plan* p = c->cache[i].second;
         if (p->view_step_rounds == step || p->view_step_topup == step) {
-            destroy_plan(p);  // (releases its references)
+            destroy_plan(p, true);  // (releases its references)
             c->cache.erase(c->cache.begin() + static_cast<long>(i));
         } else {
             ++i;
         }
     }
     victim = c->stride_views.find(step);
-    (void)hipDeviceSynchronize();
     free_view(c, victim->second);
     c->stride_views.erase(victim);
     c->view_evictions++;
@@ -209,14 +209,21 @@ int ensure_stride_view(aqe_ctx* c, uint64_t step, const double** view, uint64_t*
         return AQE_OK;
     }
     *view = nullptr;
-    if (c->stride_views.size() >= kMaxStrideViews && !evict_one_view(c)) {
-        c->view_fallbacks++;  // every view is held by a live plan: this step is swept in place
-        return AQE_OK;
-    }
     StrideView v;
     v.M = M;
     v.q0 = q0;
     v.bytes = (static_cast<size_t>(step) * M + 2) * sizeof(double);  // + the spare rows the 16-byte loads park on
+    // A table may hold kMaxStrideViews views whatever their size, and more while all of them fit the view budget (16 GiB;
+    // AQE_VIEW_BUDGET_MB, read per call): HBM capacity is the cheap resource here — a 10 M-row table holds a view per
+    // step anybody asks for and never falls back to sweeping in place, a 1 B-row table (8 GB per view) stops at eight.
+    uint64_t budget = 16ull << 30;
+    if (const char* e = std::getenv("AQE_VIEW_BUDGET_MB")) budget = std::strtoull(e, nullptr, 10) << 20;
+    while (c->stride_views.size() >= kMaxStrideViews && c->view_bytes + v.bytes > budget) {
+        if (!evict_one_view(c)) {
+            c->view_fallbacks++;  // every view is held by a live plan: this step is swept in place
+            return AQE_OK;
+        }
+    }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&v.amount), v.bytes));
     hipError_t e = hipMemsetAsync(v.amount, 0, v.bytes, c->stream);
     if (e == hipSuccess) e = launch_stride_view(c->amount, c->n_local, c->shard_lo, step, M, q0, v.amount, c->stream);
@@ -547,6 +554,9 @@ void aqe_destroy(aqe_ctx* c) {
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     if (c->grp_partial) (void)hipFree(c->grp_partial);
     if (c->grp_out_host) (void)hipHostFree(c->grp_out_host);
+    if (c->grp_check_host) (void)hipHostFree(c->grp_check_host);
+    if (c->grp_acc) (void)hipFree(c->grp_acc);
+    if (c->grp_ticket) (void)hipFree(c->grp_ticket);
     for (hipStream_t s : c->lanes) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -918,6 +918,23 @@ def test_stride_view_lifecycle(nat, oracle, table):
         m = oracle.moments_idx(rows, idx)
         assert res.visited == len(idx) and res.n == m.n and rel(res.sum, m.sum) <= SUM_TOL and rel(res.sumsq, m.sumsq) <= SUM_TOL
 
+    import os
+    with Engine(0) as eng:  # the default budget (16 GiB of views): a small table simply gets a view per step, nothing is evicted
+        eng.stage_records(rows, keep_aos=False)
+        for step in range(2, 13):
+            check(eng, step, eng.reduce(q_of(step)))
+        t = eng.info()
+        assert (t.n_views, t.view_evictions, t.view_fallbacks) == (11, 0, 0)
+    os.environ["AQE_VIEW_BUDGET_MB"] = "0"  # from here on: the eight views a table may always hold, and no more
+    try:
+        _stride_view_lifecycle_at_the_cap(nat, eng_rows=(rows, n), q_of=q_of, check=check)
+    finally:
+        del os.environ["AQE_VIEW_BUDGET_MB"]
+
+
+def _stride_view_lifecycle_at_the_cap(nat, eng_rows, q_of, check):
+    from approximatequeryengine_amd.engine import Engine, make_query
+    rows, n = eng_rows
     with Engine(0) as eng:
         eng.stage_records(rows, keep_aos=False)
         base = eng.info()
@@ -995,9 +1012,10 @@ def test_file_staging_round_trip(nat, oracle, golden, table, tmp_path):
 
 
 def test_file_staging_several_pinned_chunks(nat, oracle, tmp_path):
-    """Config 3's staging path at a size that needs several pinned bounce buffers (2 Mi rows = 64 MiB each): a 5 M-row
-    file in the reference's format, mmap -> pinned double buffers -> HBM, whole and as the middle shard of three; the
-    exact SUM, a strided sample and the rows themselves against the host copy."""
+    """Config 3's staging path at a size that needs several turns of the pinned ring (four buffers of 256 Ki rows = 8 MiB
+    each for a table this size): a 5 M-row file in the reference's format, pread -> pinned ring -> HBM, whole and as the
+    middle shard of three; the exact SUM, a strided sample and the rows themselves against the host copy; and where the
+    time went (aqe_last_stage_stats): the ring is pinned by the context's first staging only."""
     from approximatequeryengine_amd.engine import Engine, make_query
     n = 5_000_000
     rows = oracle.synth(n, 7)
@@ -1006,12 +1024,17 @@ def test_file_staging_several_pinned_chunks(nat, oracle, tmp_path):
     with Engine(0) as eng:
         eng.stage_file(p, keep_aos=True)
         assert eng.info().global_rows == n and eng.info().has_aos == 1
+        st = eng.stage_stats()
+        assert st.chunks == (n + (1 << 18) - 1) >> 18 and st.host_bytes == 32 * n == st.link_bytes and st.fill_threads >= 1
+        assert st.pinned_alloc_ms > 0.0 and st.total_ms >= st.fill_ms > 0.0
         r = eng.reduce(make_query(nat.M_EXACT, 100.0))
         assert r.n == n and rel(r.value, math.fsum(rows["amount"])) <= SUM_TOL
         got = eng.gather(make_query(nat.M_MEMORY_STRIDE, 1.0))
         assert got.tobytes() == rows[::100][: len(got)].tobytes() and len(got) == n // 100
         lo, hi = n // 3, 2 * n // 3
         eng.stage_file(p, shard_lo=lo, n_local=hi - lo, keep_aos=False)  # amounts only: a quarter of the bytes cross PCIe
+        st = eng.stage_stats()
+        assert st.pinned_alloc_ms == 0.0 and st.host_bytes == 32 * (hi - lo) and st.link_bytes == 8 * (hi - lo)  # (the ring was there)
         t = eng.info()
         assert (t.global_rows, t.shard_lo, t.local_rows, t.has_aos) == (n, lo, hi - lo, 0)
         import torch
