@@ -28,7 +28,7 @@ Q_SHARE_GPU = 16
 Q_NO_LEAN = 32
 Q_FORCE_LEAN = 64
 KERNEL_ROUND, KERNEL_SWEEP_PERSIST, KERNEL_SWEEP_LEAN, KERNEL_SWEEP_MULTI, KERNEL_SWEEP_LEAN_MULTI = 0, 1, 2, 3, 4
-KERNEL_NAMES = {0: "k_round", 1: "k_sweep_persist", 2: "k_sweep_lean", 3: "k_sweep_multi", 4: "k_sweep_lean_multi"}
+KERNEL_NAMES = {0: "k_round", 1: "k_sweep_persist", 2: "k_sweep_lean", 3: "k_sweep_multi", 4: "k_sweep_lean_multi", 5: "k_indexed", 6: "k_permuted"}
 F_TOPUP = 1
 F_PAIR = 2
 STAGE_KEEP_AOS = 1

@@ -181,7 +181,7 @@ hipStream_t pick(aqe_plan* p, void* stream) { return stream ? static_cast<hipStr
 
 int enqueue_launch(aqe_plan* p, const LaunchDesc& L, uint32_t index, bool topup, bool fused, double* out_vec, hipStream_t s, unsigned long long epoch = 0) {
     aqe_ctx* c = p->ctx;
-    if (!topup && index == 0) { p->last_exec = 0; p->last_kernel = AQE_KERNEL_ROUND; }
+    if (!topup && index == 0) { p->last_exec = 0; p->last_kernel = p->host.is_random ? AQE_KERNEL_INDEXED : p->host.is_perm ? AQE_KERNEL_PERMUTED : AQE_KERNEL_ROUND; }
     if (!epoch) p->poll_epoch = 0;  // this launch writes no check word: whatever it finishes is fetched the ordinary way
     RoundLaunch a = round_launch(p, L, index, topup, fused, out_vec, epoch);
     const bool prof = p->profile && 2 * (p->lev_used + 1) <= p->lev.size();

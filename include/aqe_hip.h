@@ -446,11 +446,13 @@ AQE_API int aqe_plan_last_kernel_ms(aqe_plan* plan, float* ms);
 AQE_API int aqe_plan_set_profiling(aqe_plan* plan, int enable);
 AQE_API int aqe_plan_launch_ms(aqe_plan* plan, float* ms, uint32_t cap, uint32_t* n_out);
 /* Which kernel swept the rounds of the plan's most recent execution (diagnostics, roofline reports). */
-#define AQE_KERNEL_ROUND 0         /* one k_round / k_indexed / k_permuted launch per round                        */
+#define AQE_KERNEL_ROUND 0         /* one k_round launch per round                                                 */
 #define AQE_KERNEL_SWEEP_PERSIST 1 /* k_sweep_persist: every round in one launch, a monitor wave judges as rounds complete */
 #define AQE_KERNEL_SWEEP_LEAN 2    /* k_sweep_lean: every round in one launch, judged once by the last workgroup to arrive */
 #define AQE_KERNEL_SWEEP_MULTI 3   /* k_sweep_multi: the plan ran as a group of a batch's one launch (groups with monitor waves) */
 #define AQE_KERNEL_SWEEP_LEAN_MULTI 4 /* k_sweep_lean_multi: ... as a lean group (every plan of the batch qualifies)    */
+#define AQE_KERNEL_INDEXED 5       /* k_indexed: the seeded-random sampler over its host-built index list (one launch)  */
+#define AQE_KERNEL_PERMUTED 6      /* k_permuted: AQE_M_RANDOM_DEVICE, rows drawn in the kernel (one launch)            */
 AQE_API int aqe_plan_last_kernel(const aqe_plan* plan, int* kernel);
 /* samples (sampled rows) each sweep launch of this shard folds, in launch order; the top-up entry is
  * its upper bound */

@@ -276,6 +276,35 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     assert np.array_equal(np.sort(got["id"] - 1), np.sort(idx.astype(np.int64)))
 
 
+def test_clt_on_the_heterogeneous_table_of_the_reference_fixture(nat, oracle):
+    """tests/golden/clt_hetero.json (reference runs on a table whose halves have spreads 1 : 0.2): the HIP path gives the
+    restatement's answer recorded there — the leader's stop point, which IS the reference's where thread 0 converges first
+    and is later than the reference's where another fast thread does (test_oracle_golden.py says how far)."""
+    import json, os
+    from approximatequeryengine_amd.engine import Engine, make_query
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "clt_hetero.json")))
+    n = g["rows"]
+    for flip in (False, True):
+        rows = oracle.synth(n, g["seed"])
+        a, b = g["scales"]
+        rows["amount"] = 500.5 + (rows["amount"] - 500.5) * np.where(np.arange(n) < n // 2, b if flip else a, a if flip else b)
+        with Engine(0) as eng:
+            eng.stage_records(rows, keep_aos=False)
+            for case in (c for c in g["cases"] if c["flip"] == flip):
+                want = case["restatement"]
+                for R0, growth in ((case["check_interval"], 1), (64, 2)):  # the reference's cadence; a geometric schedule against the oracle
+                    q = make_query(nat.M_CLT_DUAL_POINTER, case["pct"], agg=nat.AVG, check_interval=case["check_interval"], num_threads=case["T"],
+                                   max_error_percent=case["e"], clt_round0=R0, clt_growth=growth)
+                    r = eng.reduce(q)
+                    rc, w, _ = oracle.clt_run(rows, case["pct"], 0.95, case["check_interval"], case["T"], case["e"], R0=R0, growth=growth)
+                    assert rc == 0
+                    assert (r.n, r.topup, r.converged, r.rounds) == (w.final.n, w.topup, w.converged, w.rounds), (case["T"], case["e"], R0)
+                    assert rel(r.sum, w.final.sum) <= SUM_TOL and rel(r.value, w.final.sum / w.final.n) <= EST_TOL
+                    if growth == 1:
+                        assert (r.n, r.topup, r.converged, r.rounds) == (want["n"], want["topup"], want["converged"], want["rounds"])
+                        assert rel(r.value, want["avg"]) <= EST_TOL
+
+
 @pytest.mark.parametrize("n", [1_000_000, 10_000_000])
 def test_clt_stop_points_of_the_reference(nat, golden, engines, n):
     """Where the CLT monitor stops, against the reference's own runs (golden clt_fast_stop, distributions), at 1 M rows and

@@ -2,7 +2,9 @@
 (tests/golden/ref_golden.json, made by oracle/make_golden.py).  Index sets: bit-exact.
 Sums: <= 1e-12 relative.  Estimates / intervals (CLI expressions): <= 1e-9."""
 import base64
+import json
 import math
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -323,3 +325,47 @@ def test_group_by_matches_sqlite_running_the_reference_sql(oracle):
     for k, n, s, q in got:
         m = sub["product_id"] == k
         assert n == int(m.sum()) and abs(s - sub["amount"][m].sum()) <= 1e-9 * s
+
+
+def _hetero_rows(oracle, g, flip):
+    rows = oracle.synth(g["rows"], g["seed"])
+    n = g["rows"]
+    a, b = g["scales"]
+    s = np.where(np.arange(n) < n // 2, b if flip else a, a if flip else b)
+    rows["amount"] = 500.5 + (rows["amount"] - 500.5) * s
+    return rows
+
+
+def test_clt_on_a_heterogeneous_table_against_the_reference(oracle):
+    """Where naming fast worker 0 the leader matters (tests/golden/clt_hetero.json, recorded from the reference's own C++ by
+    oracle/make_golden_clt_hetero.py): the two halves of the table have spreads 1 : 0.2, so the reference's fast threads —
+    each judging its own samples, whichever gets there first stopping the query (DB.cpp:936-961) — converge at very
+    different row counts.
+      * The quiet half is the leader's (`flip`): the reference's thread 0 converges before the other threads have taken a
+        row; what it returns is that thread's rows + the top-up — and the restatement's leader stops on EXACTLY that row
+        count (every worker then holds as many: T x as many rows collected, the round-synchronous reading).
+      * The quiet half is another fast thread's: the reference stops when THAT thread converges; the restatement goes on
+        until its leader does and collects more rows than any of the reference's 30 runs — conservative (its error
+        guarantee at the stop is the leader's own), NOT the reference's stop point.  T >= 4 on heterogeneous tables is
+        therefore 'parity unpinned'; DESIGN.md section 5 says so."""
+    g = json.loads((Path(__file__).parent / "golden" / "clt_hetero.json").read_text())
+    for case in g["cases"]:
+        rows = _hetero_rows(oracle, g, case["flip"])
+        rc, res, _ = oracle.clt_run(rows, case["pct"], 0.95, case["check_interval"], case["T"], case["e"])
+        assert rc == 0
+        want = case["restatement"]  # (the fixture's own record of the restatement: the oracle has not drifted)
+        assert (res.final.n, res.topup, res.converged, res.rounds, res.fast.n) == (want["n"], want["topup"], want["converged"], want["rounds"], want["leader_rows"])
+        base = int(g["rows"] * case["pct"] / 100.0)
+        ref_n = [r["n"] for r in case["reference_runs"]]
+        ref_collected = [n - base // 4 for n in ref_n]  # every recorded run stopped early and took the top-up (DB.cpp:1031-1040)
+        assert min(ref_collected) > 0
+        ours_collected = res.final.n - res.topup
+        for r in case["reference_runs"]:  # both answers are within the requested error of the truth
+            assert abs(r["avg"] - case["true_mean"]) / case["true_mean"] <= case["e"] / 100.0 * 1.5
+        assert abs(want["avg"] - case["true_mean"]) / case["true_mean"] <= case["e"] / 100.0 * 1.5
+        if case["flip"]:
+            # thread 0 converges first: its own row count is the leader's, exactly (the reference's fastest runs hold nothing else)
+            assert min(ref_collected) == res.fast.n, (case["T"], case["e"], min(ref_collected), res.fast.n)
+            assert ours_collected == case["T"] * res.fast.n
+        else:
+            assert ours_collected >= max(ref_collected), (case["T"], case["e"], ours_collected, max(ref_collected))
