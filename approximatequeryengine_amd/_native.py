@@ -16,6 +16,8 @@ M_OPTIMIZED_CLT, M_CLT_DUAL_POINTER, M_FAST_POINTER, M_SLOW_POINTER, M_DUAL_POIN
 M_PARALLEL_POINTER, M_REGION_STRIDE, M_RANDOM_START_STRIDE, M_ADAPTIVE_BLOCK, M_STRATIFIED_BLOCK = 12, 13, 14, 15, 16
 M_ROWID_MOD = 17
 M_RANDOM_DEVICE = 18
+M_DIRECT_ACCESS = 19
+M_OPTIMIZED_SEQUENTIAL = 20
 GROUP_REGION, GROUP_PRODUCT = 1, 2
 
 SUM, AVG, COUNT = 0, 1, 2
@@ -142,6 +144,7 @@ def lib() -> C.CDLL:
         "aqe_query_defaults": (None, [P(Query)]),
         "aqe_plan_families": (C.c_int, [P(Query), u64, u64, u64, u32, P(Family), u32, P(u32), P(u32), P(u64)]),
         "aqe_plan_random_indices": (C.c_int, [u64, dbl, u32, u64, u64, P(u64), u64, P(u64)]),
+        "aqe_plan_row_list": (C.c_int, [P(Query), u64, u64, u64, P(u64), u64, P(u64)]),
         "aqe_plan_adaptive_families": (C.c_int, [P(Query), u64, P(dbl), P(Family), u32, P(u32), P(u64)]),
         "aqe_parse_where": (C.c_int, [C.c_char_p, P(dbl), P(dbl)]),
         "aqe_confidence_heuristic": (dbl, [dbl, u64]),
@@ -247,4 +250,16 @@ def plan_random_indices(n_global: int, pct: float, seed: int, lo: int = 0, hi: i
     check(L.aqe_plan_random_indices(n_global, pct, seed, lo, hi, None, 0, C.byref(n)))
     out = np.zeros(max(n.value, 1), dtype=np.uint64)
     check(L.aqe_plan_random_indices(n_global, pct, seed, lo, hi, out.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)))
+    return out[: n.value]
+
+
+def plan_row_list(q: Query, n_global: int, lo: int = 0, hi: int | None = None):
+    """Host-side row list (no GPU) of a sampler without families: RANDOM_POINTER, DIRECT_ACCESS, OPTIMIZED_SEQUENTIAL."""
+    import numpy as np
+    L = lib()
+    hi = n_global if hi is None else hi
+    n = C.c_uint64()
+    check(L.aqe_plan_row_list(C.byref(q), n_global, lo, hi, None, 0, C.byref(n)))
+    out = np.zeros(max(n.value, 1), dtype=np.uint64)
+    check(L.aqe_plan_row_list(C.byref(q), n_global, lo, hi, out.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)))
     return out[: n.value]

@@ -14,7 +14,9 @@ from the reference are deliberate and listed in INTEGRATION.md; the important on
 * fused ``approx_sum / approx_avg / approx_count`` return the aggregate + interval without materialising
   Python ``Record`` objects (the reference reduces in Python, enhanced_aqe_cli.py:189-200).
 
-Tree-walking samplers that §8 of SURVEY.md rules out raise NotImplementedError.
+Tree-walking samplers that §8 of SURVEY.md rules out raise NotImplementedError (the two the reference CLI routes small
+tables to — direct_access_sample, optimized_sequential_sample — are in: their row lists follow from the leaf shape the
+reference builds from ascending inserts).
 """
 from __future__ import annotations
 
@@ -100,8 +102,8 @@ class ApproxResult:
 
 _AGG = {"SUM": nat.SUM, "AVG": nat.AVG, "COUNT": nat.COUNT}
 _OUT_OF_SCOPE = (
-    "optimized_sequential_sample", "index_based_sample", "node_skip_sample", "balanced_tree_sample",
-    "direct_access_sample", "byte_offset_sample", "random_start_nth_sample", "address_arithmetic_sample",
+    "index_based_sample", "node_skip_sample", "balanced_tree_sample",
+    "byte_offset_sample", "random_start_nth_sample", "address_arithmetic_sample",
     "signal_based_clt_sample",
 )
 
@@ -313,6 +315,18 @@ class CustomBPlusDB:
     def optimized_address_arithmetic_sample(self, sample_percent, *, as_array=False):
         return self._gather(make_query(nat.M_ADDRESS_ARITHMETIC, sample_percent), as_array)
 
+    def direct_access_sample(self, sample_percent, *, as_array=False):
+        """custom_bplus_db.cpp:584-644 — what the reference CLI takes for 10 k < N <= 50 k rows: ~10 % of the B+ tree's leaves
+        at a fixed node step, evenly spaced records in each.  The leaves are those the reference builds from ascending inserts
+        (127 rows each, the last 128 ... 254); rows in the reference's order, duplicates included."""
+        return self._gather(make_query(nat.M_DIRECT_ACCESS, sample_percent), as_array)
+
+    def optimized_sequential_sample(self, sample_percent, *, seed=None, as_array=False):
+        """custom_bplus_db.cpp:366-428 — the reference CLI's sampler for N <= 10 k rows: systematic, step 100 / pct from a
+        random start (std::random_device there; seeded here)."""
+        seed = int.from_bytes(os.urandom(4), "little") if seed is None else int(seed) & 0xFFFFFFFF
+        return self._gather(make_query(nat.M_OPTIMIZED_SEQUENTIAL, sample_percent, seed=seed), as_array)
+
     def random_pointer_sample(self, sample_percent, seed=42, *, as_array=False):
         return self._gather(make_query(nat.M_RANDOM_POINTER, sample_percent, seed=int(seed) & 0xFFFFFFFF), as_array)
 
@@ -453,6 +467,7 @@ class CustomBPlusDB:
                 q.row_lo, q.row_hi = rows
         else:
             m = {"stride": nat.M_MEMORY_STRIDE, "random": nat.M_RANDOM_POINTER, "random_device": nat.M_RANDOM_DEVICE, "block": nat.M_BLOCK, "page": nat.M_PAGE,
+                 "direct_access": nat.M_DIRECT_ACCESS, "sequential": nat.M_OPTIMIZED_SEQUENTIAL,
                  "parallel_block": nat.M_PARALLEL_BLOCK, "region": nat.M_REGION_STRIDE, "exact": nat.M_EXACT,
                  "adaptive_block": nat.M_ADAPTIVE_BLOCK, "stratified_block": nat.M_STRATIFIED_BLOCK}[method]
             if method == "adaptive_block" and block_size == 1000:
@@ -473,7 +488,7 @@ class CustomBPlusDB:
         specs = [dict(kw) for kw in queries]
         qs = [self._approx_query(**kw) for kw in specs]
         out: "List[Optional[ApproxResult]]" = [None] * len(qs)
-        fused = [i for i, kw in enumerate(specs) if kw.get("method", "stride") not in ("random", "random_device")]
+        fused = [i for i, kw in enumerate(specs) if kw.get("method", "stride") not in ("random", "random_device", "direct_access", "sequential")]
         for i in set(range(len(qs))) - set(fused):
             out[i] = ApproxResult(self._reduce(qs[i]), specs[i].get("method", "stride"))
         if fused:

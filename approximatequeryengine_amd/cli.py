@@ -136,7 +136,10 @@ def run(args, out=sys.stdout) -> int:
     # honoured by every sampler that has a WHERE form; the reference CLI ignores it for scalar queries altogether
     where = aqe_backend.parse_where(clean)
     if qtype == QUERY_RANDOM:
-        m = {"block": "block", "parallel": "region", "random": "random"}.get(args.method or "", "stride")
+        # the reference CLI's own routing by table size when no method is named (enhanced_aqe_cli.py:178-186): memory stride
+        # above 50 k rows, direct access above 10 k, the sequential sampler below
+        auto = "stride" if n > 50_000 else "direct_access" if n > 10_000 else "sequential"
+        m = {"block": "block", "parallel": "region", "random": "random"}.get(args.method or "", auto)
         res = db.approx(agg, method=m, sample_percent=s, seed=args.seed, num_threads=args.threads, where=where)
         name = f"{m} sampling ({s}%)"
     elif qtype == QUERY_CLT:

@@ -125,6 +125,21 @@ int aqe_plan_random_indices(uint64_t n_global, double pct, uint32_t seed, uint64
     return AQE_OK;
 }
 
+int aqe_plan_row_list(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, uint64_t shard_hi, uint64_t* out, uint64_t cap, uint64_t* n_out) {
+    if (!q) return AQE_ERR_INVALID;
+    HostPlan P;
+    std::string err;
+    int rc = build_plan(*q, n_global, ClipWindow{shard_lo, shard_hi}, P, err);
+    if (rc != AQE_OK) return fail(nullptr, rc, err);
+    if (!P.is_random) return fail(nullptr, AQE_ERR_INVALID, "this sampler is a family sampler: use aqe_plan_families");
+    if (n_out) *n_out = P.random_idx.size();
+    if (out) {
+        if (cap < P.random_idx.size()) return fail(nullptr, AQE_ERR_CAPACITY, "index buffer too small");
+        std::copy(P.random_idx.begin(), P.random_idx.end(), out);
+    }
+    return AQE_OK;
+}
+
 int aqe_parse_where(const char* query, double* lo, double* hi) {
     double a, b;
     bool found = parse_where(query, &a, &b);

@@ -167,6 +167,85 @@ int random_pointer_indices(u64 N, double pct, uint32_t seed, ClipWindow shard, s
     return AQE_OK;
 }
 
+// ---- the CLI's samplers for small tables (enhanced_aqe_cli.py:181-186): explicit index lists, like random_pointer_sample ----
+
+// Leaf sizes of the reference's B+ tree after N ascending inserts (what insert_batch — it sorts by id, DB.cpp:196-208 —
+// and load_from_file produce): a leaf splits when it reaches MAX_KEYS = 255 keys, keeps MAX_KEYS / 2 = 127 and hands 128
+// to the new right sibling (DB.cpp:43-62, 211-221), which alone grows from then on.  So every leaf but the last holds 127
+// rows and the last one 128 ... 254 (a table below 255 rows is one leaf).
+void reference_leaves(u64 N, u64& full_leaves, u64& last_size) {
+    if (N < 255) { full_leaves = 0; last_size = N; return; }
+    full_leaves = (N - 255) / 127 + 1;
+    last_size = N - 127 * full_leaves;
+}
+
+// direct_access_sample (DB.cpp:584-644): ~10 % of the leaves at a fixed node step, evenly spaced records inside each.
+// Rows in the reference's order (ascending leaves; a leaf visited twice — more nodes asked for than the tree has — gives
+// its rows twice: duplicates are part of the reference's sample).
+int direct_access_indices(u64 N, double pct, ClipWindow shard, std::vector<u64>& out, u64& global_samples, std::string& err) {
+    out.clear();
+    global_samples = 0;
+    if (N == 0 || !(pct > 0.0)) return AQE_OK;
+    auto emit = [&](u64 row) { ++global_samples; if (row >= shard.lo && row < shard.hi) out.push_back(row); };
+    if (pct >= 100.0) { for (u64 i = 0; i < N; ++i) emit(i); return AQE_OK; }
+    const u64 target = static_cast<u64>(static_cast<double>(N) * pct / 100.0);  // size_t(total * pct / 100.0)
+    u64 full = 0, last = 0;
+    reference_leaves(N, full, last);
+    const u64 L = full + 1;
+    if (L > 0x7fffffffull) AQE_FAIL("direct_access_sample: table too large");
+    const u64 nodes_to_sample = std::max<u64>(1, target / 10);
+    const double node_step = static_cast<double>(L) / static_cast<double>(nodes_to_sample);
+    u64 count = 0;
+    for (u64 i = 0; i < nodes_to_sample && count < target; ++i) {
+        const u64 node = static_cast<u64>(static_cast<double>(i) * node_step);
+        if (node >= L) continue;
+        const int kc = static_cast<int>(node < full ? 127 : last);
+        const u64 start = node < full ? node * 127 : full * 127;
+        int rpn = std::max(1, static_cast<int>(target / nodes_to_sample));
+        rpn = std::min(rpn, kc);
+        const double record_step = static_cast<double>(kc) / rpn;
+        for (int j = 0; j < rpn && count < target; ++j) {
+            const int ri = static_cast<int>(j * record_step);
+            if (ri < kc) { emit(start + static_cast<u64>(ri)); ++count; }
+        }
+    }
+    return AQE_OK;
+}
+
+// optimized_sequential_sample (DB.cpp:366-428): systematic, one row whenever the running count reaches the next sample
+// point, which advances by step = 100 / pct (a double, accumulated as the reference accumulates it) from a start in
+// [0, step).  The reference draws the start from std::random_device; here it comes from the query's seed the way
+// libstdc++ would draw it from mt19937(seed): uniform_real_distribution<double>(0, step) = generate_canonical<double, 53>
+// (two 32-bit draws, low word first) * step.
+int optimized_sequential_indices(u64 N, double pct, uint32_t seed, ClipWindow shard, std::vector<u64>& out, u64& global_samples, std::string& err) {
+    (void)err;
+    out.clear();
+    global_samples = 0;
+    if (N == 0 || !(pct > 0.0)) return AQE_OK;
+    auto emit = [&](u64 row) { ++global_samples; if (row >= shard.lo && row < shard.hi) out.push_back(row); };
+    if (pct >= 100.0) { for (u64 i = 0; i < N; ++i) emit(i); return AQE_OK; }
+    const u64 target = static_cast<u64>(static_cast<double>(N) * pct / 100.0);
+    if (target == 0) return AQE_OK;
+    const double step = 100.0 / pct;
+    Mt19937 g(seed);
+    const double lo32 = static_cast<double>(g.next()), hi32 = static_cast<double>(g.next());
+    double canon = (lo32 + hi32 * 4294967296.0) / 18446744073709551616.0;
+    if (canon >= 1.0) canon = std::nextafter(1.0, 0.0);
+    double next = canon * step + 0.0;  // (b - a) * canonical + a
+    u64 taken = 0, count = 0;
+    while (taken < target) {
+        // the first running count (1-based) with count >= next: rows are visited one by one, a row is taken at most once
+        u64 c = next <= 1.0 ? 1 : static_cast<u64>(std::ceil(next));
+        if (c <= count) c = count + 1;
+        if (c > N) break;
+        count = c;
+        emit(c - 1);
+        ++taken;
+        next += step;
+    }
+    return AQE_OK;
+}
+
 static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPlan& P, std::string& err, const double* zone_var);
 
 // Row window (key-range pruning): plan over the window as if it were the whole table, then shift.
@@ -434,6 +513,16 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
             int target = N ? target_of(N, pct) : 0;
             P.global_samples = target > 0 ? std::min<u64>(static_cast<u64>(target), N) : 0;
             return AQE_OK;
+        }
+        case AQE_M_DIRECT_ACCESS: {
+            P.is_random = true;  // (an explicit row list: the kernels of the seeded-random sampler)
+            P.rounds = 1;
+            return direct_access_indices(N, pct, shard, P.random_idx, P.global_samples, err);
+        }
+        case AQE_M_OPTIMIZED_SEQUENTIAL: {
+            P.is_random = true;
+            P.rounds = 1;
+            return optimized_sequential_indices(N, pct, static_cast<uint32_t>(q.seed), shard, P.random_idx, P.global_samples, err);
         }
         case AQE_M_RANDOM_DEVICE: {  // sample_records' semantics (DB.cpp:345-363: a uniform prefix of a shuffle), drawn on the device
             P.is_perm = true;

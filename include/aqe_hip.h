@@ -81,7 +81,7 @@ typedef enum aqe_method {
                                      rowid = row + 1 (executor.cpp:21-26, 36-41); sample_percent >= 100: every row */
     AQE_M_STRATIFIED_BLOCK = 16,  /* stratified_block_sample, DB.cpp:1331-1379: blocks of the amount-SORTED table (needs a
                                      device sort of the column, cached per table); num_threads = strata_count */
-    AQE_M_RANDOM_DEVICE = 18      /* a simple random sample WITHOUT replacement of int(N pct/100) rows, drawn on the device:
+    AQE_M_RANDOM_DEVICE = 18,     /* a simple random sample WITHOUT replacement of int(N pct/100) rows, drawn on the device:
                                      row = P_seed(k), k = 0 .. target-1, where P_seed is a keyed bijection of [0, N) (multiply /
                                      xor-shift rounds on ceil(log2 N) bits, cycle-walked into [0, N)).  Counter-based: no host
                                      index list (RANDOM_POINTER draws mt19937 + Lemire on the host, 4.7 ns per index), any grid,
@@ -89,6 +89,16 @@ typedef enum aqe_method {
                                      seeded samplers (sample_records, DB.cpp:345-363: shuffle all rows, take a prefix — hence
                                      parallel_{sum,avg,count}[_where]_sample, DB.cpp:276-343), which admit statistical parity
                                      only; RANDOM_POINTER stays the bit-exact restatement of random_pointer_sample(seed) */
+    AQE_M_DIRECT_ACCESS = 19,     /* direct_access_sample, DB.cpp:584-644 — what the reference CLI takes for 10 k < N <= 50 k rows
+                                     (CLI:181-183): ~10 % of the B+ tree's leaves at a fixed node step, evenly spaced records in
+                                     each.  The leaves are those the reference builds from ascending inserts (insert_batch sorts
+                                     by id; load_from_file): 127 rows each, the last 128 ... 254.  Deterministic; a leaf visited
+                                     twice gives its rows twice, as in the reference.  An explicit row list (k_indexed) */
+    AQE_M_OPTIMIZED_SEQUENTIAL = 20 /* optimized_sequential_sample, DB.cpp:366-428 — the CLI's sampler for N <= 10 k rows
+                                     (CLI:184-186): one row whenever the running count reaches the next sample point, which
+                                     advances by 100 / pct from a random start in [0, 100 / pct).  The reference seeds the start
+                                     from std::random_device (statistical parity only); here `seed` feeds mt19937 the way
+                                     libstdc++'s uniform_real_distribution would read it */
 } aqe_method;
 
 typedef enum aqe_agg { AQE_SUM = 0, AQE_AVG = 1, AQE_COUNT = 2 } aqe_agg;
@@ -273,6 +283,10 @@ AQE_API int aqe_plan_adaptive_families(const aqe_query* q, uint64_t n_global, co
 /* Ascending unique indices of random_pointer_sample(pct, seed) that fall in [shard_lo, shard_hi). */
 AQE_API int aqe_plan_random_indices(uint64_t n_global, double pct, uint32_t seed, uint64_t shard_lo,
                                     uint64_t shard_hi, uint64_t* out, uint64_t cap, uint64_t* n_out);
+/* The explicit row list of a sampler that has no families — RANDOM_POINTER, DIRECT_ACCESS, OPTIMIZED_SEQUENTIAL — in the
+ * reference's order, restricted to [shard_lo, shard_hi) (a row window of the query applies). */
+AQE_API int aqe_plan_row_list(const aqe_query* q, uint64_t n_global, uint64_t shard_lo, uint64_t shard_hi, uint64_t* out,
+                              uint64_t cap, uint64_t* n_out);
 /* WHERE-range extraction of the façade (SCH.cpp:277-294): returns 1 and fills lo/hi, 0 if none. */
 AQE_API int aqe_parse_where(const char* query, double* lo, double* hi);
 AQE_API double aqe_confidence_heuristic(double sample_percent, uint64_t total_records); /* SCH.cpp:296-305 */

@@ -236,6 +236,96 @@ int64_t aqo_idx_random_pointer(uint64_t N, double pct, uint32_t seed, uint64_t* 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * R2's small-table siblings — what the reference CLI takes below 50 k rows (enhanced_aqe_cli.py:181-186)
+ * ---------------------------------------------------------------------------------------------- */
+/* Leaf sizes of the reference's B+ tree after N ascending inserts, by SIMULATING the inserts (DB.cpp:164-240 with
+ * BPlusTreeNode::split, DB.cpp:43-62): the rightmost leaf takes every row; at MAX_KEYS = 255 keys it splits, keeps
+ * MAX_KEYS / 2 = 127 and hands the rest to a new right sibling.  Returns the number of leaves (sizes[] may be NULL). */
+int64_t aqo_leaf_sizes(uint64_t N, uint32_t* sizes, int64_t cap) {
+    int64_t leaves = N ? 1 : 0;
+    uint32_t cur = 0;
+    for (uint64_t i = 0; i < N; ++i) {
+        ++cur;
+        if (cur >= 255) { /* insert_into_node reports a full leaf; the parent splits it */
+            if (sizes && leaves - 1 < cap) sizes[leaves - 1] = 255 / 2;
+            cur -= 255 / 2;
+            ++leaves;
+        }
+    }
+    if (N && sizes && leaves - 1 < cap) sizes[leaves - 1] = cur;
+    return leaves;
+}
+
+/* direct_access_sample, DB.cpp:584-644: rows in the reference's order (duplicates included). */
+int64_t aqo_idx_direct_access(uint64_t N, double pct, uint64_t* out, int64_t cap) {
+    sink s = {out, cap, 0};
+    if (N == 0 || !(pct > 0.0)) return 0;
+    if (pct >= 100.0) { for (uint64_t i = 0; i < N; ++i) emit(&s, i); return s.n; }
+    uint64_t target = (uint64_t)((double)N * pct / 100.0); /* DB.cpp:593 */
+    int64_t L = aqo_leaf_sizes(N, NULL, 0);
+    uint32_t* sz = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)L);
+    uint64_t* first = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)L);
+    if (!sz || !first) { free(sz); free(first); return -1; }
+    aqo_leaf_sizes(N, sz, L);
+    uint64_t acc = 0;
+    for (int64_t l = 0; l < L; ++l) { first[l] = acc; acc += sz[l]; }
+    uint64_t nodes_to_sample = umax(1, target / 10);                 /* DB.cpp:621 */
+    double node_step = (double)L / (double)nodes_to_sample;           /* DB.cpp:622 */
+    uint64_t count = 0;
+    for (uint64_t i = 0; i < nodes_to_sample && count < target; ++i) {
+        uint64_t node_index = (uint64_t)((double)i * node_step);
+        if (node_index < (uint64_t)L) {
+            int key_count = (int)sz[node_index];
+            int records_per_node = (int)(target / nodes_to_sample);
+            if (records_per_node < 1) records_per_node = 1;
+            if (records_per_node > key_count) records_per_node = key_count;
+            double record_step = (double)key_count / records_per_node;
+            for (int j = 0; j < records_per_node && count < target; ++j) {
+                int record_index = (int)(j * record_step);
+                if (record_index < key_count) { emit(&s, first[node_index] + (uint64_t)record_index); ++count; }
+            }
+        }
+    }
+    free(sz);
+    free(first);
+    return s.n;
+}
+
+/* libstdc++ 11: std::uniform_real_distribution<double>(0, hi)(std::mt19937(seed)) = generate_canonical<double, 53>
+ * (bits/random.tcc: k = 2 draws, sum = g0 + g1 * 2^32, / 2^64, clamped below 1) * (hi - 0) + 0. */
+double aqo_uniform_real(uint32_t seed, double hi) {
+    mt19937 g;
+    mt_seed(&g, seed);
+    double sum = (double)mt_next(&g);
+    sum += (double)mt_next(&g) * 4294967296.0;
+    double r = sum / 18446744073709551616.0;
+    if (r >= 1.0) r = nextafter(1.0, 0.0);
+    return r * hi;
+}
+
+/* optimized_sequential_sample, DB.cpp:366-428, walked record by record as the reference walks its leaves; the start offset
+ * (std::random_device there) from mt19937(seed). */
+int64_t aqo_idx_optimized_sequential(uint64_t N, double pct, uint32_t seed, uint64_t* out, int64_t cap) {
+    sink s = {out, cap, 0};
+    if (N == 0 || !(pct > 0.0)) return 0;
+    if (pct >= 100.0) { for (uint64_t i = 0; i < N; ++i) emit(&s, i); return s.n; }
+    uint64_t target = (uint64_t)((double)N * pct / 100.0);
+    if (target == 0) return 0;
+    double step = 100.0 / pct;
+    double next_sample_point = aqo_uniform_real(seed, step);
+    uint64_t current_count = 0, taken = 0;
+    for (uint64_t i = 0; i < N && taken < target; ++i) {
+        current_count++;
+        if ((double)current_count >= next_sample_point && taken < target) {
+            emit(&s, i);
+            ++taken;
+            next_sample_point += step;
+        }
+    }
+    return s.n;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * R4 — block family
  * ---------------------------------------------------------------------------------------------- */
 /* DB.cpp:1151-1181. */

@@ -52,6 +52,10 @@ int64_t aqo_idx_address_arithmetic(uint64_t M, double pct, uint64_t* out, int64_
 int64_t aqo_idx_random_start_stride(uint64_t M, double pct, uint64_t stride_bytes, uint64_t seed,
                                     const uint64_t* start_override, uint64_t* out, int64_t cap);
 int64_t aqo_idx_random_pointer(uint64_t N, double pct, uint32_t seed, uint64_t* out, int64_t cap);
+int64_t aqo_leaf_sizes(uint64_t N, uint32_t* sizes, int64_t cap);                               /* DB.cpp:164-240, 43-62 */
+int64_t aqo_idx_direct_access(uint64_t N, double pct, uint64_t* out, int64_t cap);              /* DB.cpp:584-644 */
+double aqo_uniform_real(uint32_t seed, double hi);                                              /* libstdc++ uniform_real_distribution over mt19937 */
+int64_t aqo_idx_optimized_sequential(uint64_t N, double pct, uint32_t seed, uint64_t* out, int64_t cap); /* DB.cpp:366-428 */
 int64_t aqo_idx_block(uint64_t N, double pct, uint64_t block_rows, uint64_t* out, int64_t cap);
 int64_t aqo_idx_page(uint64_t N, double pct, uint64_t page_bytes, uint64_t* out, int64_t cap);
 int64_t aqo_idx_parallel_block(uint64_t N, double pct, uint64_t block_rows, int T, uint64_t* out, int64_t cap);

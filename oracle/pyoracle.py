@@ -90,6 +90,8 @@ class Oracle:
             "aqo_idx_memory_stride": [C.c_uint64],
             "aqo_idx_address_arithmetic": [],
             "aqo_idx_random_pointer": [C.c_uint32],
+            "aqo_idx_direct_access": [],
+            "aqo_idx_optimized_sequential": [C.c_uint32],
             "aqo_idx_block": [C.c_uint64],
             "aqo_idx_page": [C.c_uint64],
             "aqo_idx_parallel_block": [C.c_uint64, C.c_int],
@@ -210,6 +212,22 @@ class Oracle:
     def idx_memory_stride(self, M, pct, stride_bytes=0): return self._idx("aqo_idx_memory_stride", M, pct, stride_bytes)
     def idx_address_arithmetic(self, M, pct): return self._idx("aqo_idx_address_arithmetic", M, pct)
     def idx_random_pointer(self, N, pct, seed=42): return self._idx("aqo_idx_random_pointer", N, pct, seed)
+    def idx_direct_access(self, N, pct): return self._idx("aqo_idx_direct_access", N, pct)
+    def idx_optimized_sequential(self, N, pct, seed=42): return self._idx("aqo_idx_optimized_sequential", N, pct, seed)
+
+    def leaf_sizes(self, N):
+        self.lib.aqo_leaf_sizes.restype = C.c_int64
+        self.lib.aqo_leaf_sizes.argtypes = [C.c_uint64, C.c_void_p, C.c_int64]
+        n = self.lib.aqo_leaf_sizes(N, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self.lib.aqo_leaf_sizes(N, out.ctypes.data, n)
+        return out[:n]
+
+    def uniform_real(self, seed, hi):
+        self.lib.aqo_uniform_real.restype = C.c_double
+        self.lib.aqo_uniform_real.argtypes = [C.c_uint32, C.c_double]
+        return self.lib.aqo_uniform_real(seed, hi)
+
     def idx_block(self, N, pct, B=1000): return self._idx("aqo_idx_block", N, pct, B)
     def idx_page(self, N, pct, page=4096): return self._idx("aqo_idx_page", N, pct, page)
     def idx_parallel_block(self, N, pct, B=1000, T=4): return self._idx("aqo_idx_parallel_block", N, pct, B, T)
@@ -337,7 +355,7 @@ REF_METHODS = {
     "clt_validated_dual_pointer_sample": 8, "fast_pointer_sample": 9, "slow_pointer_sample": 10,
     "dual_pointer_sample": 11, "parallel_pointer_sample": 12, "multithreaded_memory_stride_sample": 13,
     "random_start_memory_stride_sample": 14, "signal_based_clt_sample": 15, "sample_records": 16,
-    "adaptive_block_sample": 17, "stratified_block_sample": 18,
+    "adaptive_block_sample": 17, "stratified_block_sample": 18, "direct_access_sample": 19, "optimized_sequential_sample": 20,
 }
 
 
@@ -421,6 +439,21 @@ class Ref:
         return self.lib.ref_parallel_sum_where_sample(self.h, lo, hi, pct, t)
     def fast_aggregated_memory_stride_sum(self, pct, t=4):
         return self.lib.ref_fast_aggregated_memory_stride_sum(self.h, pct, t)
+
+    def leaf_sizes(self):
+        """key_count of every leaf, in leaf order (the next_leaf chain)."""
+        self.lib.ref_leaf_sizes.restype = C.c_int64
+        self.lib.ref_leaf_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        n = self.lib.ref_leaf_sizes(self.h, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self.lib.ref_leaf_sizes(self.h, out.ctypes.data, n)
+        return out[:n]
+
+    def uniform_real(self, seed, hi):
+        """std::uniform_real_distribution<double>(0, hi)(std::mt19937(seed)) of this container's libstdc++."""
+        self.lib.ref_uniform_real.restype = C.c_double
+        self.lib.ref_uniform_real.argtypes = [C.c_uint32, C.c_double]
+        return self.lib.ref_uniform_real(seed, hi)
 
     def sample(self, method: str, pct: float, a=0.0, b=0.0, c=0.0, d=0.0):
         """Run a sampler; returns the ids (np.int64, reference order) or None if it threw."""

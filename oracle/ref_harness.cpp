@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <exception>
+#include <random>
 #include <string>
 #include <utility>
 #include <vector>
@@ -134,6 +135,8 @@ int64_t ref_sample(void* h, int method, double pct, double a, double b, double c
             case 16: H->last = db.sample_records(pct); break;
             case 17: H->last = db.adaptive_block_sample(pct, static_cast<size_t>(a), static_cast<size_t>(b)); break;
             case 18: H->last = db.stratified_block_sample(pct, static_cast<size_t>(a), static_cast<int>(b)); break;
+            case 19: H->last = db.direct_access_sample(pct); break;         // needs the real tree: ref_fill_insert
+            case 20: H->last = db.optimized_sequential_sample(pct); break;  // std::random_device start: statistical
             default: return -2;
         }
     } catch (const std::exception&) {
@@ -162,6 +165,25 @@ int64_t ref_last_rows(void* h, void* out32, int64_t cap) {
     int64_t m = n < cap ? n : cap;
     if (m > 0) std::memcpy(out32, H->last.data(), static_cast<size_t>(m) * sizeof(Record));
     return n;
+}
+
+// key_count of every leaf in leaf order (leftmost leaf, then the next_leaf chain): pins the restatement's leaf model
+int64_t ref_leaf_sizes(void* h, uint32_t* out, int64_t cap) {
+    auto* H = static_cast<Handle*>(h);
+    auto node = H->db.root;
+    while (node && !node->is_leaf) node = node->children.empty() ? nullptr : node->children[0];
+    int64_t n = 0;
+    for (; node; node = node->next_leaf, ++n)
+        if (out && n < cap) out[n] = static_cast<uint32_t>(node->key_count);
+    return n;
+}
+
+// this container's libstdc++: what optimized_sequential_sample's start offset would be were its generator mt19937(seed)
+// (the reference seeds it from std::random_device).  No reference code involved: <random> only.
+double ref_uniform_real(uint32_t seed, double hi) {
+    std::mt19937 gen(seed);
+    std::uniform_real_distribution<> dis(0.0, hi);
+    return dis(gen);
 }
 
 int ref_save_to_file(void* h, const char* path) {

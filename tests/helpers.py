@@ -27,6 +27,10 @@ def oracle_indices(o, rows, call, cache_rows=None):
         return o.idx_address_arithmetic(M, pct)
     if m == "random_pointer_sample":
         return o.idx_random_pointer(N, pct, int(a[0]))
+    if m == "direct_access_sample":
+        return o.idx_direct_access(N, pct)
+    if m == "optimized_sequential_sample":
+        return o.idx_optimized_sequential(N, pct, int(a[0]))
     if m == "block_sample":
         return o.idx_block(N, pct, int(a[0]))
     if m == "page_sample":

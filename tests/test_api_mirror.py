@@ -29,9 +29,9 @@ def test_record_and_result_types_have_the_reference_fields():
                  "random_pointer_sample", "clt_validated_dual_pointer_sample", "optimized_clt_sample", "block_sample",
                  "page_sample", "parallel_block_sample", "memory_stride_sample", "optimized_address_arithmetic_sample",
                  "multithreaded_memory_stride_sample", "fast_aggregated_memory_stride_sum",
-                 "random_start_memory_stride_sample"):  # bindings.cpp:44-101
+                 "random_start_memory_stride_sample", "direct_access_sample", "optimized_sequential_sample"):  # bindings.cpp:44-101
         assert callable(getattr(db, name)), name
-    for name in ("index_based_sample", "node_skip_sample", "signal_based_clt_sample", "direct_access_sample"):
+    for name in ("index_based_sample", "node_skip_sample", "signal_based_clt_sample", "balanced_tree_sample"):
         with pytest.raises(NotImplementedError):
             getattr(db, name)(10.0)
     s = m.CustomApproximateScheduler()
@@ -223,6 +223,15 @@ def test_cli_end_to_end(tmp_path, oracle, table):
         out = io.StringIO()
         assert cli.run(cli.build_parser().parse_args(argv), out) == 0, out.getvalue()
         assert frag in out.getvalue(), out.getvalue()
+    # the reference CLI's routing by table size (enhanced_aqe_cli.py:178-186): direct access above 10 k rows, sequential below
+    for n_small, frag in ((20_000, "direct_access sampling (5.0%)"), (5_000, "sequential sampling (5.0%)")):
+        ps = tmp_path / f"small{n_small}.db"
+        assert oracle.file_write(ps, rows[:n_small]) == 0
+        out = io.StringIO()
+        assert cli.run(cli.build_parser().parse_args(["SELECT AVG(amount) FROM sales", "--db", str(ps), "--s", "5", "--ci"]), out) == 0, out.getvalue()
+        assert frag in out.getvalue(), out.getvalue()
+        val = float(out.getvalue().split("value:")[1].split()[0].replace(",", ""))
+        assert abs(val - float(rows["amount"][:n_small].mean())) < 30.0
     out = io.StringIO()
     cli.run(cli.build_parser().parse_args(["SELECT SUM(amount) FROM sales", "--db", str(p)]), out)
     val = float(out.getvalue().split("value:")[1].split()[0].replace(",", ""))

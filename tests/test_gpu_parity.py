@@ -53,6 +53,8 @@ def _query_for(nat, call):
         "memory_stride_sample": lambda: make_query(nat.M_MEMORY_STRIDE, pct, stride_bytes=int(a[0])),
         "optimized_address_arithmetic_sample": lambda: make_query(nat.M_ADDRESS_ARITHMETIC, pct),
         "random_pointer_sample": lambda: make_query(nat.M_RANDOM_POINTER, pct, seed=int(a[0])),
+        "direct_access_sample": lambda: make_query(nat.M_DIRECT_ACCESS, pct),
+        "optimized_sequential_sample": lambda: make_query(nat.M_OPTIMIZED_SEQUENTIAL, pct, seed=int(a[0])),
         "block_sample": lambda: make_query(nat.M_BLOCK, pct, block_size=int(a[0])),
         "page_sample": lambda: make_query(nat.M_PAGE, pct, block_size=int(a[0])),
         "parallel_block_sample": lambda: make_query(nat.M_PARALLEL_BLOCK, pct, block_size=int(a[0]), num_threads=int(a[1])),
@@ -274,6 +276,35 @@ def test_clt_monitor_matches_oracle(nat, oracle, table, engines, case):
     assert rel(res.ci_lower, lo) <= EST_TOL and rel(res.ci_upper, hi) <= EST_TOL
     got = eng.gather(q)
     assert np.array_equal(np.sort(got["id"] - 1), np.sort(idx.astype(np.int64)))
+
+
+def test_small_table_samplers_against_the_reference_fixture(nat, oracle):
+    """direct_access_sample / optimized_sequential_sample (what the reference CLI takes below 50 k rows): the HIP reduce and
+    gather against the reference's recorded rows (tests/golden/small_tables.json) and the oracle."""
+    import json, os
+    from approximatequeryengine_amd.engine import Engine, make_query
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "small_tables.json")))
+    for n_s, T in G["tables"].items():
+        n = int(n_s)
+        rows = oracle.synth(n, G["seed"])
+        with Engine(0) as eng:
+            eng.stage_records(rows, keep_aos=True)
+            for d in T["direct_access"]:
+                q = make_query(nat.M_DIRECT_ACCESS, d["pct"])
+                got = eng.gather(q)
+                assert digest(got["id"] - 1) == d["idx"], (n, d["pct"])  # the reference's rows, in its order, duplicates included
+                idx = oracle.idx_direct_access(n, d["pct"])
+                if len(idx):
+                    _check_against_oracle(nat, oracle, eng, rows, q, idx)
+                    q.has_where, q.where_min, q.where_max = 1, 200.0, 640.0
+                    _check_against_oracle(nat, oracle, eng, rows, q, idx, where=(200.0, 640.0))
+            for pct, seed in ((1.0, 5), (12.5, 42), (37.5, 77)):
+                q = make_query(nat.M_OPTIMIZED_SEQUENTIAL, pct, seed=seed)
+                idx = oracle.idx_optimized_sequential(n, pct, seed)
+                got = eng.gather(q)
+                assert np.array_equal(got["id"] - 1, idx.astype(np.int64))
+                if len(idx):
+                    _check_against_oracle(nat, oracle, eng, rows, q, idx)
 
 
 def test_clt_on_the_heterogeneous_table_of_the_reference_fixture(nat, oracle):
@@ -508,7 +539,7 @@ def test_randomised_sampler_parameters_against_the_oracle(nat, oracle):
                 pct = float(pick(0.01, 0.37, 1.0, 3.3, 10.0, 25.0, 50.0, 99.0, 100.0, round(float(rng.uniform(0.05, 60.0)), 3)))
                 m = pick("memory_stride_sample", "optimized_address_arithmetic_sample", "block_sample", "page_sample", "parallel_block_sample",
                          "optimized_clt_sample", "fast_pointer_sample", "slow_pointer_sample", "dual_pointer_sample", "parallel_pointer_sample",
-                         "random_pointer_sample", "clt_validated_dual_pointer_sample")
+                         "random_pointer_sample", "clt_validated_dual_pointer_sample", "direct_access_sample", "optimized_sequential_sample")
                 args = {"memory_stride_sample": [int(pick(0, 32, 64, 96, 320, 3200, 32 * int(rng.integers(1, 500))))],
                         "optimized_address_arithmetic_sample": [],
                         "block_sample": [int(pick(1, 7, 100, 1000, 4096, int(rng.integers(1, 6000))))],
@@ -519,6 +550,7 @@ def test_randomised_sampler_parameters_against_the_oracle(nat, oracle):
                         "slow_pointer_sample": [], "dual_pointer_sample": [],
                         "parallel_pointer_sample": [int(rng.integers(1, 9))],
                         "random_pointer_sample": [int(rng.integers(0, 2**31 - 1))],
+                        "direct_access_sample": [], "optimized_sequential_sample": [int(rng.integers(0, 2**31 - 1))],
                         "clt_validated_dual_pointer_sample": [float(pick(0.9, 0.95, 0.99)), int(pick(4, 10, 25)), int(pick(1, 2, 4, 6)), float(pick(0.0, 0.5, 2.0, 5.0))]}[m]
                 if m == "clt_validated_dual_pointer_sample" and n > 60_000:
                     continue  # (the reference's cadence: tens of thousands of rounds on a big table; covered by CLT_CASES)

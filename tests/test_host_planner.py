@@ -313,3 +313,25 @@ def test_device_sampler_permutation_is_a_uniform_sample_without_replacement():
     est = np.array([x[perm_rows(N, 1.0, s).astype(np.int64)].sum() * 100 for s in range(100)])
     sd_theory = x.std() * 100 * np.sqrt(tgt) * np.sqrt(1 - tgt / N)
     assert abs(est.mean() - x.sum()) < 4 * sd_theory / 10 and 0.75 * sd_theory < est.std() < 1.3 * sd_theory
+
+
+def test_row_lists_of_the_small_table_samplers_match_the_oracle(oracle):
+    """aqe_plan_row_list (planner.cpp: closed-form leaf model, sample points by ceil) against the oracle (inserts simulated,
+    records walked one by one) — whole tables, shards, row windows."""
+    from approximatequeryengine_amd import _native as nat
+    from approximatequeryengine_amd.engine import make_query
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 100, 254, 255, 256, 381, 382, 383, 1_000, 9_999, 10_001, 20_000, 50_000, 123_457):
+        for pct in (0.0, 0.3, 1.0, 5.0, 12.5, 20.0, 37.5, 99.0, 100.0):
+            da = nat.plan_row_list(make_query(nat.M_DIRECT_ACCESS, pct), n)
+            assert np.array_equal(da, oracle.idx_direct_access(n, pct)), (n, pct)
+            seed = int(rng.integers(0, 2**32))
+            sq = nat.plan_row_list(make_query(nat.M_OPTIMIZED_SEQUENTIAL, pct, seed=seed), n)
+            assert np.array_equal(sq, oracle.idx_optimized_sequential(n, pct, seed)), (n, pct, seed)
+            if n >= 1000:  # a shard keeps the rows it holds, in order
+                lo, hi = n // 3, 2 * n // 3
+                part = nat.plan_row_list(make_query(nat.M_DIRECT_ACCESS, pct), n, lo, hi)
+                assert np.array_equal(part, da[(da >= lo) & (da < hi)])
+    # a row window is the table (key-range pruning): rows relative to the window, shifted back
+    q = make_query(nat.M_DIRECT_ACCESS, 10.0, rows=(5_000, 25_000))
+    assert np.array_equal(nat.plan_row_list(q, 100_000), oracle.idx_direct_access(20_000, 10.0) + 5_000)

@@ -369,3 +369,54 @@ def test_clt_on_a_heterogeneous_table_against_the_reference(oracle):
             assert ours_collected == case["T"] * res.fast.n
         else:
             assert ours_collected >= max(ref_collected), (case["T"], case["e"], ours_collected, max(ref_collected))
+
+
+def _small():
+    return json.loads((Path(__file__).parent / "golden" / "small_tables.json").read_text())
+
+
+def test_small_table_samplers_of_the_reference_cli(oracle):
+    """The samplers the reference CLI routes small tables to (enhanced_aqe_cli.py:181-186), against the reference's own runs
+    on tables built through insert_record (tests/golden/small_tables.json, oracle/make_golden_small.py): the leaf shape of
+    the B+ tree, direct_access_sample's exact rows (duplicates included), libstdc++'s uniform_real over mt19937, and every
+    recorded run of optimized_sequential_sample (std::random_device start) as the restatement's rows for SOME start."""
+    G = _small()
+    for u in G["uniform_real"]:
+        assert oracle.uniform_real(u["seed"], u["hi"]) == u["value"], u
+    for n_s, T in G["tables"].items():
+        n = int(n_s)
+        ls = oracle.leaf_sizes(n)
+        assert (len(ls), int(ls[0]), int(ls[-1])) == (T["leaves"], T["leaf_first"], T["leaf_last"])
+        assert sorted(set(int(x) for x in ls[:-1])) == T["leaf_sizes_distinct_inner"] and int(ls.sum()) == n
+        for d in T["direct_access"]:
+            idx = oracle.idx_direct_access(n, d["pct"])
+            assert digest(idx) == d["idx"], (n, d["pct"])
+            assert len(np.unique(idx)) == d["distinct"]
+        for case in T["optimized_sequential"]:
+            pct = case["pct"]
+            step = 100.0 / pct
+            target = int(n * pct / 100.0)
+            for run in case["runs"]:
+                rows = np.asarray(run if isinstance(run, list) else run["first"], dtype=np.int64)
+                count = len(run) if isinstance(run, list) else run["n"]
+                if pct >= 100.0:
+                    assert count == n
+                    continue
+                assert count <= target and count >= target - 1  # (the table can end one sample point short of the target)
+                if len(rows) == 0:
+                    continue
+                # row k is the first with (row + 1) >= start + k step: start lies in (row_k - k step, row_k + 1 - k step] for every k
+                k = np.arange(len(rows), dtype=np.float64)
+                lo = float(np.max(rows - k * step)), float(np.min(rows + 1.0 - k * step))
+                assert lo[0] < lo[1] + 1e-9 and lo[1] > -1e-9 and lo[0] < step + 1e-9, (n, pct, lo)
+    # the seeded form: the restatement's rows for seed s are those of a start equal to libstdc++'s draw
+    for n, pct, seed in ((9_999, 3.0, 42), (2_000, 37.5, 7), (300, 10.0, 0)):
+        idx = oracle.idx_optimized_sequential(n, pct, seed).astype(np.int64)
+        start, step = oracle.uniform_real(seed, 100.0 / pct), 100.0 / pct
+        assert len(idx) == int(n * pct / 100.0)
+        want, nxt = [], start
+        for c in range(1, n + 1):
+            if c >= nxt and len(want) < len(idx):
+                want.append(c - 1)
+                nxt += step
+        assert want == [int(x) for x in idx]
