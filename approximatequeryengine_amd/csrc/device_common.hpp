@@ -79,6 +79,16 @@ __device__ __forceinline__ double read_lane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// One lane of a wave has written LDS words that the other lanes of the SAME wave read next (a result parked for a
+// wave-wide store).  The hardware keeps a wave's LDS accesses in order, but the compiler orders each thread on its own:
+// without this it is free to run the readers' side of the branch before the writer's (it did, in k_round).  The
+// convergent wave barrier pins the join; the wavefront-scope fences pin the accesses to their side of it.
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct Acc {
     double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
     unsigned na = 0, nb = 0, nv = 0;

@@ -498,7 +498,8 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
         }
     }
     lean_judge(T, tot, static_cast<unsigned>(lane), t0, epoch, lds_res);
-    lean_send_result(T, lds_res, static_cast<unsigned>(lane));  // (same wave: LDS accesses of a wave are in order)
+    wave_lds_handoff();  // (the finishing lane's words, read by the whole wave)
+    lean_send_result(T, lds_res, static_cast<unsigned>(lane));
 }
 
 template <bool kNT, bool kWide>
