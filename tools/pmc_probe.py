@@ -1,7 +1,7 @@
 """Run under `rocprofv3 --pmc FETCH_SIZE` (and WRITE_SIZE in a second pass): a dense exact scan of the 10 M-row
 amount column (known traffic: 80 MB of 8-byte-per-lane coalesced loads) to calibrate the counter for this
-library's access width, then the bench step (ONE k_sweep_multi launch for a batch of 32 queries), the single-query
-launch (k_sweep_persist), a block sample, the seeded random sample (k_indexed: sector traffic of a sparse gather)
+library's access width, then the single-query launch (k_sweep_lean), the exact scan as a lean launch, the bench step (ONE
+k_sweep_lean_multi launch for a batch of 32 queries, in both layouts), a block sample, the seeded random sample (k_indexed: sector traffic of a sparse gather)
 and the grouped reductions, so that each kernel's traffic can be read per launch."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,13 +13,17 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 eng = Engine(0)
 eng.generate_synthetic(n)
 exact = make_query(nat.M_EXACT, 100.0)
+exact.flags = nat.Q_NO_LEAN  # the calibration scan stays a k_round launch (its name + grid tell it apart in the counter file)
+exact_lean = make_query(nat.M_EXACT, 100.0)
 clt = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.01, clt_round0=bench.CLT_ROUND0, clt_growth=bench.CLT_GROWTH)
 blk = make_query(nat.M_BLOCK, 1.0, block_size=1000)
 rnd = make_query(nat.M_RANDOM_POINTER, 1.0, seed=42)
 for _ in range(20):
     eng.reduce(exact)
-for _ in range(20):
+for _ in range(40):
     eng.reduce(clt)
+for _ in range(20):
+    eng.reduce(exact_lean)  # the same 80 MB through k_sweep_lean: AFTER the 40 CLT launches of the same kernel name and grid (tools/pmc_summarize.py)
 for _ in range(20):
     eng.reduce(blk)
 for _ in range(20):

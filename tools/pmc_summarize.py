@@ -1,4 +1,4 @@
-"""Turn the two rocprofv3 --pmc passes over tools/pmc_probe.py into profiles/round2_pmc_raw.json.
+"""Turn the two rocprofv3 --pmc passes over tools/pmc_probe.py into profiles/round3_pmc_raw.json.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 tools/pmc_probe.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 tools/pmc_probe.py
@@ -60,7 +60,21 @@ doc["batch_kernel"] = next((re.split(r"[<\s]", k, maxsplit=1)[0] for k in F if r
 doc["batch_traffic_bytes_per_launch"] = fa * 1024.0 * corr + (wa or 0.0) * 1024.0 if fa else None
 doc["batch_packed_traffic_bytes_per_launch"] = fp * 1024.0 * corr + (wp or 0.0) * 1024.0 if fp else None
 doc["batch_raw_KB"] = {"xcd_aligned (default)": {"FETCH_SIZE": fa, "WRITE_SIZE": wa}, "packed": {"FETCH_SIZE": fp, "WRITE_SIZE": wp}}
-doc["single_query_traffic_bytes_per_launch"] = traffic("k_sweep_lean") or traffic("k_sweep_persist")
+# k_sweep_lean<false, false> on the full grid serves two probes in dispatch order: 40 launches of the CLT bench query (32 MB sampled),
+# then 20 exact scans (80 MB): told apart by order
+def lean_groups(d):
+    vals = []
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(path)) if re.search(r"::k_sweep_lean<", r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE" and r["Grid_Size"] == "262144"]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        vals = [float(r["Counter_Value"]) for r in rows]
+    return vals
+lv = lean_groups(fetch_dir)
+if len(lv) >= 60:
+    doc["single_query_traffic_bytes_per_launch"] = statistics.median(lv[:40]) * 1024.0 * corr
+    doc["exact_scan_lean_traffic_bytes_per_launch"] = statistics.median(lv[40:60]) * 1024.0 * corr
+else:
+    doc["single_query_traffic_bytes_per_launch"] = traffic("k_sweep_lean") or traffic("k_sweep_persist")
 doc["k_indexed_traffic_bytes_per_launch"] = traffic("k_indexed")
 # grouped sweeps (tools/pmc_probe.py runs, per key column, the reference's 10 % rowid sample — 1 M sampled rows, 12 B each: amount + key —
 # and the exact scan — 10 M rows): per template instance, the smaller median is the sample, the larger the scan
