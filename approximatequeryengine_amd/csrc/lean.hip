@@ -441,6 +441,9 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
     // slots, whatever the size of the sweep: all of a thread's loads in flight together, ONE round trip for the launch — in
     // ascending order; the eight parts of a wave combine by DPP, the W waves of a round through LDS, in wave order: a fixed
     // order whatever arrives when — bit-reproducible.
+#ifdef AQE_ABL_FOLD0  // (ablation: the folding workgroup stops here — tail in LDS read, nothing fetched yet)
+    if (rounds != 0x7fffffffu) return;
+#endif
     unsigned W = 1;
     while (2u * W * rounds <= kPersistWaves) W *= 2u;
     const unsigned wshift = static_cast<unsigned>(__builtin_ctz(W)), per_pass = kPersistWaves >> wshift;
@@ -470,33 +473,56 @@ __device__ __forceinline__ void lean_query(const LeanLaunch& a, const LeanRuns* 
         s += dpp_f64<0x141>(s);  // the other quad of the eight
         if (mine && (lane & 7) == 0) lds_round[q * W + wsub][c] = s;
     }
+#ifdef AQE_ABL_FOLD1  // (ablation: ... here — partials fetched and summed per round, before the barrier)
+    if (rounds != 0x7fffffffu) return;
+#endif
     __syncthreads();
     LEAN_STAMP_FOLD(1);
     if (wave != 0) return;
+#ifdef AQE_ABL_FOLD2  // (ablation: ... here — after the barrier, before the scan and the rules)
+    if (rounds != 0x7fffffffu) return;
+#endif
     // lane q: the moments through round q (a slot's own total in the totals form, and for the top-up slot)
     const bool tslot = T.topup_slot != 0;
-    const unsigned rounds_j = rounds - (tslot ? 1u : 0u);
     const bool own = T.totals_only != 0 || (tslot && static_cast<unsigned>(lane) == rounds - 1u);
-    double tot[7] = {0, 0, 0, 0, 0, 0, 0};
-    {   // rows of lds_round in order (round-major, the W waves of a round in wave order); the next row's reads are in
-        // flight while this one is added: the loop is a chain of LDS round trips otherwise
+    // Row L of lds_round (round-major, the W waves of a round in wave order; at most 32 rows) goes to lane L — ONE batch of
+    // LDS reads — and the rounds are scanned ACROSS the lanes with DPP shifts: an inclusive prefix over the rows (what the
+    // rules judge: the moments through round q) and, beside it, every round's own total (the totals form; the top-up slot).
+    // The loop this replaces — every lane walking all rows, one LDS round trip after the other — was 1.4 us of a 10 us
+    // launch (profiles/round3_lean_ablation.txt).  Fixed shift pattern: bit-reproducible.
+    double tot[7];
+    {
         const unsigned nrow = rounds * W;
-        double nx[7];
+        double own_t[7];
 #pragma unroll
-        for (int cc = 0; cc < 7; ++cc) nx[cc] = lds_round[0][cc];
-        for (unsigned i = 0; i < nrow; ++i) {
-            double cur[7];
+        for (int cc = 0; cc < 7; ++cc) tot[cc] = static_cast<unsigned>(lane) < nrow ? lds_round[lane][cc] : 0.0;
 #pragma unroll
-            for (int cc = 0; cc < 7; ++cc) cur[cc] = nx[cc];
-            const unsigned j = i + 1u < nrow ? i + 1u : i;
-#pragma unroll
-            for (int cc = 0; cc < 7; ++cc) nx[cc] = lds_round[j][cc];
-            const unsigned r = i >> wshift;  // (W is a power of two)
-            const bool take = own ? r == static_cast<unsigned>(lane) : (r <= static_cast<unsigned>(lane) && r < rounds_j);
-#pragma unroll
-            for (int cc = 0; cc < 7; ++cc) tot[cc] += take ? cur[cc] : 0.0;
+        for (int cc = 0; cc < 7; ++cc) {
+            double o = tot[cc];  // the W rows of a round: aligned groups of W lanes (W = 1, 2, 4, 8 or 16), butterfly
+            if (W >= 2u) o += dpp_f64<0xB1>(o);    // lane ^ 1
+            if (W >= 4u) o += dpp_f64<0x4E>(o);    // lane ^ 2
+            if (W >= 8u) o += dpp_f64<0x141>(o);   // the other quad of the eight (all four of its lanes agree)
+            if (W >= 16u) o += dpp_f64<0x128>(o);  // the other half of the row of sixteen
+            own_t[cc] = o;
+            double p = tot[cc];  // inclusive prefix within the row of sixteen: shifts by 1, 2, 4, 8 (lanes shifted in from outside add 0)
+            p += dpp_f64<0x111>(p);
+            p += dpp_f64<0x112>(p);
+            p += dpp_f64<0x114>(p);
+            p += dpp_f64<0x118>(p);
+            const double carry = read_lane_f64(p, 15);  // rows 16 .. 31 sit in the second row of lanes: plus the first row's total
+            tot[cc] = p + (lane >= 16 ? carry : 0.0);
         }
+        if (W > 1u) {  // lane q takes what the last row of round q holds
+            const int src = static_cast<int>((static_cast<unsigned>(lane) + 1u) * W - 1u) & 63;
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc) { tot[cc] = __shfl(tot[cc], src, 64); own_t[cc] = __shfl(own_t[cc], src, 64); }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 7; ++cc) tot[cc] = own ? own_t[cc] : tot[cc];
     }
+#ifdef AQE_ABL_FOLD3  // (ablation: ... here — rounds scanned, nothing judged or stored)
+    if (tot[0] + tot[6] != -1.0) { if (lane == 0) T.state->n_a = tot[0] + tot[1] + tot[2] + tot[3] + tot[4] + tot[5] + tot[6]; return; }
+#endif
     lean_judge(T, tot, static_cast<unsigned>(lane), t0, epoch, lds_res);
     wave_lds_handoff();  // (the finishing lane's words, read by the whole wave)
     lean_send_result(T, lds_res, static_cast<unsigned>(lane));

@@ -31,7 +31,7 @@ cp $O/bench_report.json gpurun_out/bench_report.json
 echo "--- GROUP BY wall per call (fused, then the two-launch form)"
 python tools/group_time.py > $O/group_wall.txt 2>/dev/null; AQE_GROUP_UNFUSED=1 python tools/group_time.py >> $O/group_wall.txt 2>/dev/null; cat $O/group_wall.txt
 echo "--- lean launch: ablation + in-kernel timeline"
-[ -f tools/lib_nofold.bin ] && ABL_V="base nojudge nofold nostore noticket nosweep" tools/ab_ablate.sh run > $O/lean_ablation.txt 2>&1; cat $O/lean_ablation.txt
+[ -f tools/lib_nofold.bin ] && tools/ab_ablate.sh run > $O/lean_ablation.txt 2>&1; cat $O/lean_ablation.txt
 [ -f tools/lib_stamps.bin ] && AQE_HIP_LIB=$PWD/tools/lib_stamps.bin timeout -k 10 100 python tools/stamp_lean.py clt 2>/dev/null | tail -3 > $O/lean_timeline.txt; cat $O/lean_timeline.txt
 rm -f $O/pmc_fetch/f_kernel_trace.csv $O/pmc_write/w_kernel_trace.csv $O/pmc_disjoint/d_kernel_trace.csv
 du -sh $O
