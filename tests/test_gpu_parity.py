@@ -1358,6 +1358,44 @@ def test_native_batch_drives_several_plans_with_two_calls_per_step(nat, table):
             p.close()
 
 
+def test_batch_of_single_round_samplers_as_lean_groups(nat, oracle, table):
+    """A batch whose plans are single-round samplers made of runs and rows of blocks — exact scans (whole table, a key-range
+    window with odd ends), a strided sample through its view, block samples (1000-row blocks: a segmented run; 4096-row
+    blocks with WHERE; the window cutting the first and the last block) — runs as lean groups of ONE launch
+    (k_sweep_lean_multi): tiles dealt out wave by wave inside a group when it has at least a tile per wave, contiguous
+    shares otherwise.  Every query against the oracle's moments over the oracle's index list, step after step."""
+    from approximatequeryengine_amd.engine import Batch, Engine, make_query
+    n = 3_000_017
+    rows = table(n)
+    specs = [
+        (make_query(nat.M_EXACT, 100.0), np.arange(n, dtype=np.uint64), None),
+        (make_query(nat.M_EXACT, 100.0, agg=nat.AVG, rows=(100_003, 2_900_001), where=(100.0, 800.0)), np.arange(100_003, 2_900_001, dtype=np.uint64), (100.0, 800.0)),
+        (make_query(nat.M_MEMORY_STRIDE, 20.0), oracle.idx_memory_stride(n, 20.0), None),
+        (make_query(nat.M_BLOCK, 20.0), oracle.idx_block(n, 20.0, 1000), None),
+        (make_query(nat.M_BLOCK, 10.0, block_size=4096, where=(250.0, 750.0), convention=nat.EST_CPP), oracle.idx_block(n, 10.0, 4096), (250.0, 750.0)),
+        (make_query(nat.M_BLOCK, 33.0, block_size=777), oracle.idx_block(n, 33.0, 777), None),
+        (make_query(nat.M_PARALLEL_BLOCK, 12.0, block_size=2000, num_threads=4), oracle.idx_parallel_block(n, 12.0, 2000, 4), None),
+    ]
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)
+        plans = [eng.plan(q) for q, _, _ in specs]
+        b = Batch(plans)
+        for step in range(3):
+            b.enqueue_all(0)
+            got = b.fetch()
+            assert plans[0].last_kernel() == nat.KERNEL_SWEEP_LEAN_MULTI
+            for (q, idx, where), r in zip(specs, got):
+                m = oracle.moments_idx(rows, idx, where=where)
+                assert (r.visited, r.n, r.device_status, r.topup_pending) == (len(idx), m.n, 0, 0), (step, q.method, r.as_dict())
+                assert rel(r.sum, m.sum) <= SUM_TOL and rel(r.sumsq, m.sumsq) <= SUM_TOL and rel(r.m2, m.m2) <= 1e-9
+        single = [eng.reduce(q) for q, _, _ in specs]  # ... and what each reports as a launch of its own
+        for r, w in zip(got, single):
+            assert (r.n, r.visited) == (w.n, w.visited) and rel(r.value, w.value) <= 1e-12 and rel(r.ci_lower, w.ci_lower) <= 1e-12
+        b.close()
+        for p in plans:
+            p.close()
+
+
 def test_batch_in_one_launch_matches_single_plans_and_oracle(nat, oracle, table):
     """aqe_batch_enqueue_all: a mixed batch of queries in ONE launch (a group of workgroups per query: lean groups,
     k_sweep_lean_multi, when every plan's families are plain runs of rows; else k_sweep_multi, a monitor wave and a
