@@ -1358,6 +1358,45 @@ def test_native_batch_drives_several_plans_with_two_calls_per_step(nat, table):
             p.close()
 
 
+def test_single_round_lean_route_over_row_windows(nat, oracle, table):
+    """Key-range windows (`WHERE id BETWEEN`: the sampler runs over the window as if it were the table) through the lean
+    single-round route: a window cuts the first and the last block of a block sample wherever it likes, so the segmented
+    run comes with plain runs at both ends — and through k_round, the same rows: both against the oracle."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    n = 1_234_567
+    rows = table(n)
+    rng = np.random.default_rng(5)
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=False)
+        for _ in range(40):
+            lo = int(rng.integers(0, n - 70_000))
+            hi = int(rng.integers(lo + 60_000, n + 1))
+            w = hi - lo
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                q, idx = make_query(nat.M_EXACT, 100.0, rows=(lo, hi)), np.arange(w, dtype=np.uint64)
+            elif kind == 1:
+                B = int(rng.choice([512, 777, 1000, 1024, 1025, 4096, 5000]))
+                pct = float(rng.choice([5.0, 20.0, 33.0, 50.0]))
+                q, idx = make_query(nat.M_BLOCK, pct, block_size=B, rows=(lo, hi)), oracle.idx_block(w, pct, B)
+            elif kind == 2:
+                pct = float(rng.choice([10.0, 20.0, 25.0, 50.0]))
+                q, idx = make_query(nat.M_MEMORY_STRIDE, pct, rows=(lo, hi)), oracle.idx_memory_stride(w, pct)
+            else:
+                B, T, pct = int(rng.choice([600, 1000, 2048])), int(rng.integers(1, 7)), float(rng.choice([10.0, 30.0]))
+                q, idx = make_query(nat.M_PARALLEL_BLOCK, pct, block_size=B, num_threads=T, rows=(lo, hi)), oracle.idx_parallel_block(w, pct, B, T)
+            where = (150.0, 850.0) if rng.integers(0, 2) else None
+            if where:
+                q.has_where, q.where_min, q.where_max = 1, where[0], where[1]
+            m = oracle.moments_idx(rows, idx + np.uint64(lo), where=where)
+            for flags in (0, nat.Q_FORCE_LEAN, nat.Q_NO_LEAN):
+                q.flags = flags
+                r = eng.reduce(q)
+                assert (r.visited, r.n) == (len(idx), m.n), (kind, lo, hi, flags, r.as_dict())
+                if m.n:
+                    assert rel(r.sum, m.sum) <= SUM_TOL and rel(r.sumsq, m.sumsq) <= SUM_TOL, (kind, lo, hi, flags)
+
+
 def test_batch_of_single_round_samplers_as_lean_groups(nat, oracle, table):
     """A batch whose plans are single-round samplers made of runs and rows of blocks — exact scans (whole table, a key-range
     window with odd ends), a strided sample through its view, block samples (1000-row blocks: a segmented run; 4096-row
