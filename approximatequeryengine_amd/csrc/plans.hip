@@ -548,24 +548,24 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
         p->d_ctl = sc.d_ctl; p->d_rehearsal = sc.d_rehearsal; p->d_fams_small = sc.d_fams_small;
     } else {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->partials), sizeof(double) * kVec * kMaxBlocks));
-        HIPCHK(c, hipMemset(p->partials, 0, sizeof(double) * kVec * kMaxBlocks));
+        HIPCHK(c, hipMemsetAsync(p->partials, 0, sizeof(double) * kVec * kMaxBlocks, c->stream));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->counter), sizeof(unsigned) * kCounterWords));
-        HIPCHK(c, hipMemset(p->counter, 0, sizeof(unsigned) * kCounterWords));
+        HIPCHK(c, hipMemsetAsync(p->counter, 0, sizeof(unsigned) * kCounterWords, c->stream));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_state), 1024));  // (QueryState; the rest is scratch of the ablation builds, tools/ab_ablate.sh)
         static_assert(sizeof(QueryState) <= 256, "state block");
-        HIPCHK(c, hipMemset(p->d_state, 0, sizeof(QueryState)));
+        HIPCHK(c, hipMemsetAsync(p->d_state, 0, sizeof(QueryState), c->stream));
         // (coherent, i.e. fine-grained: the device's stores must reach host memory while the launch is still running — fetch() polls)
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p->h_result), kSeqOffset + 64, hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_result), p->h_result, 0));
         HIPCHK(c, hipEventCreate(&p->ev0));
         HIPCHK(c, hipEventCreate(&p->ev1));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_ctl), sizeof(PersistCtl)));
-        HIPCHK(c, hipMemset(p->d_ctl, 0, sizeof(PersistCtl)));
+        HIPCHK(c, hipMemsetAsync(p->d_ctl, 0, sizeof(PersistCtl), c->stream));
         HIPCHK(c, hipMalloc(&p->d_rehearsal, sizeof(QueryState) + sizeof(aqe_result)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p->d_fams_small), kPoolFams * sizeof(DevFamily)));
-        // (hipMemset of device memory may return before it has run, and it runs on the null stream, which the plan's
-        // streams — non-blocking ones — do not wait for: the tickets must be zero before the first launch draws one)
-        HIPCHK(c, hipDeviceSynchronize());
+        // (the tickets must be zero before the first launch — on whatever stream the caller picks — draws one: the memsets
+        // run on the context's stream and only that stream is waited for; other work in flight on the device goes on)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     std::memset(p->h_result, 0, kSeqOffset + 64);
     p->h_seq = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(p->h_result) + kSeqOffset);
