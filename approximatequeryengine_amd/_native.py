@@ -156,6 +156,10 @@ def lib() -> C.CDLL:
         "aqe_grouped_finish": (C.c_int, [vp, P(Query), C.c_int32, u32, vp, vp, P(GroupResult), u32, P(u32)]),
         "aqe_gather": (C.c_int, [vp, P(Query), vp, u64, P(u64)]),
         "aqe_plan_create": (C.c_int, [vp, P(Query), P(vp)]),
+        "aqe_plan_create_families": (C.c_int, [vp, P(Query), P(Family), u32, u64, C.c_int, P(vp)]),
+        "aqe_zone_moments": (C.c_int, [vp, P(dbl)]),
+        "aqe_set_zone_variances": (C.c_int, [vp, P(dbl)]),
+        "aqe_sorted_counts": (C.c_int, [vp, P(dbl), u32, P(u64), P(u64)]),
         "aqe_plan_destroy": (None, [vp]),
         "aqe_plan_rounds": (C.c_int, [vp, P(u32), P(i32)]),
         "aqe_plan_enqueue_round": (C.c_int, [vp, u32, vp, vp]),

@@ -274,7 +274,14 @@ SweepCommon sweep_common(const aqe_plan* p, const DevFamily* fams, uint32_t nfam
 FoldParams fold_params(const aqe_plan* p, bool topup);
 FinalizeParams finalize_params(const aqe_plan* p);
 int plan_is_current(aqe_plan* p);
-int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
+// Families handed in by the caller instead of planned from q.method (aqe_plan_create_families).
+struct GivenFamilies {
+    const aqe_family* fams;
+    uint32_t n;
+    uint64_t global_samples;
+    bool on_sorted;
+};
+int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out, const GivenFamilies* given = nullptr);
 int cached_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out);
 int enqueue_all(aqe_plan* p, hipStream_t s, bool timed);
 int run_sync(aqe_plan* p, hipStream_t s, bool timed);

@@ -292,6 +292,8 @@ hipError_t launch_gather(const aqe_record* aos, uint64_t shard_lo, const DevFami
                          uint64_t ntiles, aqe_record* out, int dense16, const uint32_t* perm, hipStream_t s);
 // sort.hip: ascending amounts + their rows (rocPRIM radix sort), synchronous
 hipError_t sort_amounts(const double* amount, uint64_t n, double* sorted_amount, uint32_t* sorted_row, hipStream_t s);
+hipError_t sorted_counts(const double* sorted_amount, uint64_t n, const double* values, uint32_t m, uint64_t* n_less,
+                         uint64_t* n_less_equal, hipStream_t s);
 hipError_t launch_gather_indexed(const aqe_record* aos, uint64_t shard_lo, const uint64_t* idx, uint64_t n,
                                  aqe_record* out, hipStream_t s);
 

@@ -139,6 +139,8 @@ inline u64 splitmix64_at(u64 seed, u64 i) {
 
 }  // namespace
 
+void clip_family(std::vector<aqe_family>& out, const aqe_family& f, ClipWindow w) { clip_push(out, f, w); }
+
 int random_pointer_indices(u64 N, double pct, uint32_t seed, ClipWindow shard, std::vector<u64>& out,
                            std::string& err) {
     out.clear();

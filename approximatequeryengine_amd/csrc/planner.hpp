@@ -69,6 +69,9 @@ inline PermSpec perm_spec(uint64_t n, uint64_t lo, uint64_t target, uint64_t see
     return p;
 }
 
+// Appends the part of family f whose rows lie in [w.lo, w.hi) (nothing when it has none).
+void clip_family(std::vector<aqe_family>& out, const aqe_family& f, ClipWindow w);
+
 // Returns AQE_OK or AQE_ERR_INVALID (err gets the reason).  shard = [lo, hi) global rows.
 // zone_var: the ten zone variances ADAPTIVE_BLOCK needs (nullptr for every other method).
 int build_plan(const aqe_query& q, uint64_t n_global, ClipWindow shard, HostPlan& out, std::string& err,

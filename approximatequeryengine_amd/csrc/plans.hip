@@ -488,7 +488,7 @@ int families_to_view(aqe_ctx* c, std::vector<std::vector<aqe_family>*> lists, co
 
 }  // namespace
 
-int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
+int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out, const GivenFamilies* given) {
     if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
     if (q->agg < AQE_SUM || q->agg > AQE_COUNT) return fail(c, AQE_ERR_INVALID, "agg must be AQE_SUM, AQE_AVG or AQE_COUNT");
     if (q->convention < AQE_EST_CLI || q->convention > AQE_EST_RAW) return fail(c, AQE_ERR_INVALID, "convention must be AQE_EST_CLI, AQE_EST_CPP or AQE_EST_RAW");
@@ -499,14 +499,58 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     p->table_epoch = c->table_epoch;
     std::string err;
     const double* zone_var = nullptr;
-    if (q->method == AQE_M_ADAPTIVE_BLOCK || q->method == AQE_M_STRATIFIED_BLOCK) {
-        if (c->shard_lo != 0 || c->n_local != c->n_global)
-            return fail(c, AQE_ERR_UNSUPPORTED, "adaptive/stratified block samplers need the whole table in this context (they need a global variance pass / sort)");
-        int rc0 = q->method == AQE_M_ADAPTIVE_BLOCK ? ensure_zone_variances(c) : ensure_sorted(c);
+    const bool whole_table = c->shard_lo == 0 && c->n_local == c->n_global;
+    if (!given && q->method == AQE_M_ADAPTIVE_BLOCK) {
+        // (a shard cannot see the other shards' zones: its ranks agree on the variances first, aqe_set_zone_variances)
+        if (!whole_table && !c->zone_var_valid)
+            return fail(c, AQE_ERR_UNSUPPORTED, "adaptive_block_sample over a sharded table: all-reduce aqe_zone_moments and hand the variances to aqe_set_zone_variances first");
+        int rc0 = ensure_zone_variances(c);
         if (rc0 != AQE_OK) return rc0;
-        zone_var = q->method == AQE_M_ADAPTIVE_BLOCK ? c->zone_var : nullptr;
+        zone_var = c->zone_var;
     }
-    int rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err, zone_var);
+    if (!given && q->method == AQE_M_STRATIFIED_BLOCK) {
+        if (!whole_table)
+            return fail(c, AQE_ERR_UNSUPPORTED, "stratified_block_sample over a sharded table: map the global sorted positions with aqe_sorted_counts and plan the local runs with aqe_plan_create_families");
+        int rc0 = ensure_sorted(c);
+        if (rc0 != AQE_OK) return rc0;
+    }
+    int rc = AQE_OK;
+    if (given) {
+        // the caller's families, as a single-round plan (aqe_plan_create_families)
+        HostPlan& P = p->host;
+        P = HostPlan{};
+        P.pct = q->sample_percent;
+        P.visible_rows = c->n_global;
+        P.rounds = 1;
+        P.round_fams.assign(1, {});
+        P.global_samples = given->global_samples;
+        P.on_sorted = given->on_sorted;
+        if (given->on_sorted) {
+            rc = ensure_sorted(c);
+            if (rc != AQE_OK) return rc;
+        }
+        for (uint32_t i = 0; i < given->n; ++i) {
+            aqe_family f = given->fams[i];
+            if ((f.flags & (AQE_F_PAIR | AQE_F_TOPUP)) || f.group != 0) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: plain families of group 0 only");
+            if (f.ord_hi <= f.ord_lo) continue;
+            if (f.seg_len == 0 || f.step == 0) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: seg_len and step must be positive");
+            const uint64_t last = f.ord_hi - 1, limit = given->on_sorted ? c->n_local : c->n_global;
+            // (the last ordinal's row, with the products checked: a family that leaves the table must never reach a kernel)
+            const uint64_t seg = last / f.seg_len, within = last % f.seg_len;
+            if ((seg && f.pitch > (limit - 1) / seg) || (within && f.step > (limit - 1) / within)) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: family leaves the table");
+            const uint64_t off = seg * f.pitch + within * f.step;
+            if (f.row0 >= limit || off > limit - 1 - f.row0) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: family leaves the table");
+            if (seg && (f.seg_len - 1) > (~0ull) / f.step) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: family leaves the table");
+            if (given->on_sorted) {
+                f.row0 += c->shard_lo;  // (device families carry global rows; the sorted column's positions are this shard's own)
+                P.round_fams[0].push_back(f);
+            } else {
+                clip_family(P.round_fams[0], f, ClipWindow{c->shard_lo, c->shard_lo + c->n_local});
+            }
+        }
+    } else {
+        rc = build_plan(*q, c->n_global, ClipWindow{c->shard_lo, c->shard_lo + c->n_local}, p->host, err, zone_var);
+    }
     if (rc != AQE_OK) return fail(c, rc, err);
     if (!(q->flags & AQE_Q_NO_LAYOUT) && c->n_local && !p->host.is_random && !p->host.is_perm && !p->host.on_sorted) {
         // strided pointers — a CLT query's rounds (one step) and its top-up (another), the strided samplers — read
@@ -1316,6 +1360,15 @@ int aqe_plan_create(aqe_ctx* c, const aqe_query* q, aqe_plan** out) {
     if (!c || !q || !out) return AQE_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     return create_plan(c, q, out);
+}
+
+int aqe_plan_create_families(aqe_ctx* c, const aqe_query* q, const aqe_family* fams, uint32_t n_fams, uint64_t global_samples, int on_sorted, aqe_plan** out) {
+    if (!c || !q || !out || (n_fams && !fams)) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    aqe_query plain = *q;  // (method only picks the estimators: AQE_M_EXACT = the unscaled sum of the rows given, anything else = a sample's)
+    plain.row_lo = plain.row_hi = 0;
+    const GivenFamilies given{fams, n_fams, global_samples, on_sorted != 0};
+    return create_plan(c, &plain, out, &given);
 }
 
 void aqe_plan_destroy(aqe_plan* p) {

@@ -118,25 +118,43 @@ int ensure_keys(aqe_ctx* c, int column) {
 
 // adaptive_block_sample's pre-pass (DB.cpp:1291-1308): population variance of each of the ten zones from raw
 // moments, var = Q/n - (S/n)^2 — ten exact window scans on the device, kept until the table changes.
-int ensure_zone_variances(aqe_ctx* c) {
-    if (c->zone_var_valid) return AQE_OK;
+// (rows, sum, sum of squares) of the rows of each zone this context holds: an exact window scan per zone.
+static int zone_moments(aqe_ctx* c, double* out30) {
     const uint64_t zone_size = c->n_global / 10;
     if (zone_size == 0) return fail(c, AQE_ERR_INVALID, "adaptive_block_sample: needs at least 10 rows");
+    const uint64_t lo = c->shard_lo, hi = c->shard_lo + c->n_local;
     for (uint64_t z = 0; z < 10; ++z) {
+        double* o = out30 + 3 * z;
+        o[0] = o[1] = o[2] = 0.0;
+        const uint64_t a = z * zone_size, b = std::min(a + zone_size, c->n_global);
+        if (std::max(a, lo) >= std::min(b, hi)) continue;  // none of the zone's rows are here
         aqe_query q;
         aqe_query_defaults(&q);
         q.method = AQE_M_EXACT;
         q.sample_percent = 100.0;
-        q.row_lo = z * zone_size;
-        q.row_hi = std::min(q.row_lo + zone_size, c->n_global);
+        q.row_lo = a;
+        q.row_hi = b;
         aqe_plan* p = nullptr;
         aqe_result r;
         int rc = cached_plan(c, &q, &p);
         if (rc == AQE_OK) rc = enqueue_all(p, c->stream, false);
         if (rc == AQE_OK) rc = fetch(p, &r, c->stream);
         if (rc != AQE_OK) return rc;
-        const double cnt = static_cast<double>(q.row_hi - q.row_lo), mean = r.sum / cnt;
-        c->zone_var[z] = (r.sumsq / cnt) - (mean * mean);
+        o[0] = static_cast<double>(r.n);
+        o[1] = r.sum;
+        o[2] = r.sumsq;
+    }
+    return AQE_OK;
+}
+
+int ensure_zone_variances(aqe_ctx* c) {
+    if (c->zone_var_valid) return AQE_OK;  // (of a sharded table: what its ranks agreed on, aqe_set_zone_variances)
+    double m[30];
+    int rc = zone_moments(c, m);
+    if (rc != AQE_OK) return rc;
+    for (int z = 0; z < 10; ++z) {
+        const double cnt = m[3 * z], mean = m[3 * z + 1] / cnt;
+        c->zone_var[z] = (m[3 * z + 2] / cnt) - (mean * mean);
     }
     c->zone_var_valid = true;
     return AQE_OK;
@@ -703,6 +721,54 @@ int aqe_table_info_get(const aqe_ctx* c, aqe_table_info* out) {
     out->view_evictions = static_cast<uint32_t>(c->view_evictions);
     out->view_fallbacks = static_cast<uint32_t>(c->view_fallbacks);
     out->reserved = 0;
+    return AQE_OK;
+}
+
+// ---- the variance-aware samplers over a sharded table (include/aqe_hip.h) ----
+int aqe_zone_moments(aqe_ctx* c, double* out30) {
+    if (!c || !out30) return AQE_ERR_INVALID;
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    HIPCHK(c, hipSetDevice(c->device));
+    return zone_moments(c, out30);
+}
+
+int aqe_set_zone_variances(aqe_ctx* c, const double* var10) {
+    if (!c || !var10) return AQE_ERR_INVALID;
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    for (int z = 0; z < 10; ++z)
+        if (!(var10[z] == var10[z])) return fail(c, AQE_ERR_INVALID, "zone variance is NaN");
+    HIPCHK(c, hipSetDevice(c->device));
+    // plans made from other variances must not be served again
+    bool changed = !c->zone_var_valid;
+    for (int z = 0; z < 10 && !changed; ++z) changed = c->zone_var[z] != var10[z];
+    if (changed) {
+        bool any = false;
+        for (auto& kv : c->cache) any = any || kv.second->q.method == AQE_M_ADAPTIVE_BLOCK;
+        if (any) {
+            (void)hipDeviceSynchronize();
+            for (size_t i = 0; i < c->cache.size();) {
+                if (c->cache[i].second->q.method == AQE_M_ADAPTIVE_BLOCK) {
+                    destroy_plan(c->cache[i].second, true);
+                    c->cache.erase(c->cache.begin() + static_cast<long>(i));
+                } else {
+                    ++i;
+                }
+            }
+        }
+    }
+    std::memcpy(c->zone_var, var10, sizeof c->zone_var);
+    c->zone_var_valid = true;
+    return AQE_OK;
+}
+
+int aqe_sorted_counts(aqe_ctx* c, const double* values, uint32_t n, uint64_t* n_less, uint64_t* n_less_equal) {
+    if (!c || (n && (!values || !n_less || !n_less_equal))) return AQE_ERR_INVALID;
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_sorted(c);
+    if (rc != AQE_OK) return rc;
+    hipError_t e = sorted_counts(c->sorted_amount, c->n_local, values, n, n_less, n_less_equal, c->stream);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("aqe_sorted_counts: ") + hipGetErrorString(e));
     return AQE_OK;
 }
 

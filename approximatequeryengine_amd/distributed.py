@@ -234,6 +234,135 @@ def sharded_group_by(engine, query, group_column: int, bins, all_reduce_sum: Cal
     return engine.grouped_finish(query, kmin, nbins, b.data_ptr(), stream)
 
 
+# ---- the variance-aware samplers over a sharded table (SURVEY 8e "what does not shard") ---------------------------------
+# Both need one fact about the WHOLE table before a shard can plan (include/aqe_hip.h, the block above aqe_zone_moments).
+# The exchanges below are small host arrays, once per table and query shape — `host_all_reduce_sum(a) -> a summed over the
+# ranks` for a float64 numpy array (torch_host_all_reduce) — the plan they end in runs like any other (ShardedQuery).
+
+def sharded_adaptive_plan(engine, query, host_all_reduce_sum: Callable):
+    """adaptive_block_sample (custom_bplus_db.cpp:1273-1329) over a sharded table: the ten zones' raw moments are additive,
+    so ONE all-reduce of 30 doubles gives every rank the reference's zone variances (var = Q/n - (S/n)^2, DB.cpp:1291-1308);
+    every rank then plans the same blocks and keeps the part inside its rows."""
+    import numpy as np
+    m = np.asarray(host_all_reduce_sum(np.ascontiguousarray(engine.zone_moments(), dtype=np.float64).reshape(-1))).reshape(10, 3)
+    cnt = m[:, 0]
+    mean = m[:, 1] / cnt
+    engine.set_zone_variances(m[:, 2] / cnt - mean * mean)
+    return engine.plan(query)
+
+
+_KEY_TOP = 1 << 63
+
+
+def _key_to_double(keys):
+    """Inverse of the order-preserving map double -> uint64 (sign bit flipped for positives, all bits for negatives)."""
+    import numpy as np
+    k = np.asarray(keys, dtype=np.uint64)
+    pos = (k & np.uint64(_KEY_TOP)) != 0
+    bits = np.where(pos, k ^ np.uint64(_KEY_TOP), ~k)
+    return bits.view(np.float64)
+
+
+def _double_to_key(values):
+    import numpy as np
+    b = np.asarray(values, dtype=np.float64).view(np.uint64)
+    neg = (b & np.uint64(_KEY_TOP)) != 0
+    return np.where(neg, ~b, b | np.uint64(_KEY_TOP))
+
+
+def sorted_positions_to_local(engine, positions, n_global: int, host_all_reduce_sum: Callable, rank: int, world: int):
+    """Where positions of the GLOBAL amount-sorted order fall in this rank's own sorted column: L(p) = how many of the first
+    p rows of the global order this rank holds (so the global run [s, e) is the local run [L(s), L(e)), and the local runs of
+    all ranks add up to it).  The value at global position p is found by bisection over the doubles' bit patterns — 64 steps,
+    each one `engine.sorted_counts` and one all-reduce of the counts, for all positions at once — and rows that tie with it
+    are dealt to the ranks in rank order (tied rows hold the same amount: any of them gives the same aggregate)."""
+    import numpy as np
+    pos = np.asarray(positions, dtype=np.uint64)
+    M = len(pos)
+    if M == 0:
+        return np.zeros(0, dtype=np.uint64)
+    inside = np.minimum(pos, np.uint64(max(n_global, 1) - 1))  # (position N itself is past the last row: fixed below)
+    want = inside.astype(np.float64) + 1.0
+    lo = np.full(M, _double_to_key(np.array([-np.inf]))[0], dtype=np.uint64)
+    hi = np.full(M, _double_to_key(np.array([np.inf]))[0], dtype=np.uint64)
+    for _ in range(64):  # the smallest value v with (rows <= v over all ranks) >= p + 1 is the value at position p
+        mid = lo + (hi - lo) // np.uint64(2)
+        _, le = engine.sorted_counts(_key_to_double(mid))
+        ok = np.asarray(host_all_reduce_sum(le.astype(np.float64))) >= want
+        hi = np.where(ok, mid, hi)
+        lo = np.where(ok, lo, mid + np.uint64(1))
+    lt, le = engine.sorted_counts(_key_to_double(lo))
+    pack = np.zeros((world + 1, M), dtype=np.float64)
+    pack[rank] = (le - lt).astype(np.float64)  # this rank's rows that tie with the value
+    pack[world] = lt.astype(np.float64)
+    pack = np.asarray(host_all_reduce_sum(pack.reshape(-1))).reshape(world + 1, M)
+    need = inside.astype(np.float64) - pack[world]          # tied rows that come before position p, over all ranks
+    before = pack[:rank].sum(axis=0)                         # ... of which the lower ranks supply these
+    mine = np.clip(need - before, 0.0, pack[rank])
+    local = lt + mine.astype(np.uint64)
+    n_local = int(engine.info().local_rows)
+    return np.where(pos >= np.uint64(n_global), np.uint64(n_local), local).astype(np.uint64)
+
+
+def _family_runs(fams):
+    """(start, length) arrays of the maximal runs of consecutive rows of step-1 families, in family order."""
+    import numpy as np
+    starts, lens = [], []
+    for f in fams:
+        if f.ord_hi <= f.ord_lo:
+            continue
+        if f.step != 1:
+            raise ValueError("runs of consecutive rows only")
+        j0, j1 = f.ord_lo // f.seg_len, (f.ord_hi - 1) // f.seg_len
+        j = np.arange(j0, j1 + 1, dtype=np.uint64)
+        o0 = np.maximum(j * np.uint64(f.seg_len), np.uint64(f.ord_lo))
+        o1 = np.minimum((j + np.uint64(1)) * np.uint64(f.seg_len), np.uint64(f.ord_hi))
+        starts.append(np.uint64(f.row0) + j * np.uint64(f.pitch) + (o0 - j * np.uint64(f.seg_len)))
+        lens.append(o1 - o0)
+    if not starts:
+        return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+    return np.concatenate(starts), np.concatenate(lens)
+
+
+def sharded_stratified_plan(engine, query, host_all_reduce_sum: Callable, rank: int, world: int):
+    """stratified_block_sample (custom_bplus_db.cpp:1331-1379) over a sharded table.  The reference sorts a copy of every
+    record by amount (DB.cpp:1342-1345) and takes blocks of that order; here every rank sorts its own rows, the blocks are
+    planned in GLOBAL sorted positions (host planner, no data needed), and `sorted_positions_to_local` turns each block
+    into the run of this rank's sorted column that lies inside it.  The rows taken over all ranks are exactly the rows of
+    the global blocks (up to which of several rows with the same amount is taken)."""
+    from . import _native as nat
+    n_global = int(engine.info().global_rows)
+    fams, _, samples = nat.plan_families(query, n_global)
+    starts, lens = _family_runs(fams)
+    import numpy as np
+    bounds = np.unique(np.concatenate([starts, starts + lens])) if len(starts) else np.zeros(0, dtype=np.uint64)
+    local = sorted_positions_to_local(engine, bounds, n_global, host_all_reduce_sum, rank, world)
+    a = local[np.searchsorted(bounds, starts)] if len(starts) else local
+    b = local[np.searchsorted(bounds, starts + lens)] if len(starts) else local
+    runs = []
+    for x, y in zip(a.tolist(), b.tolist()):
+        if y > x:
+            runs.append(nat.Family(row0=x, pitch=0, seg_len=y - x, step=1, ord_lo=0, ord_hi=y - x))
+    return engine.plan_families(query, runs, samples, on_sorted=True)
+
+
+def torch_host_all_reduce(group=None, device=None) -> Callable:
+    """host_all_reduce_sum for the planners above through torch.distributed: float64 numpy array in, its sum over the ranks
+    out (staged through `device` — the rank's GPU for backend "nccl", which only moves device tensors)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    def _ar(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+
+    return _ar
+
+
 def torch_all_reduce(group=None, op: str = "sum") -> Callable:
     """In-place all-reduce (SUM, or MAX with op="max") through torch.distributed (backend "nccl" is RCCL on ROCm;
     "gloo" on CPU)."""

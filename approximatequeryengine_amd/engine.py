@@ -24,11 +24,16 @@ assert RECORD_DTYPE.itemsize == 32
 class Plan:
     """A planned query on one Engine (aqe_plan): rounds can be enqueued one by one (multi-GPU) or at once."""
 
-    def __init__(self, engine: "Engine", query: Query):
+    def __init__(self, engine: "Engine", query: Query, families=None, global_samples: int = 0, on_sorted: bool = False):
         self.engine = engine
         self.query = query
         self._h = C.c_void_p()
-        nat.check(nat.lib().aqe_plan_create(engine._h, C.byref(query), C.byref(self._h)), engine._h)
+        if families is None:
+            nat.check(nat.lib().aqe_plan_create(engine._h, C.byref(query), C.byref(self._h)), engine._h)
+        else:  # the caller's families instead of the sampler's own (aqe_plan_create_families)
+            arr = (nat.Family * max(len(families), 1))(*families)
+            nat.check(nat.lib().aqe_plan_create_families(engine._h, C.byref(query), arr, len(families), int(global_samples),
+                                                         1 if on_sorted else 0, C.byref(self._h)), engine._h)
         engine._plans.add(self)
         r, t = C.c_uint32(), C.c_int32()
         nat.check(nat.lib().aqe_plan_rounds(self._h, C.byref(r), C.byref(t)), engine._h)
@@ -363,6 +368,34 @@ class Engine:
 
     def plan(self, query: Query) -> Plan:
         return Plan(self, query)
+
+    def plan_families(self, query: Query, families, global_samples: int, on_sorted: bool = False) -> Plan:
+        """A single-round plan over the given families (nat.Family): rows of the table in global numbering, or — on_sorted —
+        positions in this engine's amount-sorted column.  `query` supplies aggregate, estimators, sample_percent, WHERE."""
+        return Plan(self, query, families=list(families), global_samples=global_samples, on_sorted=on_sorted)
+
+    # ---- what the ranks of a sharded table exchange before the variance-aware samplers can plan (distributed.py) ----
+    def zone_moments(self) -> np.ndarray:
+        """[10, 3] float64: (rows, sum, sum of squares) of the rows of each of adaptive_block_sample's ten zones held here."""
+        out = np.zeros(30, dtype=np.float64)
+        self._chk(nat.lib().aqe_zone_moments(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.reshape(10, 3)
+
+    def set_zone_variances(self, var10) -> None:
+        v = np.ascontiguousarray(var10, dtype=np.float64)
+        if v.shape != (10,):
+            raise ValueError("ten zone variances")
+        self._chk(nat.lib().aqe_set_zone_variances(self._h, v.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def sorted_counts(self, values):
+        """(rows with amount < v, rows with amount <= v) of this engine's shard for every v of `values` (uint64 arrays)."""
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        lt = np.zeros(len(v), dtype=np.uint64)
+        le = np.zeros(len(v), dtype=np.uint64)
+        if len(v):
+            self._chk(nat.lib().aqe_sorted_counts(self._h, v.ctypes.data_as(C.POINTER(C.c_double)), len(v),
+                                                  lt.ctypes.data_as(C.POINTER(C.c_uint64)), le.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return lt, le
 
 
 def make_query(method: int, sample_percent: float = 10.0, agg: int = nat.SUM, convention: int = nat.EST_CLI,

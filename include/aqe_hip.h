@@ -260,6 +260,28 @@ AQE_API int aqe_table_info_get(const aqe_ctx* ctx, aqe_table_info* out);
 AQE_API int aqe_key_range_rows(aqe_ctx* ctx, int64_t id_min, int64_t id_max, uint64_t* row_lo, uint64_t* row_hi);
 AQE_API int aqe_release_table(aqe_ctx* ctx);
 
+/* ---- the variance-aware samplers over a SHARDED table (SURVEY 8e "what does not shard") ------------------------------
+ * adaptive_block_sample (DB.cpp:1273-1329) sizes its blocks from the population variance of ten zones of the whole table
+ * (DB.cpp:1291-1308), stratified_block_sample (DB.cpp:1331-1379) takes blocks of the table SORTED by amount (DB.cpp:1342-1345):
+ * both need something global before a shard can plan.  A context that holds the whole table does that by itself
+ * (aqe_reduce / aqe_plan_create); the ranks of a sharded table exchange it with one all-reduce each:
+ *   adaptive    aqe_zone_moments on every rank -> all-reduce SUM of the 30 doubles -> var_z = Q_z/n_z - (S_z/n_z)^2
+ *               (the reference's expression) -> aqe_set_zone_variances on every rank -> aqe_plan_create plans the same
+ *               blocks everywhere, clipped to the rank's rows.
+ *   stratified  positions in the GLOBAL sorted order map to positions in each rank's own sorted column through the value
+ *               found there: aqe_sorted_counts answers "how many of my rows are < v / <= v" for a list of values (the
+ *               host bisects on v with an all-reduce of the counts per step), the global blocks become runs of the local
+ *               sorted column, and aqe_plan_create_families plans a query over exactly those runs.
+ * distributed.py (sharded_adaptive_plan, sharded_stratified_plan) is the host side of both. */
+/* out30[3 z + {0,1,2}] = (rows, sum of amounts, sum of squared amounts) of the rows of zone z = global rows
+ * [z * (N / 10), min((z + 1) * (N / 10), N)) that this context holds (zeros where it holds none). */
+AQE_API int aqe_zone_moments(aqe_ctx* ctx, double* out30);
+/* The ten zone variances of the whole table, as agreed among the ranks; kept until the table changes. */
+AQE_API int aqe_set_zone_variances(aqe_ctx* ctx, const double* var10);
+/* For each values[i]: how many rows of this context have amount < values[i] (n_less) and <= values[i] (n_less_equal).
+ * Sorts the context's column on first use (kept until the table changes). */
+AQE_API int aqe_sorted_counts(aqe_ctx* ctx, const double* values, uint32_t n, uint64_t* n_less, uint64_t* n_less_equal);
+
 /* Device scratch for hosts that do not link the HIP runtime themselves (the moment vectors and total buffers of the
  * multi-GPU entry points live in device memory): plain hipMalloc / hipFree / a synchronous copy to the host. */
 AQE_API int aqe_device_malloc(aqe_ctx* ctx, size_t bytes, void** out);
@@ -351,6 +373,13 @@ AQE_API int aqe_grouped_finish(aqe_ctx* ctx, const aqe_query* q, int32_t key_min
 #define AQE_MOMENT_VEC 8 /* {n_a, S_a-c n_a, Q_a (shifted), n_b, S_b.., Q_b.., visited, 0}: a = group 0, b = group 1; c = aqe_table_info.shift, moved into
                             the WHERE range when the query has one and the table's shift lies outside it (the same on every shard) */
 AQE_API int aqe_plan_create(aqe_ctx* ctx, const aqe_query* q, aqe_plan** out);
+/* A single-round plan over caller-given families instead of a sampler's own: `q` supplies the aggregate, the estimator
+ * convention, sample_percent and the WHERE range (its method is ignored), `global_samples` the rows the families take over
+ * the WHOLE table on all ranks (what the estimators scale by).  on_sorted == 0: rows of the table in global numbering, clipped
+ * to this context's shard; on_sorted != 0: positions in THIS context's amount-sorted column (local numbering, see
+ * aqe_sorted_counts).  Families must be plain (no AQE_F_PAIR / AQE_F_TOPUP), group 0. */
+AQE_API int aqe_plan_create_families(aqe_ctx* ctx, const aqe_query* q, const aqe_family* fams, uint32_t n_fams,
+                                     uint64_t global_samples, int on_sorted, aqe_plan** out);
 AQE_API void aqe_plan_destroy(aqe_plan* plan);
 AQE_API int aqe_plan_rounds(const aqe_plan* plan, uint32_t* rounds, int32_t* has_topup);
 AQE_API int aqe_plan_enqueue_round(aqe_plan* plan, uint32_t round, double* dev_vec, void* stream);

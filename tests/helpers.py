@@ -105,3 +105,25 @@ def perm_rows(N, pct, seed):
             again[todo] = y >= np.uint64(N)
             todo = again
     return x
+
+
+def va_table(oracle_obj, n, lo, hi, ties=False):
+    """Rows [lo, hi) of the table the sharded variance-aware sampler tests use: zones of different spread (so
+    adaptive_block_sample's block sizes differ between zones) and, with `ties`, amounts rounded to whole numbers (hundreds of
+    rows per value: the tie rule of the global sorted positions is exercised)."""
+    import numpy as np
+    rows = oracle_obj.synth(hi - lo, 42, first=lo)
+    i = np.arange(lo, hi)
+    scale = 0.2 + 0.8 * ((i * 10 // max(n, 1)) % 3) / 2.0
+    amt = 500.5 + (rows["amount"] - 500.5) * scale
+    rows["amount"] = np.round(amt) if ties else amt
+    return rows
+
+
+VARIANCE_AWARE = [  # (sampler, pct, block_size / min_block_size, strata / max_block_size)
+    ("adaptive", 5.0, 500, 2000),
+    ("adaptive", 1.0, 64, 700),
+    ("stratified", 2.0, 100, 7),
+    ("stratified", 10.0, 1000, 4),
+    ("stratified", 0.5, 37, 10),
+]

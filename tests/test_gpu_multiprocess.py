@@ -12,9 +12,10 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from helpers import rel
+from helpers import VARIANCE_AWARE, rel, va_table
 
 N = 400_003
+N_VA = 300_007  # the table of the variance-aware samplers (helpers.va_table: zones of different spread, tied amounts)
 CLT_SPECS = [  # (pct, T, e, R0, growth)
     (20.0, 4, 1.0, 256, 2),     # converges early -> the top-up is due
     (20.0, 4, 0.0, 4096, 4),    # never converges
@@ -102,6 +103,34 @@ def _worker(rank, world, port, out_dir):
         gq = make_query(nat.M_ROWID_MOD, 10.0, agg=nat.AVG)
         out["groups"] = [g.as_dict() for g in sharded_group_by(eng, gq, nat.GROUP_PRODUCT, bins, ar_sum, ar_max, stream=st)]
         torch.cuda.synchronize()
+    # (e) adaptive_block_sample / stratified_block_sample over a sharded table: the zone variances and the global sorted
+    #     positions are agreed over the group first (distributed.py), then the plan runs like any other
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from approximatequeryengine_amd.distributed import sharded_adaptive_plan, sharded_stratified_plan, torch_host_all_reduce
+    from oracle.pyoracle import Oracle  # (test data only: the table's rows)
+    lo2, hi2 = shard_bounds(N_VA, world, rank)
+    host_ar = torch_host_all_reduce()
+    out["va"] = []
+    with Engine(0) as eng, torch.cuda.stream(side):
+        eng.stage_records(va_table(Oracle(), N_VA, lo2, hi2, ties=True), shard_lo=lo2, n_global=N_VA)
+        eng.set_shift(500.5)  # every shard of one table uses the same shift
+        vec = torch.zeros(nat.MOMENT_VEC, dtype=torch.float64, device="cuda")
+        for kind, pct, a, b in VARIANCE_AWARE:
+            if kind == "adaptive":
+                plan = sharded_adaptive_plan(eng, make_query(nat.M_ADAPTIVE_BLOCK, pct, block_size=a, block_size_max=b), host_ar)
+            else:
+                plan = sharded_stratified_plan(eng, make_query(nat.M_STRATIFIED_BLOCK, pct, block_size=a, num_threads=b), host_ar, rank, world)
+            r = ShardedQuery(plan, vec, all_reduce, stream=side.cuda_stream).run().as_dict()
+            out["va"].append(r)
+            plan.close()
+        # what a shard refuses by itself: the stratified sampler without the exchange
+        try:
+            eng.plan(make_query(nat.M_STRATIFIED_BLOCK, 2.0, block_size=100, num_threads=7))
+            out["va_refused"] = False
+        except nat.AqeError:
+            out["va_refused"] = True
+        torch.cuda.synchronize()
     torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -123,7 +152,7 @@ def test_real_engines_in_separate_processes_agree_with_one_engine_and_the_oracle
     per_rank = [torch.load(tmp_path / f"r{r}.pt", weights_only=False) for r in range(world)]
     strip = lambda d: {k: v for k, v in d.items() if k != "kernel_ms"} if isinstance(d, dict) else d
     for pr in per_rank[1:]:  # every rank folds the same reduced vectors: identical answers, bit for bit
-        for key in ("single", "batched", "batch", "piped", "groups"):
+        for key in ("single", "batched", "batch", "piped", "groups", "va"):
             assert [strip(x) for x in pr[key]] == [strip(x) for x in per_rank[0][key]], key
         assert pr["marks"] == per_rank[0]["marks"]
     g = per_rank[0]
@@ -174,3 +203,20 @@ def test_real_engines_in_separate_processes_agree_with_one_engine_and_the_oracle
     assert [(x["key"], x["n"], x["visited"]) for x in g["groups"]] == [(w.key, w.n, w.visited) for w in gref]
     for x, w in zip(g["groups"], gref):
         assert rel(x["sum"], w.sum) <= 1e-12 and rel(x["value"], w.value) <= 1e-9 and rel(x["ci_lower"], w.ci_lower) <= 1e-8
+    # the variance-aware samplers: one engine holding the whole table, and the oracle on the same rows
+    assert g["va_refused"]
+    va_rows = va_table(oracle, N_VA, 0, N_VA, ties=True)
+    with Engine(0) as whole:
+        whole.stage_records(va_rows)
+        whole.set_shift(500.5)
+        for got, (kind, pct, a, b) in zip(g["va"], VARIANCE_AWARE):
+            if kind == "adaptive":
+                want = whole.reduce(make_query(nat.M_ADAPTIVE_BLOCK, pct, block_size=a, block_size_max=b))
+                idx = oracle.idx_adaptive_block(va_rows, pct, a, b)
+            else:
+                want = whole.reduce(make_query(nat.M_STRATIFIED_BLOCK, pct, block_size=a, num_threads=b))
+                idx = oracle.idx_stratified_block(va_rows, pct, a, b)
+            m = oracle.moments_idx(va_rows, idx)
+            assert m.n > 0 and got["n"] == want.n == m.n, (kind, pct, a, b, got["n"], want.n, m.n)
+            assert rel(got["sum"], m.sum) <= 1e-12 and rel(got["sum"], want.sum) <= 1e-12
+            assert rel(got["value"], want.value) <= 1e-9 and rel(got["ci_lower"], want.ci_lower) <= 1e-8 and rel(got["ci_upper"], want.ci_upper) <= 1e-8

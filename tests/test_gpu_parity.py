@@ -1754,3 +1754,85 @@ def test_group_by_over_virtual_shards(nat, oracle, table):
                     assert abs(g_.ci_lower - w.ci_lower) <= 1e-8 * max(abs(w.ci_lower), 1.0)
         for e in engs:
             e.close()
+
+
+# ---- the variance-aware samplers over shards: the C-ABI pieces the ranks exchange (include/aqe_hip.h, distributed.py) ----
+def test_plan_over_given_families(nat, oracle, engines, table):
+    """aqe_plan_create_families: a query over the caller's families — a sampler's own families give the sampler's answer,
+    runs of the amount-sorted column give the sum of those order statistics, AQE_M_EXACT leaves the sum unscaled, and a
+    family that would leave the table never reaches a kernel."""
+    from approximatequeryengine_amd.engine import make_query
+    n = 200_003
+    eng, rows = engines(n), table(n)
+    q = make_query(nat.M_BLOCK, 5.0, block_size=700, where=(100.0, 900.0), agg=nat.AVG)
+    fams, _, samples = nat.plan_families(q, n)
+    want = eng.reduce(q)
+    plan = eng.plan_families(q, fams, samples)
+    plan.enqueue_all()
+    got = plan.fetch()
+    assert (got.n, got.visited) == (want.n, want.visited) and want.n > 0
+    assert rel(got.sum, want.sum) <= SUM_TOL and rel(got.value, want.value) <= EST_TOL and rel(got.ci_upper, want.ci_upper) <= EST_TOL
+    plan.close()
+    # runs of the sorted column
+    srt = np.sort(rows["amount"])
+    runs = [(10, 500), (7_000, 1_234), (n - 3, 3), (50_000, 40_000)]
+    fams = [nat.Family(row0=a, pitch=0, seg_len=l, step=1, ord_lo=0, ord_hi=l) for a, l in runs]
+    take = np.concatenate([srt[a:a + l] for a, l in runs])
+    for method, scaled in ((nat.M_EXACT, False), (nat.M_STRATIFIED_BLOCK, True)):
+        qq = make_query(method, 100.0 * len(take) / n)
+        plan = eng.plan_families(qq, fams, len(take), on_sorted=True)
+        plan.enqueue_all()
+        got = plan.fetch()
+        assert got.n == len(take) and rel(got.sum, float(take.sum())) <= SUM_TOL
+        if not scaled:
+            assert rel(got.value, float(take.sum())) <= SUM_TOL
+        plan.close()
+    # refused on the host
+    bad = [nat.Family(row0=n - 10, pitch=0, seg_len=11, step=1, ord_lo=0, ord_hi=11),
+           nat.Family(row0=0, pitch=n, seg_len=4, step=1, ord_lo=0, ord_hi=8),
+           nat.Family(row0=0, pitch=0, seg_len=1 << 40, step=1 << 30, ord_lo=0, ord_hi=1 << 35),
+           nat.Family(row0=0, pitch=0, seg_len=8, step=1, ord_lo=0, ord_hi=8, flags=2),
+           nat.Family(row0=0, pitch=0, seg_len=0, step=1, ord_lo=0, ord_hi=8)]
+    for f in bad:
+        for on_sorted in (False, True):
+            with pytest.raises(nat.AqeError):
+                eng.plan_families(q, [f], 8, on_sorted=on_sorted)
+
+
+def test_zone_moments_and_sorted_counts_of_a_shard(nat, oracle, table):
+    """aqe_zone_moments / aqe_sorted_counts on a shard in the middle of the table, against numpy on the same rows; a shard
+    plans adaptive_block_sample only once the variances were agreed, and then exactly the whole-table plan's rows."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    from helpers import va_table
+    n, lo, hi = 150_011, 40_000, 111_000
+    rows = va_table(oracle, n, 0, n, ties=True)
+    amt = rows["amount"]
+    q = make_query(nat.M_ADAPTIVE_BLOCK, 5.0, block_size=200, block_size_max=900)
+    with Engine(0) as eng:
+        eng.stage_records(rows[lo:hi], shard_lo=lo, n_global=n)
+        eng.set_shift(500.5)
+        zm = eng.zone_moments()
+        zs = n // 10
+        for z in range(10):
+            a, b = max(z * zs, lo), min((z + 1) * zs, hi)
+            x = amt[a:b] if b > a else amt[:0]
+            assert zm[z, 0] == len(x) and rel(zm[z, 1], float(x.sum())) <= SUM_TOL and rel(zm[z, 2], float((x * x).sum())) <= SUM_TOL
+        srt = np.sort(amt[lo:hi])
+        vals = np.concatenate([srt[::977], srt[::977] + 0.25, [-np.inf, np.inf, -1.0, 0.0, 1e9, srt[0], srt[-1]]])
+        lt, le = eng.sorted_counts(vals)
+        assert np.array_equal(lt, np.searchsorted(srt, vals, side="left")) and np.array_equal(le, np.searchsorted(srt, vals, side="right"))
+        with pytest.raises(nat.AqeError):
+            eng.plan(q)  # the shard does not know the other shards' zones
+        var = np.zeros(10)
+        for z in range(10):  # the reference's expression (DB.cpp:1291-1308)
+            x = amt[z * zs:(z + 1) * zs]
+            mean = x.sum() / len(x)
+            var[z] = (x * x).sum() / len(x) - mean * mean
+        eng.set_zone_variances(var)
+        plan = eng.plan(q)
+        plan.enqueue_all()
+        got = plan.fetch()
+        plan.close()
+    idx = oracle.idx_adaptive_block(rows, 5.0, 200, 900)
+    mine = idx[(idx >= lo) & (idx < hi)]
+    assert len(mine) > 0 and got.n == len(mine) and rel(got.sum, float(amt[mine].sum())) <= SUM_TOL
