@@ -284,7 +284,11 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
         P.rounds = 1;
         P.round_fams.assign(1, {});
         for (const auto& f : fams) {
-            P.global_samples += family_size(f);
+            // (counted inside the table: at pct > 100 the block samplers plan blocks past the last row, which the reference
+            // walks over without taking anything, DB.cpp:1254-1256)
+            std::vector<aqe_family> inside;
+            clip_push(inside, f, ClipWindow{0, N});
+            for (const auto& g : inside) P.global_samples += family_size(g);
             clip_push(P.round_fams[0], f, shard);
         }
         return AQE_OK;
@@ -334,7 +338,11 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
             int target = target_of(N, pct);
             if (target <= 0) return finish_single();
             int step = std::max(1, static_cast<int>(N / static_cast<u64>(target)));
-            if (q.method == AQE_M_FAST_POINTER) step *= q.step_size;
+            if (q.method == AQE_M_FAST_POINTER) {  // (`step *= step_size` in int, DB.cpp:750: a product past INT_MAX is undefined there — refused here)
+                const long long wide = static_cast<long long>(step) * static_cast<long long>(q.step_size);
+                if (wide > 0x7fffffffLL) AQE_FAIL("fast_pointer_sample: step * step_size overflows the reference's int");
+                step = wide <= 0 ? 0 : static_cast<int>(wide);
+            }
             if (step <= 0) AQE_FAIL("fast_pointer_sample: step_size must be positive");
             fams.push_back(strided(0, static_cast<u64>(step),
                                    std::min<u64>(static_cast<u64>(target), ceil_div(N, static_cast<u64>(step)))));
@@ -346,7 +354,9 @@ static int build_plan_whole(const aqe_query& q, u64 N, ClipWindow shard, HostPla
             if (target <= 0) return finish_single();
             int fast_target = target / 3, slow_target = target - fast_target;
             if (fast_target == 0) AQE_FAIL("dual_pointer_sample: target < 3 (the reference divides by zero)");
-            u64 fast_step = static_cast<u64>(std::max(1, static_cast<int>(N / static_cast<u64>(fast_target))) * 3);
+            const long long fast_wide = 3LL * std::max(1, static_cast<int>(N / static_cast<u64>(fast_target)));  // (`fast_step *= 3` in int, DB.cpp:800)
+            if (fast_wide > 0x7fffffffLL) AQE_FAIL("dual_pointer_sample: fast_step * 3 overflows the reference's int");
+            u64 fast_step = static_cast<u64>(fast_wide);
             u64 n_fast = std::min<u64>(static_cast<u64>(fast_target), ceil_div(N, fast_step));
             fams.push_back(strided(0, fast_step, n_fast));
             u64 slow_step = static_cast<u64>(std::max(1, static_cast<int>(N / static_cast<u64>(slow_target))));

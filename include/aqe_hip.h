@@ -375,7 +375,7 @@ AQE_API int aqe_grouped_finish(aqe_ctx* ctx, const aqe_query* q, int32_t key_min
 AQE_API int aqe_plan_create(aqe_ctx* ctx, const aqe_query* q, aqe_plan** out);
 /* A single-round plan over caller-given families instead of a sampler's own: `q` supplies the aggregate, the estimator
  * convention, sample_percent and the WHERE range (its method is ignored), `global_samples` the rows the families take over
- * the WHOLE table on all ranks (what the estimators scale by).  on_sorted == 0: rows of the table in global numbering, clipped
+ * the WHOLE table on all ranks (bookkeeping: the estimators use the rows actually folded, all-reduced by the caller).  on_sorted == 0: rows of the table in global numbering, clipped
  * to this context's shard; on_sorted != 0: positions in THIS context's amount-sorted column (local numbering, see
  * aqe_sorted_counts).  Families must be plain (no AQE_F_PAIR / AQE_F_TOPUP), group 0. */
 AQE_API int aqe_plan_create_families(aqe_ctx* ctx, const aqe_query* q, const aqe_family* fams, uint32_t n_fams,

@@ -91,6 +91,33 @@ int main(int argc, char** argv) {
             fprintf(stderr, "sharded batch: query %d differs\n", i);
             return 1;
         }
+    /* what the ranks of a sharded table exchange for the variance-aware samplers, from C (here the "shard" is the whole table):
+     * zone moments -> variances -> adaptive plan; a value's rank in the sorted column; a query over caller-given families */
+    {
+        double zm[30], var[10];
+        CHECK(aqe_zone_moments(ctx, zm));
+        for (int z = 0; z < 10; ++z) { const double m = zm[3 * z + 1] / zm[3 * z]; var[z] = zm[3 * z + 2] / zm[3 * z] - m * m; }
+        CHECK(aqe_set_zone_variances(ctx, var));
+        aqe_query qa; aqe_query_defaults(&qa); qa.method = AQE_M_ADAPTIVE_BLOCK; qa.sample_percent = 2.0; qa.block_size = 500;
+        aqe_result ra; CHECK(aqe_reduce(ctx, &qa, &ra));
+        const double probe[3] = {-1.0, 500.5, 1e9};
+        uint64_t lt[3], le[3];
+        CHECK(aqe_sorted_counts(ctx, probe, 3, lt, le));
+        if (ra.n == 0 || lt[0] != 0 || le[2] != rows || lt[1] > le[1] || le[1] == 0 || le[1] >= rows) { fprintf(stderr, "variance-aware pieces differ\n"); return 1; }
+        aqe_family f; memset(&f, 0, sizeof f);
+        f.row0 = le[1]; f.seg_len = 1000; f.step = 1; f.ord_hi = 1000;   /* the 1000 rows next above 500.5 in the sorted column */
+        aqe_query qe; aqe_query_defaults(&qe); qe.method = AQE_M_EXACT; qe.agg = AQE_AVG;
+        aqe_plan* pf = NULL; aqe_result rf;
+        if (le[1] + 1000 <= rows) {
+            CHECK(aqe_plan_create_families(ctx, &qe, &f, 1, 1000, 1, &pf));
+            CHECK(aqe_plan_enqueue_all(pf, NULL));
+            CHECK(aqe_plan_fetch(pf, &rf, NULL));
+            aqe_plan_destroy(pf);
+            if (rf.n != 1000 || !(rf.mean > 500.5) || !(rf.mean < 502.0)) { fprintf(stderr, "families plan: n %llu mean %f\n", (unsigned long long)rf.n, rf.mean); return 1; }
+        }
+        f.row0 = rows - 10;  /* leaves the table: refused on the host */
+        if (aqe_plan_create_families(ctx, &qe, &f, 1, 1000, 0, &pf) != AQE_ERR_INVALID) { fprintf(stderr, "bad family accepted\n"); return 1; }
+    }
     aqe_batch_destroy(b4);
     aqe_batch_destroy(batch);
     for (int i = 0; i < Q; ++i) aqe_plan_destroy(plans[i]);
