@@ -127,3 +127,20 @@ VARIANCE_AWARE = [  # (sampler, pct, block_size / min_block_size, strata / max_b
     ("stratified", 10.0, 1000, 4),
     ("stratified", 0.5, 37, 10),
 ]
+
+
+def lognormal_table(oracle_obj):
+    """(fixture, rows) of tests/golden/clt_lognormal.json: the skewed table regenerated from numpy's PCG64 stream.  Skips the
+    calling test when the platform's exp() rounds differently from where the fixture was recorded (the digest says so)."""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    import numpy as np
+    import pytest
+    g = json.loads((Path(__file__).parent / "golden" / "clt_lognormal.json").read_text())
+    rows = oracle_obj.synth(g["rows"], g["seed"])
+    rows["amount"] = np.random.Generator(np.random.PCG64(g["rng_seed"])).lognormal(g["mu"], g["sigma"], g["rows"])
+    if hashlib.sha256(np.ascontiguousarray(rows["amount"]).tobytes()).hexdigest() != g["amount_sha256"]:
+        pytest.skip("numpy/libm on this platform generate a different log-normal table than the fixture was recorded on")
+    return g, rows

@@ -1836,3 +1836,48 @@ def test_zone_moments_and_sorted_counts_of_a_shard(nat, oracle, table):
     idx = oracle.idx_adaptive_block(rows, 5.0, 200, 900)
     mine = idx[(idx >= lo) & (idx < hi)]
     assert len(mine) > 0 and got.n == len(mine) and rel(got.sum, float(amt[mine].sum())) <= SUM_TOL
+
+
+def test_lognormal_table_against_the_reference(nat, oracle):
+    """The skewed table of tests/golden/clt_lognormal.json (log-normal amounts: cv 2.9, single rows ~1 000 x the mean) on the
+    device, against the reference's own recorded runs: the exact scan, the CLT monitor's stop in the race-free regime (T = 2:
+    the leader stops on exactly the reference's row count), the T = 4 answers of the restatement, and five samplers — two of
+    which (adaptive, stratified) pick their rows from the VALUES through the device pre-passes (zone variances, the sort)."""
+    from approximatequeryengine_amd.engine import Engine, make_query
+    from helpers import lognormal_table
+    G, rows = lognormal_table(oracle)
+    n = G["rows"]
+    with Engine(0) as eng:
+        eng.stage_records(rows, keep_aos=True)
+        r = eng.reduce(make_query(nat.M_EXACT, 100.0))
+        assert r.n == n and rel(r.sum, G["exact_sum"]) <= SUM_TOL
+        for g in G["clt_fast_stop"]:
+            for flags in (0, nat.Q_NO_PERSIST):
+                q = make_query(nat.M_CLT_DUAL_POINTER, g["pct"], agg=nat.AVG, confidence_level=0.95, check_interval=g["check_interval"], num_threads=2,
+                               max_error_percent=g["e"], flags=flags)
+                r = eng.reduce(q)
+                w = g["restatement"]
+                assert r.converged == 1 and r.rounds == g["n_fast_at_stop"] // g["check_interval"], (g["e"], flags, r.rounds)
+                assert (r.n, r.topup) == (w["n"], w["topup"]) and r.n - r.topup == 2 * g["n_fast_at_stop"]
+                assert rel(r.value, w["avg"]) <= EST_TOL
+        for c in G["clt_T4"]:
+            w = c["restatement"]
+            for flags in (0, nat.Q_NO_LEAN, nat.Q_NO_PERSIST):
+                q = make_query(nat.M_CLT_DUAL_POINTER, c["pct"], agg=nat.AVG, confidence_level=0.95, check_interval=c["check_interval"], num_threads=c["T"],
+                               max_error_percent=c["e"], flags=flags)
+                r = eng.reduce(q)
+                assert (r.n, r.topup, r.converged, r.rounds) == (w["n"], w["topup"], w["converged"], w["rounds"]), (c["e"], flags)
+                assert rel(r.value, w["avg"]) <= EST_TOL
+        for s in G["samplers"]:
+            q = _query_for(nat, {"method": s["method"], "pct": s["pct"], "args": s["args"]})
+            for flags in (0, nat.Q_FORCE_LEAN):
+                q.flags = flags
+                r = eng.reduce(q)
+                assert r.n == s["n"] and rel(r.sum, s["sum"]) <= SUM_TOL and rel(r.sumsq, s["sumsq"]) <= SUM_TOL, (s["method"], flags)
+            got = eng.gather(q)
+            assert len(got) == s["n"]
+            import hashlib
+            if s["method"] != "stratified_block_sample":  # (gathered in the reference's order; the sorted sample's order among equal amounts is free)
+                assert hashlib.sha256(np.ascontiguousarray(got["id"].astype(np.int64)).tobytes()).hexdigest() == s["ids_sha256"], s["method"]
+            else:
+                assert sorted(got["id"].tolist()) == sorted((oracle.idx_stratified_block(rows, s["pct"], int(s["args"][0]), int(s["args"][1])).astype(np.int64) + 1).tolist())
