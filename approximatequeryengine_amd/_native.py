@@ -36,6 +36,8 @@ F_PAIR = 2
 STAGE_KEEP_AOS = 1
 MOMENT_VEC = 8
 COMM_ID_BYTES = 128
+MAILBOX_HANDLE_BYTES = 64
+MAILBOX_MAX_DOUBLES = 4096
 
 
 class Query(C.Structure):
@@ -155,6 +157,13 @@ def lib() -> C.CDLL:
         "aqe_grouped_enqueue_bins": (C.c_int, [vp, P(Query), C.c_int, C.c_int32, u32, vp, vp]),
         "aqe_grouped_finish": (C.c_int, [vp, P(Query), C.c_int32, u32, vp, vp, P(GroupResult), u32, P(u32)]),
         "aqe_gather": (C.c_int, [vp, P(Query), vp, u64, P(u64)]),
+        "aqe_mailbox_create": (C.c_int, [vp, C.c_int, C.c_int, P(vp)]),
+        "aqe_mailbox_handle": (C.c_int, [vp, vp]),
+        "aqe_mailbox_connect": (C.c_int, [vp, vp]),
+        "aqe_mailbox_connect_local": (C.c_int, [P(vp), C.c_int]),
+        "aqe_mailbox_all_reduce_sum": (C.c_int, [vp, vp, u64, vp]),
+        "aqe_mailbox_status": (C.c_int, [vp, P(u32)]),
+        "aqe_mailbox_destroy": (None, [vp]),
         "aqe_plan_create": (C.c_int, [vp, P(Query), P(vp)]),
         "aqe_plan_create_families": (C.c_int, [vp, P(Query), P(Family), u32, u64, C.c_int, P(vp)]),
         "aqe_zone_moments": (C.c_int, [vp, P(dbl)]),

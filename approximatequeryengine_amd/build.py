@@ -16,7 +16,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libaqe_hip.so"
-SOURCES = [CSRC / "capi.hip", CSRC / "table.hip", CSRC / "plans.hip", CSRC / "kernels.hip", CSRC / "persist.hip", CSRC / "lean.hip", CSRC / "grouped.hip", CSRC / "sort.hip", CSRC / "comm.hip", CSRC / "planner.cpp"]
+SOURCES = [CSRC / "capi.hip", CSRC / "table.hip", CSRC / "plans.hip", CSRC / "kernels.hip", CSRC / "persist.hip", CSRC / "lean.hip", CSRC / "grouped.hip", CSRC / "sort.hip", CSRC / "comm.hip", CSRC / "mailbox.hip", CSRC / "planner.cpp"]
 HEADERS = [CSRC / "host.hpp", CSRC / "kernels.hpp", CSRC / "device_common.hpp", CSRC / "planner.hpp", ROOT / "include" / "aqe_hip.h"]
 ARCH = "gfx950"
 

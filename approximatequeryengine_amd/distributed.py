@@ -395,3 +395,27 @@ def comm_from_torch_group(engine, group=None):
     ident = [Comm.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     return Comm(engine, ident[0], world, rank)
+
+
+def mailbox_from_torch_group(engine, group=None):
+    """An engine.Mailbox over the ranks of a torch.distributed group (one process per GPU): the 64-byte IPC handles travel
+    through the group once (any backend), every rank maps every peer's mailbox."""
+    import torch.distributed as dist
+    from .engine import Mailbox
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mb = Mailbox(engine, world, rank)
+    handles = [None] * world
+    dist.all_gather_object(handles, mb.handle(), group=group)
+    mb.connect(handles)
+    dist.barrier(group=group)  # every rank has mapped its peers before the first store
+    return mb
+
+
+def mailbox_all_reduce(mailbox, stream: int) -> Callable:
+    """In-place all-reduce SUM through the peer-mapped mailbox (engine.Mailbox): one single-workgroup launch per rank on
+    `stream`, no library collective.  For tensors of at most 4096 doubles — the moment vectors and round totals of this path."""
+
+    def _ar(t):
+        mailbox.all_reduce_sum(t.data_ptr(), t.numel(), stream)
+
+    return _ar

@@ -231,6 +231,55 @@ class Comm:
                                                   C.c_void_p(stream)), self.engine._h)
 
 
+class Mailbox:
+    """The one-shot peer-mapped all-reduce (aqe_mailbox): every rank writes its vector into every peer's mailbox and adds up
+    what arrived, in ONE single-workgroup launch — for the moment vectors of the multi-GPU path, where a collective is pure
+    latency.  One process per GPU: ``mb = Mailbox(engine, nranks, rank)``, exchange ``mb.handle()`` (64 bytes) in rank order,
+    ``mb.connect(handles)``.  One process, several GPUs: ``Mailbox.connect_local(mailboxes)``."""
+
+    def __init__(self, engine: "Engine", nranks: int, rank: int):
+        self.engine, self.nranks, self.rank = engine, nranks, rank
+        self._h = C.c_void_p()
+        nat.check(nat.lib().aqe_mailbox_create(engine._h, nranks, rank, C.byref(self._h)), engine._h)
+        engine._comms.add(self)
+
+    def handle(self) -> bytes:
+        buf = C.create_string_buffer(nat.MAILBOX_HANDLE_BYTES)
+        nat.check(nat.lib().aqe_mailbox_handle(self._h, buf), self.engine._h)
+        return buf.raw
+
+    def connect(self, handles) -> None:
+        blob = b"".join(bytes(h) for h in handles)
+        if len(blob) != self.nranks * nat.MAILBOX_HANDLE_BYTES:
+            raise ValueError("one 64-byte handle per rank, in rank order")
+        nat.check(nat.lib().aqe_mailbox_connect(self._h, C.create_string_buffer(blob, len(blob))), self.engine._h)
+
+    @staticmethod
+    def connect_local(mailboxes) -> None:
+        arr = (C.c_void_p * len(mailboxes))(*[m._h for m in mailboxes])
+        nat.check(nat.lib().aqe_mailbox_connect_local(arr, len(mailboxes)), mailboxes[0].engine._h)
+
+    def all_reduce_sum(self, dev_ptr: int, count: int, stream: int = 0):
+        nat.check(nat.lib().aqe_mailbox_all_reduce_sum(self._h, C.c_void_p(dev_ptr), count, C.c_void_p(stream)), self.engine._h)
+
+    def late_ranks(self) -> int:
+        """Bit r set: rank r did not show up within the bound in some all-reduce (whose vector was then left untouched)."""
+        v = C.c_uint32()
+        nat.check(nat.lib().aqe_mailbox_status(self._h, C.byref(v)), self.engine._h)
+        return v.value
+
+    def close(self):
+        if self._h:
+            nat.lib().aqe_mailbox_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One GPU context holding one shard [shard_lo, shard_lo+local_rows) of a table of global_rows rows."""
 

@@ -466,6 +466,32 @@ AQE_API int aqe_plan_run_sharded(aqe_plan* plan, aqe_comm* comm, double* dev_vec
  * of dev_totals[n_plans][row_stride], replays (ONE launch).  Results: aqe_batch_fetch. */
 AQE_API int aqe_batch_run_sharded(aqe_batch* batch, aqe_comm* comm, double* dev_totals, uint64_t row_stride_doubles, uint32_t n_plans, void* stream);
 
+/* ---- the one-shot peer-mapped all-reduce ---------------------------------------------------------------
+ * For the moment vectors of this path a collective is pure latency.  On up to 16 GPUs that can write each other's memory
+ * (xGMI peers) every rank owns a MAILBOX in its own HBM; an all-reduce is ONE single-workgroup launch per rank that stores
+ * the rank's vector into its slot of every peer's mailbox, raises a flag there, waits for the peers' flags in its own mailbox
+ * and adds the slots up in rank order (so every rank holds the same sum, bit for bit — what the shared stop decision needs).
+ * A drop-in for aqe_comm_all_reduce_sum between the sweep and the fold:
+ *     aqe_mailbox_create(ctx, nranks, rank, &mb)
+ *     one process per GPU:  aqe_mailbox_handle(mb, h) -> exchange the 64-byte handles out of band, in rank order ->
+ *                           aqe_mailbox_connect(mb, all_handles)            (HIP IPC)
+ *     one process, n GPUs:  aqe_mailbox_connect_local(mbs, n)               (peer access)
+ *     aqe_mailbox_all_reduce_sum(mb, dev_vec, count, stream)                asynchronous, count <= AQE_MAILBOX_MAX_DOUBLES
+ * Every rank must issue the same sequence of calls (the call count is the epoch).  A rank that does not show up within
+ * ~2 s ends the peers' launches with the vector untouched and the late ranks' bits in aqe_mailbox_status — never a hang.
+ * Destroy a mailbox only after every rank is done with it, and before its context. */
+typedef struct aqe_mailbox aqe_mailbox;
+#define AQE_MAILBOX_HANDLE_BYTES 64
+#define AQE_MAILBOX_MAX_DOUBLES 4096
+#define AQE_MAILBOX_MAX_RANKS 16
+AQE_API int aqe_mailbox_create(aqe_ctx* ctx, int nranks, int rank, aqe_mailbox** out);
+AQE_API int aqe_mailbox_handle(aqe_mailbox* mb, void* handle64);
+AQE_API int aqe_mailbox_connect(aqe_mailbox* mb, const void* handles_in_rank_order);
+AQE_API int aqe_mailbox_connect_local(aqe_mailbox* const* mbs, int n);
+AQE_API int aqe_mailbox_all_reduce_sum(aqe_mailbox* mb, double* dev_buf, uint64_t count, void* stream);
+AQE_API int aqe_mailbox_status(aqe_mailbox* mb, uint32_t* late_ranks);
+AQE_API void aqe_mailbox_destroy(aqe_mailbox* mb);
+
 /* fused single-GPU form: the whole query, asynchronously.  A multi-round (CLT) plan is ONE launch with in-kernel
  * decisions; the reference's top-up (DB.cpp:1031-1040), rarely due, gets its own launch only when the plan's
  * previous execution needed it — otherwise aqe_plan_fetch runs it if the result turns out to want it.

@@ -124,6 +124,23 @@ def _worker(rank, world, port, out_dir):
             r = ShardedQuery(plan, vec, all_reduce, stream=side.cuda_stream).run().as_dict()
             out["va"].append(r)
             plan.close()
+        # (f) the peer-mapped mailbox instead of the library collective (the IPC handles travel through the group once): the
+        #     same sharded queries, stepwise and batched, and a batch per collective
+        from approximatequeryengine_amd.distributed import mailbox_all_reduce, mailbox_from_torch_group
+        mb = mailbox_from_torch_group(eng)
+        mar = mailbox_all_reduce(mb, side.cuda_stream)
+        out["mailbox"] = []
+        for pct, T, e, r0, g in CLT_SPECS[:3]:
+            plan = eng.plan(make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, num_threads=T, max_error_percent=e, clt_round0=r0, clt_growth=g))
+            v2 = torch.zeros(max(nat.MOMENT_VEC, plan.totals_len), dtype=torch.float64, device="cuda")
+            for batched in (False, True):
+                a = ShardedQuery(plan, v2, mar, stream=side.cuda_stream, batched=batched).run().as_dict()
+                b = ShardedQuery(plan, v2, all_reduce, stream=side.cuda_stream, batched=batched).run().as_dict()
+                out["mailbox"].append((a, b))
+            plan.close()
+        out["mailbox_late"] = mb.late_ranks()
+        dist.barrier()  # every rank is done with its peers' mailboxes before any is destroyed
+        mb.close()
         # what a shard refuses by itself: the stratified sampler without the exchange
         try:
             eng.plan(make_query(nat.M_STRATIFIED_BLOCK, 2.0, block_size=100, num_threads=7))
@@ -203,6 +220,13 @@ def test_real_engines_in_separate_processes_agree_with_one_engine_and_the_oracle
     assert [(x["key"], x["n"], x["visited"]) for x in g["groups"]] == [(w.key, w.n, w.visited) for w in gref]
     for x, w in zip(g["groups"], gref):
         assert rel(x["sum"], w.sum) <= 1e-12 and rel(x["value"], w.value) <= 1e-9 and rel(x["ci_lower"], w.ci_lower) <= 1e-8
+    # the peer-mapped mailbox gives what the library collective gives (the sum's order of additions may differ: 1e-12)
+    assert all(pr["mailbox_late"] == 0 for pr in per_rank)
+    for pr in per_rank:
+        for (a, b), (a0, _) in zip(pr["mailbox"], per_rank[0]["mailbox"]):
+            assert strip(a) == strip(a0)  # every rank adds the slots in rank order: identical, bit for bit
+            assert (a["n"], a["visited"], a["converged"], a["rounds"], a["topup"]) == (b["n"], b["visited"], b["converged"], b["rounds"], b["topup"])
+            assert rel(a["sum"], b["sum"]) <= 1e-12 and rel(a["value"], b["value"]) <= 1e-9 and rel(a["ci_lower"], b["ci_lower"]) <= 1e-9
     # the variance-aware samplers: one engine holding the whole table, and the oracle on the same rows
     assert g["va_refused"]
     va_rows = va_table(oracle, N_VA, 0, N_VA, ties=True)

@@ -1881,3 +1881,85 @@ def test_lognormal_table_against_the_reference(nat, oracle):
                 assert hashlib.sha256(np.ascontiguousarray(got["id"].astype(np.int64)).tobytes()).hexdigest() == s["ids_sha256"], s["method"]
             else:
                 assert sorted(got["id"].tolist()) == sorted((oracle.idx_stratified_block(rows, s["pct"], int(s["args"][0]), int(s["args"][1])).astype(np.int64) + 1).tolist())
+
+
+def test_peer_mapped_mailbox_all_reduce_in_one_process(nat, table):
+    """aqe_mailbox_* with three contexts of ONE process (peers connected directly): every rank writes its vector into every
+    mailbox and adds the slots up in rank order — the same sum on every rank, bit for bit, equal to the host's sum in that
+    order, epoch after epoch; a whole sharded CLT query through it equals the single engine's; and a rank that never shows
+    up ends the others' launches with its bit in the status instead of hanging the GPU."""
+    import torch
+    from approximatequeryengine_amd.distributed import ShardedQuery, mailbox_all_reduce, shard_bounds
+    from approximatequeryengine_amd.engine import Engine, Mailbox, make_query
+    G, n = 3, 300_007
+    rows = table(n)
+    engs = [Engine(0) for _ in range(G)]
+    try:
+        for g, e in enumerate(engs):
+            lo, hi = shard_bounds(n, G, g)
+            e.stage_records(rows[lo:hi], shard_lo=lo, n_global=n)
+            e.set_shift(500.5)
+        mbs = [Mailbox(e, G, g) for g, e in enumerate(engs)]
+        Mailbox.connect_local(mbs)
+        rng = np.random.default_rng(5)
+        streams = [torch.cuda.Stream() for _ in range(G)]
+        for epoch in range(40):
+            count = int(rng.integers(1, nat.MAILBOX_MAX_DOUBLES + 1)) if epoch % 4 else (1, 8, 255, nat.MAILBOX_MAX_DOUBLES)[epoch // 4 % 4]
+            host = [rng.standard_normal(count) * 10.0 ** rng.integers(-3, 6) for _ in range(G)]
+            dev = [torch.from_numpy(h.copy()).cuda() for h in host]
+            torch.cuda.synchronize()
+            for g in range(G):
+                mbs[g].all_reduce_sum(dev[g].data_ptr(), count, streams[g].cuda_stream)
+            torch.cuda.synchronize()
+            want = np.zeros(count)
+            for h in host:
+                want = want + h  # rank order
+            for g in range(G):
+                assert np.array_equal(dev[g].cpu().numpy(), want), (epoch, g)
+            assert all(m.late_ranks() == 0 for m in mbs)
+        with pytest.raises(nat.AqeError):
+            mbs[0].all_reduce_sum(dev[0].data_ptr(), nat.MAILBOX_MAX_DOUBLES + 1, 0)
+        # a sharded CLT query, stepwise, every collective through the mailboxes: the ranks run in threads (each blocks in its
+        # own fetches), the launches meet on the device
+        import threading
+        q = make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, num_threads=4, max_error_percent=1.0, clt_round0=256, clt_growth=2)
+        with Engine(0) as whole:
+            whole.stage_records(rows)
+            whole.set_shift(500.5)
+            want = whole.reduce(q)
+        got, errs = [None] * G, []
+
+        def rank_main(g):
+            try:
+                torch.cuda.set_device(0)
+                plan = engs[g].plan(q)
+                vec = torch.zeros(max(nat.MOMENT_VEC, plan.totals_len), dtype=torch.float64, device="cuda")
+                st = streams[g].cuda_stream
+                for batched in (False, True):
+                    got[g] = ShardedQuery(plan, vec, mailbox_all_reduce(mbs[g], st), stream=st, batched=batched).run()
+                    r = got[g]
+                    assert (r.n, r.converged, r.rounds, r.topup) == (want.n, want.converged, want.rounds, want.topup)
+                    assert rel(r.sum, want.sum) <= SUM_TOL and rel(r.value, want.value) <= EST_TOL
+                plan.close()
+            except Exception as ex:  # noqa: BLE001
+                errs.append((g, repr(ex)))
+
+        ts = [threading.Thread(target=rank_main, args=(g,)) for g in range(G)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not errs, errs
+        assert all(m.late_ranks() == 0 for m in mbs)
+        assert all((r.sum, r.value, r.ci_lower) == (got[0].sum, got[0].value, got[0].ci_lower) for r in got)  # bit for bit
+        # rank 2 stays away: ranks 0 and 1 give up after the bound, their vectors untouched, bit 2 set
+        keep = [torch.full((8,), float(g + 1), dtype=torch.float64, device="cuda") for g in range(2)]
+        torch.cuda.synchronize()
+        for g in range(2):
+            mbs[g].all_reduce_sum(keep[g].data_ptr(), 8, streams[g].cuda_stream)
+        torch.cuda.synchronize()
+        for g in range(2):
+            assert mbs[g].late_ranks() == 1 << 2 and np.array_equal(keep[g].cpu().numpy(), np.full(8, float(g + 1)))
+    finally:
+        for e in engs:
+            e.close()
