@@ -609,9 +609,17 @@ def main():
                 from approximatequeryengine_amd.distributed import comm_from_torch_group, native_all_reduce
                 native_comm = comm_from_torch_group(eng)
                 collective = {"backend": "aqe_comm (librccl, dlopen)", "ranks": native_comm.nranks}
+            # AQE_BENCH_MAILBOX=1: the peer-mapped mailbox (aqe_mailbox_*: one single-workgroup launch per rank, no library
+            # collective) — needs peer access between the ranks' GPUs and a batch of at most 4096 doubles
+            mailbox = None
+            if os.environ.get("AQE_BENCH_MAILBOX") == "1" and native_comm is None and B * width <= nat.MAILBOX_MAX_DOUBLES:
+                from approximatequeryengine_amd.distributed import mailbox_all_reduce, mailbox_from_torch_group
+                mailbox = mailbox_from_torch_group(eng)
+                collective = {"backend": "aqe_mailbox (peer-mapped, one launch per rank)", "ranks": mailbox.nranks}
             for ps, nb in zip(plan_sets, natives):
                 buf = torch.zeros(B, width, dtype=torch.float64, device="cuda")
-                ar = native_all_reduce(native_comm, st) if native_comm is not None else torch_all_reduce()
+                ar = (native_all_reduce(native_comm, st) if native_comm is not None else
+                      mailbox_all_reduce(mailbox, st) if mailbox is not None else torch_all_reduce())
                 sbs.append(ShardedBatch(ps, buf, ar, stream=st, batch=nb))
             pipe = PipelinedBatches(sbs)
             collectives_per_step = 1

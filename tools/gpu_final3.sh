@@ -30,6 +30,14 @@ head -8 $O/bench/b_kernel_stats.csv | cut -c1-200
 cp $O/bench_report.json gpurun_out/bench_report.json
 echo "--- GROUP BY wall per call (fused, then the two-launch form)"
 python tools/group_time.py > $O/group_wall.txt 2>/dev/null; AQE_GROUP_UNFUSED=1 python tools/group_time.py >> $O/group_wall.txt 2>/dev/null; cat $O/group_wall.txt
+echo "--- peer-mapped mailbox: cost of one all-reduce (same-device floor), and the bench's N > 1 path rehearsed on one GPU (2 ranks, gloo vs mailbox)"
+timeout -k 10 200 python tools/mailbox_time.py 1 2 4 > $O/mailbox.txt 2>&1; cat $O/mailbox.txt
+for mode in gloo mailbox; do
+  [ $mode = mailbox ] && export AQE_BENCH_MAILBOX=1
+  AQE_BENCH_REHEARSAL=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 2 --steps 10 --warmup 3 --headline-only 2> $O/rehearsal_$mode.err | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$mode', d['config'].get('collective'), 'ms_per_step', round(d['ms_per_step'],3), 'value', round(d['value']))" >> $O/mailbox.txt || tail -3 $O/rehearsal_$mode.err
+done
+unset AQE_BENCH_MAILBOX
+tail -2 $O/mailbox.txt
 echo "--- lean launch: ablation + in-kernel timeline"
 [ -f tools/lib_nofold.bin ] && tools/ab_ablate.sh run > $O/lean_ablation.txt 2>&1; cat $O/lean_ablation.txt
 [ -f tools/lib_stamps.bin ] && AQE_HIP_LIB=$PWD/tools/lib_stamps.bin timeout -k 10 100 python tools/stamp_lean.py clt 2>/dev/null | tail -3 > $O/lean_timeline.txt; cat $O/lean_timeline.txt

@@ -8,12 +8,13 @@ import time
 
 import torch
 
-from approximatequeryengine_amd import _native as nat
-from approximatequeryengine_amd.engine import Engine, Mailbox
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+from approximatequeryengine_amd import _native as nat  # noqa: E402
+from approximatequeryengine_amd.engine import Engine, Mailbox  # noqa: E402
 
 
 def main():
-    gs = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    gs = [int(a) for a in sys.argv[1:]] or [1, 2, 4]  # (one process has 4 hardware queues: more ranks than that on ONE device queue up behind each other's spinning launches)
     for G in gs:
         engs = [Engine(0) for _ in range(G)]
         for e in engs:
