@@ -540,7 +540,10 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out, const GivenFamil
             if ((seg && f.pitch > (limit - 1) / seg) || (within && f.step > (limit - 1) / within)) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: family leaves the table");
             const uint64_t off = seg * f.pitch + within * f.step;
             if (f.row0 >= limit || off > limit - 1 - f.row0) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: family leaves the table");
-            if (seg && (f.seg_len - 1) > (~0ull) / f.step) return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: family leaves the table");
+            // (rows must ascend with the ordinal — segments in order, none overlapping — as every planned family's do: then the
+            // last ordinal's row, checked above, is the largest, and clipping to a shard may bisect)
+            if (seg && ((f.seg_len - 1) > (~0ull) / f.step || f.pitch <= (f.seg_len - 1) * f.step))
+                return fail(c, AQE_ERR_INVALID, "aqe_plan_create_families: segments must not overlap (pitch > (seg_len - 1) * step)");
             if (given->on_sorted) {
                 f.row0 += c->shard_lo;  // (device families carry global rows; the sorted column's positions are this shard's own)
                 P.round_fams[0].push_back(f);

@@ -313,6 +313,10 @@ def _family_runs(fams):
             continue
         if f.step != 1:
             raise ValueError("runs of consecutive rows only")
+        if f.seg_len >= f.ord_hi:  # one segment (seg_len may be 2^64 - 1: no products with it)
+            starts.append(np.array([f.row0 + f.ord_lo], dtype=np.uint64))
+            lens.append(np.array([f.ord_hi - f.ord_lo], dtype=np.uint64))
+            continue
         j0, j1 = f.ord_lo // f.seg_len, (f.ord_hi - 1) // f.seg_len
         j = np.arange(j0, j1 + 1, dtype=np.uint64)
         o0 = np.maximum(j * np.uint64(f.seg_len), np.uint64(f.ord_lo))

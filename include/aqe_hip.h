@@ -377,7 +377,9 @@ AQE_API int aqe_plan_create(aqe_ctx* ctx, const aqe_query* q, aqe_plan** out);
  * convention, sample_percent and the WHERE range (its method is ignored), `global_samples` the rows the families take over
  * the WHOLE table on all ranks (bookkeeping: the estimators use the rows actually folded, all-reduced by the caller).  on_sorted == 0: rows of the table in global numbering, clipped
  * to this context's shard; on_sorted != 0: positions in THIS context's amount-sorted column (local numbering, see
- * aqe_sorted_counts).  Families must be plain (no AQE_F_PAIR / AQE_F_TOPUP), group 0. */
+ * aqe_sorted_counts).  Families must be plain (no AQE_F_PAIR / AQE_F_TOPUP), group 0, with rows
+ * ascending in the ordinal (pitch > (seg_len - 1) * step when there is more than one segment) and inside the table: anything else is
+ * AQE_ERR_INVALID, nothing reaches a kernel. */
 AQE_API int aqe_plan_create_families(aqe_ctx* ctx, const aqe_query* q, const aqe_family* fams, uint32_t n_fams,
                                      uint64_t global_samples, int on_sorted, aqe_plan** out);
 AQE_API void aqe_plan_destroy(aqe_plan* plan);

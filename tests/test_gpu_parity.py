@@ -1792,7 +1792,8 @@ def test_plan_over_given_families(nat, oracle, engines, table):
            nat.Family(row0=0, pitch=n, seg_len=4, step=1, ord_lo=0, ord_hi=8),
            nat.Family(row0=0, pitch=0, seg_len=1 << 40, step=1 << 30, ord_lo=0, ord_hi=1 << 35),
            nat.Family(row0=0, pitch=0, seg_len=8, step=1, ord_lo=0, ord_hi=8, flags=2),
-           nat.Family(row0=0, pitch=0, seg_len=0, step=1, ord_lo=0, ord_hi=8)]
+           nat.Family(row0=0, pitch=0, seg_len=0, step=1, ord_lo=0, ord_hi=8),
+           nat.Family(row0=n - 1200, pitch=1, seg_len=100, step=10, ord_lo=0, ord_hi=150)]  # overlapping segments: ordinal 99 is the largest row (and outside)
     for f in bad:
         for on_sorted in (False, True):
             with pytest.raises(nat.AqeError):
