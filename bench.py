@@ -497,6 +497,10 @@ def compact_line(rep: dict) -> dict:
         line["cpu_baseline"] = {k: (_r(cb.get(k), 5) if k == "value" else cb.get(k)) for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}
         if line["cpu_baseline"].get("sample") and len(line["cpu_baseline"]["sample"]) > 240:
             line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:237] + "..."
+    if rep.get("n_gpus", 1) > 1:  # how to read `value` against the N = 1 line
+        line["scaling_detail"] = {"rows_swept_per_sec": _r(rep.get("rows_swept_per_sec"), 0), "region_aggregates_per_sec": _r(rep.get("region_aggregates_per_sec"), 1),
+                                  "note": "weak: every rank holds rows_per_gpu rows (the table grows with N); value = completed queries over the GLOBAL table, "
+                                          "each one sweep per rank + one collective per batch: ideal is value constant in N while rows_swept_per_sec grows N-fold"}
     line["report"] = "bench_report.json"
     if len(json.dumps(line)) > LINE_LIMIT:  # never let a long string cost the driver the whole line
         line["config"]["workload"] = line["config"]["workload"][:200]

@@ -50,6 +50,17 @@ def test_compact_line_fits_the_driver_window_and_keeps_the_contract():
     assert json.loads(text) == line
 
 
+def test_compact_line_of_a_multi_gpu_run_says_how_to_read_its_value():
+    rep = canned_report()
+    rep.update({"n_gpus": 8, "rows_swept_per_sec": 1.9e13, "region_aggregates_per_sec": 4.8e6})
+    rep["config"].update({"global_rows": 80_000_000, "collectives_per_step": 100, "collective": {"backend": "nccl", "ranks": 8}})
+    line = bench.compact_line(rep)
+    assert len(json.dumps(line)) < 3000
+    assert line["n_gpus"] == 8 and line["value"] == 612345.7  # global queries per second, not multiplied by the ranks
+    assert line["scaling_detail"]["rows_swept_per_sec"] == 1.9e13 and "constant in N" in line["scaling_detail"]["note"]
+    assert "scaling_detail" not in bench.compact_line(canned_report())
+
+
 def test_headline_roofline_fraction_is_a_fraction():
     alg, uniq, executed = 8.0 * 4e6 * 22, 8.0 * 4.4e6, 8.0 * 4e6 * 32
     with_pmc = bench.headline_roofline("k", 53.7, alg, uniq, 197.0e6, executed)
