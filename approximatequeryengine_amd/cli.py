@@ -87,6 +87,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--ci", action="store_true", help="print the confidence interval")
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="under torchrun (one process per GPU): the torch.distributed backend (nccl = RCCL)")
+    p.add_argument("--collective", choices=["torch", "mailbox"], default="torch", help="under torchrun: the all-reduce of the moment vectors "
+                   "(mailbox = the peer-mapped one-launch form, for GPUs with peer access)")
     return p
 
 
@@ -105,13 +108,43 @@ def run(args, out=sys.stdout) -> int:
     clean, _ = parse_embedded_approx(args.query)
     qtype = determine_query_type(args.query, args)
     agg = aggregate_of(clean)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "torch.distributed" in sys.modules and sys.modules["torch.distributed"].is_initialized():  # called from a program that has its group
+        world = sys.modules["torch.distributed"].get_world_size()
+    if world > 1:
+        # launched one process per GPU (torchrun --nproc-per-node N -m approximatequeryengine_amd.cli ...): the table is sharded
+        # by row region over the ranks, every rank runs the same calls, rank 0 reports
+        import torch.distributed as dist
+        from .sharded_backend import ShardedBPlusDB
+        own_group = not dist.is_initialized()
+        if own_group:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29544")
+            if args.backend == "nccl":
+                import torch
+                dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+            else:
+                dist.init_process_group(args.backend)
+        if dist.get_rank() != 0:
+            out = open(os.devnull, "w")
+        try:
+            db = ShardedBPlusDB(device_id=args.device if args.backend != "nccl" else None, collective=args.collective)
+            return _run_on(db, args, out, clean, qtype, agg, aqe_backend, f"{world} GPUs, sharded by row region")
+        finally:
+            if own_group:
+                dist.barrier()
+                dist.destroy_process_group()
     db = aqe_backend.CustomBPlusDB(device_id=args.device)
+    return _run_on(db, args, out, clean, qtype, agg, aqe_backend, None)
+
+
+def _run_on(db, args, out, clean, qtype, agg, aqe_backend, sharded_note) -> int:
     if not db.open_database(args.db):
         print(f"error: cannot open database: {args.db}", file=out)
         return 1
     db._path = ""  # a read-only session must not rewrite the file on close
     n = db.get_total_records()
-    print(f"query: {args.query}\ndatabase: {args.db} ({n:,} records)\ntype: {qtype}", file=out)
+    print(f"query: {args.query}\ndatabase: {args.db} ({n:,} records{', ' + sharded_note if sharded_note else ''})\ntype: {qtype}", file=out)
     t0 = time.perf_counter()
     gb = re.search(r"GROUP\s+BY\s+(region|product_id)\b", clean, flags=re.IGNORECASE)
     if gb:  # one sweep, one (n, S, Q) bin per key, an interval per group (executor.cpp:202-321 semantics)

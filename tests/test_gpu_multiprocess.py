@@ -24,6 +24,25 @@ CLT_SPECS = [  # (pct, T, e, R0, growth)
 ]
 
 
+FACADE_CALLS = [  # (aggregate, keywords of approx()): what one engine holding the whole table must answer the same way
+    ("SUM", dict(method="stride", sample_percent=1.0)),
+    ("AVG", dict(method="random", sample_percent=2.0, seed=9)),
+    ("SUM", dict(method="random_device", sample_percent=1.0, seed=5)),
+    ("SUM", dict(method="block", sample_percent=5.0, where=(250.0, 750.0), convention="cpp")),
+    ("COUNT", dict(method="parallel_block", sample_percent=3.0, num_threads=6)),
+    ("AVG", dict(method="region", sample_percent=2.0, seed=11)),
+    ("AVG", dict(method="clt", error_percent=1.0)),
+    ("SUM", dict(method="clt", error_percent=0.01, num_threads=6)),
+    ("AVG", dict(method="exact", where=(100.0, 900.0))),
+    ("SUM", dict(method="adaptive_block", sample_percent=5.0)),
+    ("AVG", dict(method="stratified_block", sample_percent=2.0, block_size=100, num_threads=7)),
+]
+FACADE_BATCH = [dict(agg="AVG", method="clt", error_percent=1.0), dict(agg="SUM", method="clt", error_percent=0.01, num_threads=8),
+                dict(agg="SUM", method="block", sample_percent=1.0, where=(250.0, 750.0)), dict(agg="AVG", method="clt", error_percent=5.0)]
+FACADE_CLI = [["SELECT SUM(amount) FROM sales", "--s", "1", "--ci", "--compare"], ["SELECT AVG(amount) FROM sales", "--e", "2"],
+              ["SELECT COUNT(*) FROM sales"], ["SELECT AVG(amount) FROM sales GROUP BY region", "--s", "10", "--ci"]]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -148,6 +167,36 @@ def _worker(rank, world, port, out_dir):
         except nat.AqeError:
             out["va_refused"] = True
         torch.cuda.synchronize()
+    # (g) the CustomBPlusDB query API over the sharded table (sharded_backend.ShardedBPlusDB): every rank opens the same file
+    #     and stages only its region; the same calls on every rank, the same answers; then the CLI the same way
+    import io
+    from approximatequeryengine_amd import cli
+    from approximatequeryengine_amd.sharded_backend import ShardedBPlusDB
+    path = os.path.join(out_dir, "va.db")
+    pick = lambda r: (r.value, r.ci_lower, r.ci_upper, int(r.n), int(r.converged), int(r.rounds), int(r.topup))
+    for name, coll in (("db", "torch"), ("db_mailbox", "mailbox")):
+        db = ShardedBPlusDB(device_id=0, collective=coll)
+        assert db.open_database(path) and db.get_total_records() == N_VA and db.shard() == shard_bounds(N_VA, world, rank)
+        o = {"exact": (db.sum_amount(), db.avg_amount(), db.count_records(), db.sum_amount_where(250.0, 750.0))}
+        o["approx"] = [pick(db.approx(agg, **kw)) for agg, kw in FACADE_CALLS]
+        o["batch"] = [pick(r) for r in db.approx_batch(FACADE_BATCH)]
+        o["groups"] = {k: (g.value, g.ci_lower, g.ci_upper, g.n) for k, g in db.approx_group_by("AVG", "product_id", 10.0).items()}
+        o["psum"] = db.parallel_sum_sample(5.0, seed=3)
+        o["psum_unseeded"] = db.parallel_sum_sample(5.0)  # rank 0's seed for everybody
+        for bad in (lambda: db.memory_stride_sample(1.0), lambda: db.approx("SUM", id_between=(5, 500))):
+            try:
+                bad()
+                o["refused"] = False
+            except NotImplementedError:
+                o.setdefault("refused", True)
+        db.close_database()
+        out[name] = o
+    texts = []
+    for argv in FACADE_CLI:
+        buf = io.StringIO()
+        rc = cli.run(cli.build_parser().parse_args(argv + ["--db", path, "--backend", "gloo"]), buf)
+        texts.append((rc, buf.getvalue()))
+    out["cli"] = texts
     torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -158,6 +207,7 @@ def _worker(rank, world, port, out_dir):
 def test_real_engines_in_separate_processes_agree_with_one_engine_and_the_oracle(oracle, table, tmp_path, world):
     from approximatequeryengine_amd import _native as nat
     from approximatequeryengine_amd.engine import Engine, make_query
+    assert oracle.file_write(tmp_path / "va.db", va_table(oracle, N_VA, 0, N_VA, ties=True)) == 0
     ctx = mp.get_context("spawn")  # children initialise the GPU themselves
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
@@ -244,3 +294,73 @@ def test_real_engines_in_separate_processes_agree_with_one_engine_and_the_oracle
             assert m.n > 0 and got["n"] == want.n == m.n, (kind, pct, a, b, got["n"], want.n, m.n)
             assert rel(got["sum"], m.sum) <= 1e-12 and rel(got["sum"], want.sum) <= 1e-12
             assert rel(got["value"], want.value) <= 1e-9 and rel(got["ci_lower"], want.ci_lower) <= 1e-8 and rel(got["ci_upper"], want.ci_upper) <= 1e-8
+    # the façade over the sharded table (ShardedBPlusDB, with torch's collective and with the mailbox) and the CLI under a process group
+    import io
+    import re
+    from approximatequeryengine_amd import aqe_backend, cli
+    for name in ("db", "db_mailbox"):
+        for pr in per_rank[1:]:
+            assert pr[name] == per_rank[0][name], name  # every rank: the same answers, bit for bit
+    one = aqe_backend.CustomBPlusDB()
+    assert one.open_database(str(tmp_path / "va.db"))
+    one._path = ""
+    same_t = lambda a, b, tol: all((x == y) if isinstance(x, int) else rel(x, y) <= tol for x, y in zip(a, b))
+    pick = lambda r: (r.value, r.ci_lower, r.ci_upper, int(r.n), int(r.converged), int(r.rounds), int(r.topup))
+    for name in ("db", "db_mailbox"):
+        o = g[name]
+        assert o["refused"] is True
+        want = (one.sum_amount(), one.avg_amount(), one.count_records(), one.sum_amount_where(250.0, 750.0))
+        assert same_t(o["exact"], want, 1e-12), (name, o["exact"], want)
+        for got, (agg, kw) in zip(o["approx"], FACADE_CALLS):
+            assert same_t(got, pick(one.approx(agg, **kw)), 1e-9), (name, agg, kw, got)
+        for got, w in zip(o["batch"], one.approx_batch(FACADE_BATCH)):
+            assert same_t(got, pick(w), 1e-9), (name, got, pick(w))
+        wg = one.approx_group_by("AVG", "product_id", 10.0)
+        assert list(o["groups"]) == list(wg)
+        for k, t in o["groups"].items():
+            assert same_t(t, (wg[k].value, wg[k].ci_lower, wg[k].ci_upper, wg[k].n), 1e-8), (name, k)
+        assert rel(o["psum"], one.parallel_sum_sample(5.0, seed=3)) <= 1e-12
+        assert abs(o["psum_unseeded"] - want[0]) / want[0] < 0.05
+    numbers = lambda text: [float(x.replace(",", "")) for x in re.findall(r"(?<![\w.])-?\d[\d,]*\.\d+", "\n".join(l for l in text.splitlines() if "time" not in l))]
+    for r, pr in enumerate(per_rank):
+        for (rc, text), argv in zip(pr["cli"], FACADE_CLI):
+            assert rc == 0
+            if r:
+                assert text == ""  # rank 0 reports
+                continue
+            assert f"{world} GPUs, sharded by row region" in text
+            buf = io.StringIO()
+            assert cli.run(cli.build_parser().parse_args(argv + ["--db", str(tmp_path / "va.db")]), buf) == 0
+            a, b = numbers(text), numbers(buf.getvalue())
+            assert len(a) == len(b) and len(a) >= 1 and all(rel(x, y) <= 1e-9 for x, y in zip(a, b)), (argv, text, buf.getvalue())
+    one.close_database()
+
+
+@pytest.mark.gpu
+def test_cli_under_torchrun_shards_the_table(oracle, table, tmp_path):
+    """The documented multi-GPU invocation — `python -m torch.distributed.run --nproc-per-node N -m approximatequeryengine_amd.cli …`
+    — with two ranks sharing this box's GPU over gloo: every rank stages its region of the file, rank 0 prints one report, and
+    its numbers are the single-GPU CLI's."""
+    import io
+    import re
+    import subprocess
+    import sys
+    from approximatequeryengine_amd import cli
+    from approximatequeryengine_amd.build import ROOT
+    rows = table(200_003)
+    p = tmp_path / "sales.db"
+    assert oracle.file_write(p, rows) == 0
+    env = dict(os.environ, PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    numbers = lambda text: [float(x.replace(",", "")) for x in re.findall(r"(?<![\w.])-?\d[\d,]*\.\d+", "\n".join(l for l in text.splitlines() if "time" not in l))]
+    # (--error / --sample spelled out: torchrun's own parser reads every option-like word first and takes `--e`, `--s` for
+    # abbreviations of its own options)
+    for argv in (["SELECT AVG(amount) FROM sales", "--error", "2"], ["SELECT SUM(amount) FROM sales WHERE amount BETWEEN 250 AND 750", "--sample", "5", "--method", "block", "--ci"]):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(_free_port()), "-m", "approximatequeryengine_amd.cli", *argv, "--db", str(p), "--backend", "gloo"],
+                             env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.count("query: ") == 1 and "2 GPUs, sharded by row region" in out.stdout, out.stdout
+        buf = io.StringIO()
+        assert cli.run(cli.build_parser().parse_args(argv + ["--db", str(p)]), buf) == 0
+        a, b = numbers(out.stdout), numbers(buf.getvalue())
+        assert len(a) == len(b) and len(a) >= 2 and all(rel(x, y) <= 1e-9 for x, y in zip(a, b)), (out.stdout, buf.getvalue())
