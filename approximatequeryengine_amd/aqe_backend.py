@@ -550,8 +550,11 @@ for _n in _OUT_OF_SCOPE:
 class CustomApproximateScheduler:
     """bindings.cpp:103-123 / custom_scheduler.cpp — the query façade over a CustomBPlusDB."""
 
-    def __init__(self, error_threshold: float = 0.05, *, device_id: int = 0, seed: Optional[int] = None):
-        self._db = CustomBPlusDB(device_id=device_id)
+    def __init__(self, error_threshold: float = 0.05, *, device_id: int = 0, seed: Optional[int] = None, db: "Optional[CustomBPlusDB]" = None):
+        # db: the table to schedule over instead of a new one on `device_id` — e.g. a sharded_backend.ShardedBPlusDB, which makes
+        # every execute_* call a collective over the ranks of its process group (pass a `seed` then: every rank must draw the same
+        # sample; without one the sharded table agrees on rank 0's)
+        self._db = CustomBPlusDB(device_id=device_id) if db is None else db
         self.error_threshold = error_threshold
         self._seed = seed
         self._queries = 0
