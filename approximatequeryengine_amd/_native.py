@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
         "aqe_set_shift": (C.c_int, [vp, dbl]),
         "aqe_table_info_get": (C.c_int, [vp, P(TableInfo)]),
         "aqe_key_range_rows": (C.c_int, [vp, C.c_int64, C.c_int64, P(u64), P(u64)]),
+        "aqe_key_range_counts": (C.c_int, [vp, C.c_int64, C.c_int64, P(u64), P(u64)]),
         "aqe_release_table": (C.c_int, [vp]),
         "aqe_device_malloc": (C.c_int, [vp, C.c_size_t, P(vp)]),
         "aqe_device_free": (C.c_int, [vp, vp]),

@@ -450,7 +450,7 @@ class CustomBPlusDB:
             raise RuntimeError("No samples collected")  # enhanced_aqe_cli.py:226-228
         rows = None
         if id_between is not None:  # B+-tree key bounds -> row window (the pruning search_range never got, DB.hpp:45)
-            rows = self._eng().key_range_rows(int(id_between[0]), int(id_between[1]))
+            rows = self._key_window(int(id_between[0]), int(id_between[1]))
             if rows[1] <= rows[0]:
                 raise RuntimeError("No samples collected")
         if method == "clt":
@@ -476,6 +476,9 @@ class CustomBPlusDB:
             q = make_query(m, sample_percent, agg=a, convention=conv, where=where, seed=int(seed),
                            num_threads=int(num_threads), block_size=int(bs), rows=rows)
         return q
+
+    def _key_window(self, id_min: int, id_max: int) -> Tuple[int, int]:
+        return self._eng().key_range_rows(id_min, id_max)
 
     def approx_batch(self, queries: "List[dict]") -> "List[ApproxResult]":
         """Several APPROX queries in ONE launch (aqe_batch_enqueue_all: a group of workgroups, a monitor wave and a

@@ -800,6 +800,41 @@ int aqe_key_range_rows(aqe_ctx* c, int64_t id_min, int64_t id_max, uint64_t* row
     return AQE_OK;
 }
 
+// Key bounds of a SHARD: how many of its rows come before id_min / up to id_max.  Ids ascend in leaf order over the whole table,
+// so the counts of all shards add up to the global row window [sum n_below, sum n_upto) — one all-reduce SUM of two numbers.
+int aqe_key_range_counts(aqe_ctx* c, int64_t id_min, int64_t id_max, uint64_t* n_below, uint64_t* n_upto) {
+    if (!c || !n_below || !n_upto) return AQE_ERR_INVALID;
+    if (!c->staged) return fail(c, AQE_ERR_NO_TABLE, "no table staged");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_below = *n_upto = 0;
+    if (c->n_local == 0) return AQE_OK;
+    if (c->ids_dense) {  // id = first_id + global row: rows below x are the global rows [0, x - first_id), clipped to the shard
+        auto rows_below = [&](int64_t x) -> uint64_t {  // local rows with id < x
+            if (x <= c->first_id) return 0;
+            const unsigned __int128 g = static_cast<unsigned __int128>(static_cast<__int128>(x) - static_cast<__int128>(c->first_id));
+            const uint64_t hi = c->shard_lo + c->n_local;
+            const uint64_t gg = g > static_cast<unsigned __int128>(hi) ? hi : static_cast<uint64_t>(g);
+            return gg <= c->shard_lo ? 0 : gg - c->shard_lo;
+        };
+        *n_below = rows_below(id_min);
+        *n_upto = id_max == INT64_MAX ? c->n_local : rows_below(id_max + 1);
+        if (*n_upto < *n_below) *n_upto = *n_below;
+        return AQE_OK;
+    }
+    if (!c->aos) return fail(c, AQE_ERR_UNSUPPORTED, "key bounds on non-dense ids need the rows resident (AQE_STAGE_KEEP_AOS)");
+    uint64_t* d_out = nullptr;
+    uint64_t h_out[2] = {0, 0};
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof h_out));
+    hipError_t e = launch_id_bounds(c->aos, c->n_local, id_min, id_max, d_out, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, AQE_ERR_HIP, std::string("key bounds: ") + hipGetErrorString(e));
+    *n_below = h_out[0];
+    *n_upto = std::max(h_out[0], h_out[1]);
+    return AQE_OK;
+}
+
 int aqe_release_table(aqe_ctx* c) {
     if (!c) return AQE_ERR_INVALID;
     (void)hipSetDevice(c->device);

@@ -367,6 +367,12 @@ class Engine:
         self._chk(nat.lib().aqe_key_range_rows(self._h, id_min, id_max, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
+    def key_range_counts(self, id_min: int, id_max: int) -> Tuple[int, int]:
+        """(rows of THIS shard with id < id_min, rows with id <= id_max): summed over the shards they are the global row window."""
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._chk(nat.lib().aqe_key_range_counts(self._h, id_min, id_max, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
     # -- hot path --
     def reduce(self, query: Query) -> Result:
         res = Result()

@@ -12,7 +12,8 @@ gives.  What the reference does inside one process with a mutex, `future.get()` 
     db.open_database("sales.db")          # every rank stages only its region of the file
     r = db.approx("AVG", method="clt", error_percent=0.01)     # same ApproxResult on every rank
 
-All of approx(), approx_batch(), approx_group_by(), the exact aggregates and the fused `parallel_*_sample` entry points work;
+All of approx() (`id_between` included: the key bounds are counted per shard and summed), approx_batch(), approx_group_by(), the
+exact aggregates and the fused `parallel_*_sample` entry points work;
 the two samplers that need a fact about the whole table (adaptive_block: zone variances; stratified_block: a global sort)
 agree on it over the group first (distributed.sharded_adaptive_plan / sharded_stratified_plan).  The record-RETURNING samplers
 stay per GPU: a sharded table has no single process to hand a list of records to."""
@@ -181,11 +182,12 @@ class ShardedBPlusDB(CustomBPlusDB):
         raise NotImplementedError("record-returning samplers are per GPU: a sharded table has no single process to hand the rows to "
                                   "(use approx() / approx_batch() / approx_group_by(), or CustomBPlusDB on one GPU)")
 
-    def _approx_query(self, *a, **kw):
-        import inspect
-        if inspect.signature(CustomBPlusDB._approx_query).bind(self, *a, **kw).arguments.get("id_between") is not None:
-            raise NotImplementedError("id_between needs the key column of the whole table in one context (aqe_key_range_rows)")
-        return super()._approx_query(*a, **kw)
+    def _key_window(self, id_min: int, id_max: int):
+        """B+-tree key bounds over shards: ids ascend over the whole table, so every rank counts its rows below id_min / up to
+        id_max (aqe_key_range_counts) and ONE all-reduce SUM of the two counts is the global row window."""
+        below, upto = self._eng().key_range_counts(id_min, id_max)
+        w = self._host_ar(np.array([float(below), float(upto)]))
+        return int(w[0]), int(w[1])
 
     def _random_cpp(self, agg, sample_percent, seed, where=None) -> nat.Result:
         # (the reference draws from std::random_device; here every rank must draw the SAME sample: rank 0's seed)

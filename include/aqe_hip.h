@@ -258,6 +258,10 @@ AQE_API int aqe_table_info_get(const aqe_ctx* ctx, aqe_table_info* out);
  * never defined BPlusTreeNode::search_range (DB.hpp:45) would have pruned to.  Needs the whole table in this
  * context, and either dense ids (id = first_id + row, detected at staging) or the rows resident (KEEP_AOS). */
 AQE_API int aqe_key_range_rows(aqe_ctx* ctx, int64_t id_min, int64_t id_max, uint64_t* row_lo, uint64_t* row_hi);
+/* The same for a SHARDED table: how many of THIS context's rows have id < id_min (*n_below) and id <= id_max (*n_upto).  Ids
+ * ascend over the whole table, so the global window is [sum of n_below, sum of n_upto) over the ranks: one all-reduce SUM of
+ * two numbers, then aqe_query.row_lo / row_hi as above on every rank. */
+AQE_API int aqe_key_range_counts(aqe_ctx* ctx, int64_t id_min, int64_t id_max, uint64_t* n_below, uint64_t* n_upto);
 AQE_API int aqe_release_table(aqe_ctx* ctx);
 
 /* ---- the variance-aware samplers over a SHARDED table (SURVEY 8e "what does not shard") ------------------------------

@@ -36,6 +36,9 @@ FACADE_CALLS = [  # (aggregate, keywords of approx()): what one engine holding t
     ("AVG", dict(method="exact", where=(100.0, 900.0))),
     ("SUM", dict(method="adaptive_block", sample_percent=5.0)),
     ("AVG", dict(method="stratified_block", sample_percent=2.0, block_size=100, num_threads=7)),
+    ("SUM", dict(method="stride", sample_percent=5.0, id_between=(90_001, 250_000))),   # key bounds -> a row window that spans shards
+    ("AVG", dict(method="clt", error_percent=2.0, id_between=(10, 299_000))),
+    ("SUM", dict(method="exact", id_between=(120_000, 120_500))),                      # ... and one inside a single shard
 ]
 FACADE_BATCH = [dict(agg="AVG", method="clt", error_percent=1.0), dict(agg="SUM", method="clt", error_percent=0.01, num_threads=8),
                 dict(agg="SUM", method="block", sample_percent=1.0, where=(250.0, 750.0)), dict(agg="AVG", method="clt", error_percent=5.0)]
@@ -187,7 +190,7 @@ def _worker(rank, world, port, out_dir):
         sch = CustomApproximateScheduler(db=db, seed=77)  # the scheduler façade over the sharded table
         o["sched"] = [(r.value, r.status.name, r.samples_used) for r in (sch.execute_sum_query("SELECT SUM(amount) FROM sales WHERE amount BETWEEN 100 AND 800", 5.0),
                                                                             sch.execute_avg_query("SELECT AVG(amount) FROM sales", 2.0), sch.execute_exact_sum())]
-        for bad in (lambda: db.memory_stride_sample(1.0), lambda: db.approx("SUM", id_between=(5, 500))):
+        for bad in (lambda: db.memory_stride_sample(1.0), lambda: db.insert_record(None)):
             try:
                 bad()
                 o["refused"] = False

@@ -1964,3 +1964,41 @@ def test_peer_mapped_mailbox_all_reduce_in_one_process(nat, table):
     finally:
         for e in engs:
             e.close()
+
+
+def test_key_range_counts_of_a_shard(nat, table):
+    """aqe_key_range_counts: the rows of a shard below id_min / up to id_max — dense ids (arithmetic) and ids with gaps (two
+    bisections over the resident rows) against numpy; the counts of the shards of a partition add up to the whole table's
+    window (aqe_key_range_rows)."""
+    from approximatequeryengine_amd.engine import Engine
+    n = 90_001
+    rows = table(n).copy()
+    cuts = [0, 20_000, 20_001, 65_000, n]
+    probes = [(-5, 10), (1, 1), (1, n), (20_000, 20_002), (30_000, 29_000), (n, n + 50), (n + 1, n + 9), (-2**63, 2**63 - 1), (64_999, 2**63 - 1)]
+    for gaps in (False, True):
+        if gaps:
+            rows["id"] = 7 + 3 * np.arange(n) + (np.arange(n) % 2)  # ascending, not dense
+        ids = rows["id"]
+        pr = probes if not gaps else probes + [(7, 7), (8, 9), (int(ids[40_000]), int(ids[40_000])), (int(ids[-1]) + 1, 2**62)]
+        with Engine(0) as whole:
+            whole.stage_records(rows, keep_aos=True)
+            want = [whole.key_range_rows(a, b) for a, b in pr]
+        for (a, b), w in zip(pr, want):
+            lo, hi = int(np.searchsorted(ids, a, side="left")), int(np.searchsorted(ids, b, side="right"))
+            assert w == ((lo, hi) if hi > lo else (w[0], w[0])) or (hi <= lo and w[0] == w[1])
+        total = [[0, 0] for _ in pr]
+        for s0, s1 in zip(cuts[:-1], cuts[1:]):
+            with Engine(0) as eng:
+                eng.stage_records(rows[s0:s1], shard_lo=s0, n_global=n, keep_aos=True)
+                for k, (a, b) in enumerate(pr):
+                    below, upto = eng.key_range_counts(a, b)
+                    sub = ids[s0:s1]
+                    assert below == int(np.searchsorted(sub, a, side="left")), (gaps, s0, a, b)
+                    assert upto == max(below, int(np.searchsorted(sub, b, side="right"))), (gaps, s0, a, b)
+                    total[k][0] += below
+                    total[k][1] += upto
+        for (a, b), t, w in zip(pr, total, want):
+            if w[1] > w[0]:
+                assert tuple(t) == w, (gaps, a, b, t, w)
+            else:
+                assert t[1] <= t[0] or t[1] == t[0]
