@@ -33,6 +33,29 @@ def _stream_for(stream: int, tensor) -> int:
     return s
 
 
+class _torch_on:
+    """Makes `stream` (a raw handle) torch's current stream for the block, so that what the orchestration does THROUGH torch —
+    zeroing the moment vector, a torch.distributed collective — is ordered with the library's launches on that stream even when
+    the caller passed the handle explicitly and did not switch torch to it.  A no-op for host tensors (the CPU tests)."""
+
+    def __init__(self, stream: int, tensor):
+        self.ctx = None
+        if stream and getattr(tensor, "is_cuda", False):
+            import torch
+            if torch.cuda.current_stream(tensor.device).cuda_stream != stream:
+                self.ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=tensor.device))
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def shard_bounds(n_global: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Proper prefix partition of the flat row array: rank g owns [⌊g·N/G⌋, ⌊(g+1)·N/G⌋).
     (The reference's own region split, custom_bplus_db.cpp:1903-1921, overlaps by a row and can drop
@@ -69,6 +92,10 @@ class ShardedQuery:
             raise ValueError(f"moment buffer holds {vec.numel()} doubles, the plan needs {need}")
 
     def enqueue(self) -> None:
+        with _torch_on(self.stream, self.vec):
+            self._enqueue()
+
+    def _enqueue(self) -> None:
         p, v, s = self.plan, self.vec, self.stream
         if self.batched:
             t = v[: p.totals_len]
@@ -89,12 +116,13 @@ class ShardedQuery:
     def enqueue_topup(self) -> None:
         """The stepwise top-up step (device-gated): sweep, one collective, fold, estimate."""
         p, s = self.plan, self.stream
-        t = self.vec[:MOMENT_VEC]
-        t.zero_()
-        p.enqueue_round(p.rounds, t.data_ptr(), s)
-        self.all_reduce(t)
-        p.enqueue_update(p.rounds, t.data_ptr(), s)
-        p.enqueue_finalize(s)
+        with _torch_on(s, self.vec):
+            t = self.vec[:MOMENT_VEC]
+            t.zero_()
+            p.enqueue_round(p.rounds, t.data_ptr(), s)
+            self.all_reduce(t)
+            p.enqueue_update(p.rounds, t.data_ptr(), s)
+            p.enqueue_finalize(s)
 
     def run(self):
         self.enqueue()
@@ -138,14 +166,15 @@ class ShardedBatch:
     def finish(self) -> None:
         """Second half: the ONE collective of the batch, then every plan's replay."""
         s, ptr, stride = self.stream, self.buf.data_ptr(), self.buf.shape[1]
-        if self.batch is not None:
-            self.batch.join(s)
+        with _torch_on(s, self.buf):
+            if self.batch is not None:
+                self.batch.join(s)
+                self.all_reduce(self.buf)
+                self.batch.enqueue_replays(ptr, stride, s)
+                return
             self.all_reduce(self.buf)
-            self.batch.enqueue_replays(ptr, stride, s)
-            return
-        self.all_reduce(self.buf)
-        for i, p in enumerate(self.plans):
-            p.enqueue_replay(self.buf[i].data_ptr(), s)
+            for i, p in enumerate(self.plans):
+                p.enqueue_replay(self.buf[i].data_ptr(), s)
 
     def enqueue(self) -> None:
         self.enqueue_sweeps()
@@ -160,15 +189,16 @@ class ShardedBatch:
         due = [i for i, r in enumerate(out) if _pending(r)]
         if due:  # the rare top-ups of the batch share one more collective (same marks on every rank)
             s = self.stream
-            vecs = self.buf.view(-1)[: len(self.plans) * MOMENT_VEC].view(len(self.plans), MOMENT_VEC)  # contiguous
-            vecs.zero_()
-            for i in due:
-                self.plans[i].enqueue_round(self.plans[i].rounds, vecs[i].data_ptr(), s)
-            self.all_reduce(vecs)
-            for i in due:
-                self.plans[i].enqueue_update(self.plans[i].rounds, vecs[i].data_ptr(), s)
-                self.plans[i].enqueue_finalize(s)
-                out[i] = self.plans[i].fetch(s)
+            with _torch_on(s, self.buf):
+                vecs = self.buf.view(-1)[: len(self.plans) * MOMENT_VEC].view(len(self.plans), MOMENT_VEC)  # contiguous
+                vecs.zero_()
+                for i in due:
+                    self.plans[i].enqueue_round(self.plans[i].rounds, vecs[i].data_ptr(), s)
+                self.all_reduce(vecs)
+                for i in due:
+                    self.plans[i].enqueue_update(self.plans[i].rounds, vecs[i].data_ptr(), s)
+                    self.plans[i].enqueue_finalize(s)
+                    out[i] = self.plans[i].fetch(s)
         return out
 
 
@@ -219,6 +249,11 @@ def sharded_group_by(engine, query, group_column: int, bins, all_reduce_sum: Cal
                     ``with torch.cuda.stream(side)``: the legacy default stream is refused, see ``_stream_for``).
     """
     stream = _stream_for(stream, bins)
+    with _torch_on(stream, bins):
+        return _sharded_group_by(engine, query, group_column, bins, all_reduce_sum, all_reduce_max, stream)
+
+
+def _sharded_group_by(engine, query, group_column, bins, all_reduce_sum, all_reduce_max, stream):
     lo, hi = engine.group_key_range(group_column)
     rng = bins.new_tensor([-float(lo), float(hi)])
     all_reduce_max(rng)

@@ -1934,8 +1934,11 @@ def test_peer_mapped_mailbox_all_reduce_in_one_process(nat, table):
             try:
                 torch.cuda.set_device(0)
                 plan = engs[g].plan(q)
-                vec = torch.zeros(max(nat.MOMENT_VEC, plan.totals_len), dtype=torch.float64, device="cuda")
                 st = streams[g].cuda_stream
+                vec = torch.zeros(max(nat.MOMENT_VEC, plan.totals_len), dtype=torch.float64, device="cuda")
+                torch.cuda.current_stream().synchronize()
+                # (the stream handle is passed explicitly and torch is NOT switched to it: ShardedQuery orders what it does through
+                # torch — zeroing the vector — on that stream itself)
                 for batched in (False, True):
                     got[g] = ShardedQuery(plan, vec, mailbox_all_reduce(mbs[g], st), stream=st, batched=batched).run()
                     r = got[g]

@@ -1,29 +1,33 @@
-"""Dev helper (GPU box): device time of the dense sweeps under the library AQE_HIP_LIB names (A/B of load policies)."""
-import os, sys, statistics
+"""Dev helper (GPU box): the load policy of the lean sweep — plain against non-temporal loads (AQE_NT=0 / 1, read per plan) — by
+bytes swept, around the 256 MiB Infinity Cache where the library switches.     python tools/ab_nt.py"""
+import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from approximatequeryengine_amd import _native as nat
-from approximatequeryengine_amd.engine import Batch, Engine, make_query
-import bench
+from approximatequeryengine_amd.engine import Engine, make_query
+
+st = torch.cuda.Stream().cuda_stream
 eng = Engine(0)
-out = [os.path.basename(os.environ.get("AQE_HIP_LIB", "default"))]
-def med(q, reps=15):
-    for _ in range(3): eng.reduce(q)
-    return statistics.median(eng.reduce(q).kernel_ms for _ in range(reps)) * 1e3
-for n, tag in ((100_000_000, "100M"), (1_000_000_000, "1B")):
-    eng.generate_synthetic(n)
-    out.append(f"{tag} exact {med(make_query(nat.M_EXACT, 100.0)):.1f}")
-    out.append(f"stride20 {med(make_query(nat.M_MEMORY_STRIDE, 20.0)):.1f}")
-    out.append(f"block20 {med(make_query(nat.M_BLOCK, 20.0)):.1f}")
-    if n == 10_000_000:
-        st = torch.cuda.Stream().cuda_stream
-        ps = [eng.plan(q) for q in bench.headline_queries(nat, make_query, 32, 1, 0.01)]
-        b = Batch(ps)
-        for _ in range(5): b.enqueue_all(st); b.fetch()
-        b.set_profiling(True)
-        ms = []
-        for _ in range(30): b.enqueue_all(st); b.fetch(); ms.append(b.launch_info()[0])
-        out.append(f"batch32 {1e3 * statistics.median(ms):.1f}")
-        b.close()
-        for p in ps: p.close()
-print(" | ".join(out))
+for rows in [int(a) for a in sys.argv[1:]] or (20_000_000, 40_000_000, 60_000_000, 100_000_000, 200_000_000):
+    eng.generate_synthetic(rows)
+    cases = [("exact", make_query(nat.M_EXACT, 100.0)), ("stride 20%", make_query(nat.M_MEMORY_STRIDE, 20.0)), ("block 20%", make_query(nat.M_BLOCK, 20.0)),
+             ("CLT e=0.01%", make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.01, clt_round0=4096, clt_growth=4))]
+    for name, q in cases:
+        line = []
+        for mode in ("0", "1", "0", "1"):
+            os.environ["AQE_NT"] = mode
+            p = eng.plan(q)
+            for _ in range(5):
+                p.enqueue_all(st); r = p.fetch(st)
+            p.set_profiling(True)
+            us = []
+            for _ in range(30):
+                p.enqueue_all(st); r = p.fetch(st)
+                us.append(1e3 * sum(p.launch_ms()))
+            p.set_profiling(False)
+            med = statistics.median(us)
+            line.append("nt=%s %.2f us frac %.3f" % (mode, med, 8.0 * r.visited / (med * 1e-6) / 8e12))
+            p.close()
+        print("%4dM %-12s %7.0f MB | %s" % (rows // 1_000_000, name, 8e-6 * r.visited, " | ".join(line)), flush=True)
+os.environ.pop("AQE_NT", None)
+eng.close()
