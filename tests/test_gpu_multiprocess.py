@@ -375,3 +375,46 @@ def test_cli_under_torchrun_shards_the_table(oracle, table, tmp_path):
         assert cli.run(cli.build_parser().parse_args(argv + ["--db", str(p)]), buf) == 0
         a, b = numbers(out.stdout), numbers(buf.getvalue())
         assert len(a) == len(b) and len(a) >= 2 and all(rel(x, y) <= 1e-9 for x, y in zip(a, b)), (out.stdout, buf.getvalue())
+
+
+def _nccl_worker(port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from approximatequeryengine_amd.sharded_backend import ShardedBPlusDB
+    pick = lambda r: (r.value, r.ci_lower, r.ci_upper, int(r.n), int(r.converged), int(r.rounds), int(r.topup))
+    db = ShardedBPlusDB(device_id=0)
+    assert db.open_database(os.path.join(out_dir, "va.db"))
+    out = {"approx": [pick(db.approx(agg, **kw)) for agg, kw in FACADE_CALLS], "batch": [pick(r) for r in db.approx_batch(FACADE_BATCH)],
+           "groups": {k: (g.value, g.ci_lower, g.ci_upper, g.n) for k, g in db.approx_group_by("AVG", "product_id", 10.0).items()}}
+    db.close_database()
+    torch.save(out, os.path.join(out_dir, "nccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_facade_over_rccl_world_of_one(oracle, tmp_path):
+    """The same façade with backend "nccl" (RCCL) — what a multi-GPU node runs — as far as one GPU can take it: a world of one
+    rank, every collective of the sharded planners, queries, batches and GROUP BY going through RCCL on device tensors."""
+    from approximatequeryengine_amd import aqe_backend
+    assert oracle.file_write(tmp_path / "va.db", va_table(oracle, N_VA, 0, N_VA, ties=True)) == 0
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    got = torch.load(tmp_path / "nccl.pt", weights_only=False)
+    one = aqe_backend.CustomBPlusDB()
+    assert one.open_database(str(tmp_path / "va.db"))
+    one._path = ""
+    same_t = lambda a, b, tol: all((x == y) if isinstance(x, int) else rel(x, y) <= tol for x, y in zip(a, b))
+    pick = lambda r: (r.value, r.ci_lower, r.ci_upper, int(r.n), int(r.converged), int(r.rounds), int(r.topup))
+    for g, (agg, kw) in zip(got["approx"], FACADE_CALLS):
+        assert same_t(g, pick(one.approx(agg, **kw)), 1e-9), (agg, kw, g)
+    for g, w in zip(got["batch"], one.approx_batch(FACADE_BATCH)):
+        assert same_t(g, pick(w), 1e-9)
+    wg = one.approx_group_by("AVG", "product_id", 10.0)
+    assert list(got["groups"]) == list(wg) and all(same_t(t, (wg[k].value, wg[k].ci_lower, wg[k].ci_upper, wg[k].n), 1e-8) for k, t in got["groups"].items())
+    one.close_database()
