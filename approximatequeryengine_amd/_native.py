@@ -144,6 +144,7 @@ def lib() -> C.CDLL:
         "aqe_device_malloc": (C.c_int, [vp, C.c_size_t, P(vp)]),
         "aqe_device_free": (C.c_int, [vp, vp]),
         "aqe_device_read": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+        "aqe_device_write": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
         "aqe_query_defaults": (None, [P(Query)]),
         "aqe_plan_families": (C.c_int, [P(Query), u64, u64, u64, u32, P(Family), u32, P(u32), P(u32), P(u64)]),
         "aqe_plan_random_indices": (C.c_int, [u64, dbl, u32, u64, u64, P(u64), u64, P(u64)]),
@@ -164,6 +165,8 @@ def lib() -> C.CDLL:
         "aqe_mailbox_connect_local": (C.c_int, [P(vp), C.c_int]),
         "aqe_mailbox_all_reduce_sum": (C.c_int, [vp, vp, u64, vp]),
         "aqe_mailbox_status": (C.c_int, [vp, P(u32)]),
+        "aqe_mailbox_info": (C.c_int, [vp, P(C.c_int), P(C.c_int)]),
+        "aqe_comm_create_mailbox": (C.c_int, [vp, vp, P(vp)]),
         "aqe_mailbox_destroy": (None, [vp]),
         "aqe_plan_create": (C.c_int, [vp, P(Query), P(vp)]),
         "aqe_plan_create_families": (C.c_int, [vp, P(Query), P(Family), u32, u64, C.c_int, P(vp)]),

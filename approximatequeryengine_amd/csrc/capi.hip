@@ -51,6 +51,15 @@ int aqe_device_read(aqe_ctx* c, void* dst, const void* src, size_t bytes, void* 
     return AQE_OK;
 }
 
+int aqe_device_write(aqe_ctx* c, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!c || !dst || !src) return AQE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));  // (the host buffer may be reused at once)
+    return AQE_OK;
+}
+
 // ---- host planning ------------------------------------------------------------------------------
 void aqe_query_defaults(aqe_query* q) {
     if (!q) return;

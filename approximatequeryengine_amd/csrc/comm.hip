@@ -94,6 +94,7 @@ int rccl_ready(aqe_ctx* c) {
 
 struct aqe_comm {
     aqe_ctx* ctx = nullptr;
+    aqe_mailbox* mailbox = nullptr;  // aqe_comm_create_mailbox: SUMs go through the peer-mapped mailbox, no RCCL involved
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     int device = 0;  // (kept beside ctx: a communicator may be destroyed after its context)
@@ -126,6 +127,18 @@ int aqe_comm_create(aqe_ctx* c, const void* id, int nranks, int rank, aqe_comm**
     m->nranks = nranks;
     m->rank = rank;
     RCCLCHK(c, rccl().CommInitRank(&m->comm, nranks, u, rank));
+    *out = m.release();
+    return AQE_OK;
+}
+
+int aqe_comm_create_mailbox(aqe_ctx* c, aqe_mailbox* mb, aqe_comm** out) {
+    if (!c || !mb || !out) return AQE_ERR_INVALID;
+    std::unique_ptr<aqe_comm> m(new aqe_comm);
+    m->ctx = c;
+    m->device = c->device;
+    m->mailbox = mb;
+    int rc = aqe_mailbox_info(mb, &m->nranks, &m->rank);
+    if (rc != AQE_OK) return rc;
     *out = m.release();
     return AQE_OK;
 }
@@ -191,6 +204,10 @@ static int all_reduce(aqe_comm* m, double* buf, uint64_t count, ncclRedOp_t op, 
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (count == 0) return AQE_OK;
+    if (m->mailbox) {
+        if (op != ncclSum) return fail(c, AQE_ERR_UNSUPPORTED, "a mailbox communicator sums only");
+        return aqe_mailbox_all_reduce_sum(m->mailbox, buf, count, s);
+    }
     if (!m->comm) return fail(c, AQE_ERR_INVALID, "the communicator was aborted after a failure on this rank");
     RCCLCHK(c, rccl().AllReduce(buf, buf, static_cast<size_t>(count), ncclFloat64, op, m->comm, s));
     return AQE_OK;

@@ -192,6 +192,13 @@ int aqe_mailbox_all_reduce_sum(aqe_mailbox* m, double* dev_buf, uint64_t count, 
     return AQE_OK;
 }
 
+int aqe_mailbox_info(const aqe_mailbox* m, int* nranks, int* rank) {
+    if (!m) return AQE_ERR_INVALID;
+    if (nranks) *nranks = m->nranks;
+    if (rank) *rank = m->rank;
+    return AQE_OK;
+}
+
 int aqe_mailbox_status(aqe_mailbox* m, uint32_t* late_ranks) {
     if (!m || !late_ranks) return AQE_ERR_INVALID;
     *late_ranks = *const_cast<volatile unsigned*>(m->status);

@@ -202,6 +202,14 @@ class Comm:
         nat.check(nat.lib().aqe_comm_create_all(arr, len(engines), out), engines[0]._h)
         return [cls(e, b"", 0, 0, _handle=C.c_void_p(h)) for e, h in zip(engines, out)]
 
+    @classmethod
+    def over_mailbox(cls, engine: "Engine", mailbox: "Mailbox"):
+        """A communicator whose SUM all-reduces go through a connected Mailbox instead of RCCL (aqe_comm_create_mailbox): what
+        run_plan / run_batch then use.  Close it before the mailbox."""
+        h = C.c_void_p()
+        nat.check(nat.lib().aqe_comm_create_mailbox(engine._h, mailbox._h, C.byref(h)), engine._h)
+        return cls(engine, b"", 0, 0, _handle=h)
+
     def close(self):
         if self._h:
             nat.lib().aqe_comm_destroy(self._h)

@@ -287,10 +287,11 @@ AQE_API int aqe_set_zone_variances(aqe_ctx* ctx, const double* var10);
 AQE_API int aqe_sorted_counts(aqe_ctx* ctx, const double* values, uint32_t n, uint64_t* n_less, uint64_t* n_less_equal);
 
 /* Device scratch for hosts that do not link the HIP runtime themselves (the moment vectors and total buffers of the
- * multi-GPU entry points live in device memory): plain hipMalloc / hipFree / a synchronous copy to the host. */
+ * multi-GPU entry points live in device memory): plain hipMalloc / hipFree / synchronous copies to and from the host. */
 AQE_API int aqe_device_malloc(aqe_ctx* ctx, size_t bytes, void** out);
 AQE_API int aqe_device_free(aqe_ctx* ctx, void* dev_ptr);
 AQE_API int aqe_device_read(aqe_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, void* stream);
+AQE_API int aqe_device_write(aqe_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes, void* stream);
 
 /* ---- host-side planning (no GPU needed) ------------------------------------------------------ */
 AQE_API void aqe_query_defaults(aqe_query* q); /* reference defaults of BIND:56-101 */
@@ -495,7 +496,12 @@ AQE_API int aqe_mailbox_handle(aqe_mailbox* mb, void* handle64);
 AQE_API int aqe_mailbox_connect(aqe_mailbox* mb, const void* handles_in_rank_order);
 AQE_API int aqe_mailbox_connect_local(aqe_mailbox* const* mbs, int n);
 AQE_API int aqe_mailbox_all_reduce_sum(aqe_mailbox* mb, double* dev_buf, uint64_t count, void* stream);
+AQE_API int aqe_mailbox_info(const aqe_mailbox* mb, int* nranks, int* rank);
 AQE_API int aqe_mailbox_status(aqe_mailbox* mb, uint32_t* late_ranks);
+/* A communicator whose SUM all-reduces go through a connected mailbox instead of RCCL (vectors of at most
+ * AQE_MAILBOX_MAX_DOUBLES doubles): what aqe_plan_run_sharded / aqe_batch_run_sharded take, so a C or C++ host drives whole
+ * sharded queries over the peer-mapped path with the same two calls.  Destroy it (aqe_comm_destroy) before the mailbox. */
+AQE_API int aqe_comm_create_mailbox(aqe_ctx* ctx, aqe_mailbox* mb, aqe_comm** out);
 AQE_API void aqe_mailbox_destroy(aqe_mailbox* mb);
 
 /* fused single-GPU form: the whole query, asynchronously.  A multi-round (CLT) plan is ONE launch with in-kernel

@@ -118,6 +118,34 @@ int main(int argc, char** argv) {
         f.row0 = rows - 10;  /* leaves the table: refused on the host */
         if (aqe_plan_create_families(ctx, &qe, &f, 1, 1000, 0, &pf) != AQE_ERR_INVALID) { fprintf(stderr, "bad family accepted\n"); return 1; }
     }
+    /* the peer-mapped mailbox from C (one rank: its own mailbox is the only peer): the vector comes back as it went in */
+    {
+        aqe_mailbox* mb = NULL;
+        char handle[AQE_MAILBOX_HANDLE_BYTES];
+        double host_in[8] = {1.5, -2.0, 3.25, 0.0, 1e300, -1e-300, 7.0, 8.0}, host_out[8];
+        uint32_t late = 1;
+        CHECK(aqe_mailbox_create(ctx, 1, 0, &mb));
+        CHECK(aqe_mailbox_handle(mb, handle));   /* what a rank would hand to its peers */
+        CHECK(aqe_mailbox_connect(mb, handle));
+        for (int rep = 0; rep < 3; ++rep) {      /* three epochs: both parities */
+            CHECK(aqe_device_write(ctx, vec, host_in, sizeof host_in, NULL));
+            CHECK(aqe_mailbox_all_reduce_sum(mb, vec, 8, NULL));
+            CHECK(aqe_device_read(ctx, host_out, vec, sizeof host_out, NULL));
+            if (memcmp(host_in, host_out, sizeof host_in) != 0) { fprintf(stderr, "mailbox: vector changed (epoch %d)\n", rep); return 1; }
+        }
+        CHECK(aqe_mailbox_status(mb, &late));
+        if (late != 0) { fprintf(stderr, "mailbox: late ranks %u\n", late); return 1; }
+        /* ... and as the collective of whole sharded queries: the same two calls as with the RCCL communicator */
+        aqe_comm* mc = NULL;
+        CHECK(aqe_comm_create_mailbox(ctx, mb, &mc));
+        for (int i = 0; i < Q; ++i) {
+            aqe_result r;
+            CHECK(aqe_plan_run_sharded(plans[i], mc, vec, NULL, &r));
+            if (!same(&r, &want[i]) || r.topup_pending) { fprintf(stderr, "sharded over the mailbox: query %d differs\n", i); return 1; }
+        }
+        aqe_comm_destroy(mc);
+        aqe_mailbox_destroy(mb);
+    }
     aqe_batch_destroy(b4);
     aqe_batch_destroy(batch);
     for (int i = 0; i < Q; ++i) aqe_plan_destroy(plans[i]);

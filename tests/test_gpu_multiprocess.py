@@ -160,6 +160,16 @@ def _worker(rank, world, port, out_dir):
                 b = ShardedQuery(plan, v2, all_reduce, stream=side.cuda_stream, batched=batched).run().as_dict()
                 out["mailbox"].append((a, b))
             plan.close()
+        # ... and the host side in C: aqe_plan_run_sharded over a communicator that wraps the mailbox
+        from approximatequeryengine_amd.engine import Comm
+        mc = Comm.over_mailbox(eng, mb)
+        pct, T, e, r0, g = CLT_SPECS[0]
+        plan = eng.plan(make_query(nat.M_CLT_DUAL_POINTER, pct, agg=nat.AVG, num_threads=T, max_error_percent=e, clt_round0=r0, clt_growth=g))
+        v2 = torch.zeros(max(nat.MOMENT_VEC, plan.totals_len), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        out["mailbox_c"] = (mc.run_plan(plan, v2.data_ptr(), side.cuda_stream).as_dict(), out["mailbox"][1][0])
+        plan.close()
+        mc.close()
         out["mailbox_late"] = mb.late_ranks()
         dist.barrier()  # every rank is done with its peers' mailboxes before any is destroyed
         mb.close()
@@ -279,6 +289,9 @@ def test_real_engines_in_separate_processes_agree_with_one_engine_and_the_oracle
         assert rel(x["sum"], w.sum) <= 1e-12 and rel(x["value"], w.value) <= 1e-9 and rel(x["ci_lower"], w.ci_lower) <= 1e-8
     # the peer-mapped mailbox gives what the library collective gives (the sum's order of additions may differ: 1e-12)
     assert all(pr["mailbox_late"] == 0 for pr in per_rank)
+    for pr in per_rank:
+        a, b = pr["mailbox_c"]  # (the C host path against distributed.ShardedQuery, batched form, same collective)
+        assert strip(a) == strip(b), (a, b)
     for pr in per_rank:
         for (a, b), (a0, _) in zip(pr["mailbox"], per_rank[0]["mailbox"]):
             assert strip(a) == strip(a0)  # every rank adds the slots in rank order: identical, bit for bit
