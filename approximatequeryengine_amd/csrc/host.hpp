@@ -45,10 +45,11 @@ constexpr size_t kStageChunkRows = 1u << 19;  // 512 Ki rows: 16 MiB of AoS per 
 constexpr int kStageRing = 4;                 // pinned buffers of the staging ring (kept by the context between stagings)
 constexpr size_t kMaxStrideViews = 8;  // stride-major copies of the column a table may hold whatever their size; more while they fit the view budget (table.hip)
 constexpr size_t kBatchLanes = 3;  // side streams of the batched multi-GPU form (see ensure_lanes)
-// A sweep that the eight 4 MB L2s cannot hold from one launch to the next is read with non-temporal loads: measured
-// (tools/ab_nt.py, repeated launches) never slower from 40 MB up and up to 11-13 % faster (48-64 MB CLT sweeps 13.4 -> 11.9 and
-// 16.1 -> 14.7 us; 480 MB - 1.6 GB scans 0.68-0.72 -> 0.76-0.80 of 8 TB/s); below 32 MB plain loads keep 0.1-0.3 us (L2-resident)
-constexpr size_t kStreamBytes = 40ull << 20;
+// MI355X: a sweep beyond the Infinity Cache is streamed with non-temporal loads (+9-15 % on 0.3-8 GB scans).  Below it the
+// two load flavours trade places with how the launches are issued (profiles/round3_nt_policy.txt: on the stream the plan
+// warmed up on, non-temporal loads are up to 11 % faster from 48 MB; on a stream the plan has not run on before they cost
+// 1.5-2 us per launch at every size) — so the switch stays where both agree.  AQE_NT=0/1 forces it per plan (diagnostics).
+constexpr size_t kInfinityCacheBytes = 256ull << 20;
 constexpr size_t kGraphMinRounds = 4, kGraphMaxRounds = 8192;  // one-launch-per-round plans replayed as a HIP graph
 
 }  // namespace aqe

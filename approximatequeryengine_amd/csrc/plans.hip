@@ -629,7 +629,7 @@ int create_plan(aqe_ctx* c, const aqe_query* q, aqe_plan** out, const GivenFamil
     {   // (what one execution sweeps, in bytes of this shard: decides the load policy, sweep_common)
         uint64_t swept = p->host.has_topup ? p->topup.samples : 0;
         for (const LaunchDesc& L : p->rounds) swept += L.samples;
-        p->nt = swept * sizeof(double) > kStreamBytes;
+        p->nt = swept * sizeof(double) > kInfinityCacheBytes;
         if (const char* e = std::getenv("AQE_NT")) p->nt = e[0] == '1';  // diagnostics (tools/ab_nt.py): force the load policy, read per plan
     }
     {   // persistent single-launch forms of the rounds
@@ -1323,7 +1323,7 @@ int build_multi(aqe_batch* b, int kind, double* dev_totals, uint64_t row_stride)
         }
         uni += cur_hi - cur_lo;
         const double overlap = uni ? static_cast<double>(sum_len) / static_cast<double>(uni) : 1.0;
-        m.nt = overlap < 1.5 && static_cast<double>(swept) * sizeof(double) / overlap > static_cast<double>(kStreamBytes);
+        m.nt = overlap < 1.5 && static_cast<double>(swept) * sizeof(double) / overlap > static_cast<double>(kInfinityCacheBytes);
     }
     m.totals = dev_totals;
     m.stride = row_stride;

@@ -14,15 +14,19 @@ for rows in [int(a) for a in sys.argv[1:]] or (20_000_000, 40_000_000, 60_000_00
              ("CLT e=0.01%", make_query(nat.M_CLT_DUAL_POINTER, 20.0, agg=nat.AVG, max_error_percent=0.01, clt_round0=4096, clt_growth=4))]
     for name, q in cases:
         line = []
-        for mode in ("0", "1", "0", "1"):
+        for mode in (("1", "0", "1", "0") if os.environ.get("AB_ORDER") == "swap" else ("0", "1", "0", "1")):
             os.environ["AQE_NT"] = mode
             p = eng.plan(q)
             for _ in range(5):
                 p.enqueue_all(st); r = p.fetch(st)
             p.set_profiling(True)
             us = []
+            own = torch.cuda.Stream() if os.environ.get("AB_FRESH") == "1" else None  # (bench.py times a case on a stream of its own)
+            ts = own.cuda_stream if own is not None else st
+            if os.environ.get("AB_SYNC") == "1":
+                torch.cuda.synchronize()
             for _ in range(30):
-                p.enqueue_all(st); r = p.fetch(st)
+                p.enqueue_all(ts); r = p.fetch(ts)
                 us.append(1e3 * sum(p.launch_ms()))
             p.set_profiling(False)
             med = statistics.median(us)
