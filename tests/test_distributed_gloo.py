@@ -230,3 +230,58 @@ def test_variance_aware_samplers_over_gloo_match_the_whole_table(oracle, tmp_pat
         assert sum(x["local_rows"] for x in got) == m.n
         assert abs(g["sum"] - m.sum) <= 1e-12 * abs(m.sum), (kind, pct, a, b)
         assert abs(g["m2"] - m.m2) <= 1e-9 * abs(m.m2)
+
+
+def test_sorted_position_helpers_on_the_host():
+    """The pieces of sharded_stratified_plan that are plain arithmetic: the order-preserving map double <-> uint64 the
+    bisection walks, the runs of consecutive rows of a family, and the global -> local position map on one process with three
+    in-memory shards (every collective a sum over the shards), ties included."""
+    from fake_engine import OracleShardEngine
+    from approximatequeryengine_amd import _native as nat
+    from approximatequeryengine_amd.distributed import _double_to_key, _family_runs, _key_to_double, sorted_positions_to_local
+    v = np.array([-np.inf, -1e300, -2.5, -5e-324, -0.0, 0.0, 5e-324, 1.0, 1.0000000000000002, 1e300, np.inf])
+    k = _double_to_key(v)
+    assert np.all(k[1:] >= k[:-1]) and np.array_equal(_key_to_double(k).view(np.uint64), v.view(np.uint64))
+    fams = [nat.Family(row0=5, pitch=0, seg_len=2**64 - 1, step=1, ord_lo=3, ord_hi=10), nat.Family(row0=100, pitch=50, seg_len=7, step=1, ord_lo=5, ord_hi=16)]
+    s, l = _family_runs(fams)
+    assert s.tolist() == [8, 105, 150, 200] and l.tolist() == [7, 2, 7, 2]
+    with pytest.raises(ValueError):
+        _family_runs([nat.Family(row0=0, pitch=0, seg_len=8, step=2, ord_lo=0, ord_hi=8)])
+    # three shards of a table whose amounts tie by the dozen; the "group" is a loop over the shards
+    rng = np.random.default_rng(3)
+    n = 5_000
+    amount = np.round(rng.normal(500.0, 40.0, n))
+    cuts = [0, 1_700, 1_701, n]
+    rows = np.zeros(n, dtype=[("amount", "f8")])
+    rows["amount"] = amount
+    engs = [OracleShardEngine(rows[a:b], a, n, 500.0) for a, b in zip(cuts[:-1], cuts[1:])]
+    pos = np.unique(np.concatenate([rng.integers(0, n + 1, 200), [0, 1, n - 1, n]])).astype(np.uint64)
+    # run the three "ranks" in lockstep: every host_all_reduce call sums what the three contribute at the same step
+    import threading
+    box, bar = [None] * 3, threading.Barrier(3)
+    out = [None] * 3
+
+    def rank(r):
+        def ar(a):
+            box[r] = np.asarray(a, dtype=np.float64).copy()
+            bar.wait()
+            tot = box[0] + box[1] + box[2]
+            bar.wait()
+            return tot
+        out[r] = sorted_positions_to_local(engs[r], pos, n, ar, r, 3)
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(3)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    tot = out[0].astype(np.int64) + out[1].astype(np.int64) + out[2].astype(np.int64)
+    assert np.array_equal(tot, pos.astype(np.int64))  # the local positions add up to the global one
+    srt = np.sort(amount)
+    for r, e in enumerate(engs):
+        L = out[r].astype(np.int64)
+        assert np.all(L[1:] >= L[:-1]) and L[0] == 0 and L[-1] == len(e.sorted)
+        # the first L rows of the shard's sorted column are rows of the global prefix: none exceeds the value at the global position
+        for p, l in zip(pos.astype(np.int64), L):
+            if 0 < l and p < n:
+                assert e.sorted[l - 1] <= srt[p]
+            if l < len(e.sorted) and p > 0:
+                assert e.sorted[l] >= srt[p - 1]
