@@ -258,7 +258,7 @@ AQE_API int aqe_table_info_get(const aqe_ctx* ctx, aqe_table_info* out);
  * never defined BPlusTreeNode::search_range (DB.hpp:45) would have pruned to.  Needs the whole table in this
  * context, and either dense ids (id = first_id + row, detected at staging) or the rows resident (KEEP_AOS). */
 AQE_API int aqe_key_range_rows(aqe_ctx* ctx, int64_t id_min, int64_t id_max, uint64_t* row_lo, uint64_t* row_hi);
-/* The same for a SHARDED table: how many of THIS context's rows have id < id_min (*n_below) and id <= id_max (*n_upto).  Ids
+/* The same (BPlusTreeNode::search_range, DB.hpp:45; leaf order DB.cpp:715-735) for a SHARDED table: how many of THIS context's rows have id < id_min (*n_below) and id <= id_max (*n_upto).  Ids
  * ascend over the whole table, so the global window is [sum of n_below, sum of n_upto) over the ranks: one all-reduce SUM of
  * two numbers, then aqe_query.row_lo / row_hi as above on every rank. */
 AQE_API int aqe_key_range_counts(aqe_ctx* ctx, int64_t id_min, int64_t id_max, uint64_t* n_below, uint64_t* n_upto);
@@ -478,6 +478,9 @@ AQE_API int aqe_batch_run_sharded(aqe_batch* batch, aqe_comm* comm, double* dev_
  * (xGMI peers) every rank owns a MAILBOX in its own HBM; an all-reduce is ONE single-workgroup launch per rank that stores
  * the rank's vector into its slot of every peer's mailbox, raises a flag there, waits for the peers' flags in its own mailbox
  * and adds the slots up in rank order (so every rank holds the same sum, bit for bit — what the shared stop decision needs).
+ * Replaces, like aqe_comm_*: the reference's in-process merges of its workers' results — the mutex-guarded vector, the
+ * future.get() concatenation, the CAS loop on atomic<double> (DB.cpp:948-951, 966-967, 2031-2036) — and the atomic<bool>
+ * should_stop every worker polls (DB.cpp:930, 987): every rank derives the same decision from the same sum.
  * A drop-in for aqe_comm_all_reduce_sum between the sweep and the fold:
  *     aqe_mailbox_create(ctx, nranks, rank, &mb)
  *     one process per GPU:  aqe_mailbox_handle(mb, h) -> exchange the 64-byte handles out of band, in rank order ->
